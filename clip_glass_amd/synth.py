@@ -1,0 +1,245 @@
+"""Deterministic synthetic weights / noise / inputs: value = f(seed, name, shape).
+
+There is no network and no pretrained checkpoint in this environment, so every
+test, the oracle and bench.py regenerate the *same* tensors from (seed, name)
+with numpy's PCG64.  Names are the reference's own state-dict keys
+(stylegan2/models.py:111-132 container: sub-dicts `G_mapping`, `G_synthesis`;
+clip/model.py:363-399 for CLIP), prefixed with the sub-model
+(`G_mapping.`, `G_synthesis.`, `D.`, `clip.`), so a real checkpoint loaded by
+the host shim goes through exactly the same `load_tensor(name, array)` calls.
+
+Distributions follow the reference initialisers so activations have sane
+magnitudes (modules.py:87-118 `_get_weight_and_coef`: stored weight ~
+N(0, 1/lr_mul), runtime coefficient applied every forward; biases = fill value,
+perturbed here so the bias paths are exercised; noise strengths initialise to 0
+in the reference (modules.py:326) and are set non-zero here for the same reason).
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+FFHQ_CHANNELS = [32, 64, 128, 256, 512, 512, 512, 512, 512]  # 1024px config-f, G order last->first
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), zlib.crc32(name.encode())])))
+
+
+def normal(seed, name, shape, std=1.0, mean=0.0):
+    return (_rng(seed, name).standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# StyleGAN2 architecture bookkeeping (own restatement of the layer list that
+# stylegan2/models.py:771-896 (G) and :1043-1191 (D) build).
+# --------------------------------------------------------------------------
+def g_layers(channels):
+    """Synthesis conv layers in execution order.
+
+    Returns list of dicts(name, cin, cout, res, up, latent_idx) for the 1+2*(n-1)
+    modulated 3x3 convs and list of toRGB dicts(name, cin, res, latent_idx).
+    `channels` is in the reference's G order (last layer -> first layer)."""
+    n = len(channels)
+    convs, rgbs = [], []
+    res = 4
+    li = 0
+    for b in range(n):
+        cin = channels[-1] if b == 0 else channels[-b]
+        cout = channels[-1] if b == 0 else channels[-b - 1]
+        nl = 1 if b == 0 else 2
+        if b > 0:
+            res *= 2
+        for l in range(nl):
+            convs.append(dict(name="conv_blocks.%d.conv_block.%d" % (b, l),
+                              cin=cin if l == 0 else cout, cout=cout, res=res,
+                              up=(b > 0 and l == 0), latent_idx=li))
+            li += 1
+        rgbs.append(dict(name="to_data_layers.%d" % b, cin=cout, res=res, latent_idx=li))
+    return convs, rgbs
+
+
+def stylegan2_g_spec(channels=FFHQ_CHANNELS, latent_size=512, mapping_layers=8, data_channels=3):
+    """(name, shape, kind) for every tensor of G (mapping + synthesis)."""
+    spec = []
+    for i in range(mapping_layers):
+        spec.append(("G_mapping.main.%d.layer.weight" % i, (latent_size, latent_size), "w_map"))
+        spec.append(("G_mapping.main.%d.bias" % i, (latent_size,), "b_map"))
+    spec.append(("G_synthesis.const", (channels[-1], 4, 4), "const"))
+    convs, rgbs = g_layers(channels)
+    for c in convs:
+        p = "G_synthesis." + c["name"]
+        spec.append((p + ".layer.layer.weight", (c["cout"], c["cin"], 3, 3), "w"))
+        spec.append((p + ".layer.layer.dense.layer.weight", (c["cin"], latent_size), "w"))
+        spec.append((p + ".layer.layer.dense.bias", (c["cin"],), "b_style"))
+        spec.append((p + ".layer.weight", (1,), "noise_strength"))
+        spec.append((p + ".bias", (c["cout"],), "b"))
+    for r in rgbs:
+        p = "G_synthesis." + r["name"]
+        spec.append((p + ".layer.weight", (data_channels, r["cin"], 1, 1), "w"))
+        spec.append((p + ".layer.dense.layer.weight", (r["cin"], latent_size), "w"))
+        spec.append((p + ".layer.dense.bias", (r["cin"],), "b_style"))
+        spec.append((p + ".bias", (data_channels,), "b"))
+    return spec
+
+
+def stylegan2_d_spec(channels=FFHQ_CHANNELS, data_channels=3):
+    """(name, shape, kind) for every tensor of D. `channels` in D order (first->last)."""
+    n = len(channels)
+    spec = [("D.from_data_layers.0.layer.weight", (channels[0], data_channels, 1, 1), "w"),
+            ("D.from_data_layers.0.bias", (channels[0],), "b")]
+    for i in range(n - 1):
+        p = "D.conv_blocks.%d" % i
+        spec.append((p + ".conv_block.0.layer.weight", (channels[i], channels[i], 3, 3), "w"))
+        spec.append((p + ".conv_block.0.bias", (channels[i],), "b"))
+        spec.append((p + ".conv_block.1.layer.weight", (channels[i + 1], channels[i], 3, 3), "w"))
+        spec.append((p + ".conv_block.1.bias", (channels[i + 1],), "b"))
+        spec.append((p + ".projection.weight", (channels[i + 1], channels[i], 1, 1), "w"))
+    p = "D.conv_blocks.%d.1" % (n - 1)
+    spec.append((p + ".conv_block.0.layer.weight", (channels[-1], channels[-1] + 1, 3, 3), "w"))
+    spec.append((p + ".conv_block.0.bias", (channels[-1],), "b"))
+    spec.append(("D.dense.0.layer.weight", (channels[-1], channels[-1] * 16), "w"))
+    spec.append(("D.dense.0.bias", (channels[-1],), "b"))
+    spec.append(("D.dense.1.layer.weight", (1, channels[-1]), "w"))
+    spec.append(("D.dense.1.bias", (1,), "b"))
+    return spec
+
+
+def clip_visual_spec(width=768, layers=12, patch=32, res=224, out_dim=512):
+    """(name, shape, kind) of the CLIP visual tower (clip/model.py:201-216,166-178)."""
+    n_tok = (res // patch) ** 2 + 1
+    s = width ** -0.5
+    spec = [("clip.visual.conv1.weight", (width, 3, patch, patch), ("n16", (3 * patch * patch) ** -0.5)),
+            ("clip.visual.class_embedding", (width,), ("n", s)),
+            ("clip.visual.positional_embedding", (n_tok, width), ("n", s)),
+            ("clip.visual.ln_pre.weight", (width,), ("ln_w", 0.1)),
+            ("clip.visual.ln_pre.bias", (width,), ("n", 0.1))]
+    proj_std = s * (2 * layers) ** -0.5
+    for i in range(layers):
+        p = "clip.visual.transformer.resblocks.%d." % i
+        spec += [(p + "ln_1.weight", (width,), ("ln_w", 0.1)), (p + "ln_1.bias", (width,), ("n", 0.1)),
+                 (p + "attn.in_proj_weight", (3 * width, width), ("n16", s)),
+                 (p + "attn.in_proj_bias", (3 * width,), ("n16", 0.02)),
+                 (p + "attn.out_proj.weight", (width, width), ("n16", proj_std)),
+                 (p + "attn.out_proj.bias", (width,), ("n16", 0.02)),
+                 (p + "ln_2.weight", (width,), ("ln_w", 0.1)), (p + "ln_2.bias", (width,), ("n", 0.1)),
+                 (p + "mlp.c_fc.weight", (4 * width, width), ("n16", (2 * width) ** -0.5)),
+                 (p + "mlp.c_fc.bias", (4 * width,), ("n16", 0.02)),
+                 (p + "mlp.c_proj.weight", (width, 4 * width), ("n16", proj_std)),
+                 (p + "mlp.c_proj.bias", (width,), ("n16", 0.02))]
+    spec += [("clip.visual.ln_post.weight", (width,), ("ln_w", 0.1)),
+             ("clip.visual.ln_post.bias", (width,), ("n", 0.1)),
+             ("clip.visual.proj", (width, out_dim), ("n16", s))]
+    return spec
+
+
+def clip_text_spec(width=512, layers=12, ctx=77, vocab=49408, out_dim=512):
+    """(name, shape, kind) of the CLIP text tower (clip/model.py:277-290); init stds follow
+    OpenAI's initialize_parameters (not in the vendored file)."""
+    s = width ** -0.5
+    proj_std = s * (2 * layers) ** -0.5
+    spec = [("clip.token_embedding.weight", (vocab, width), ("n", 0.02)),
+            ("clip.positional_embedding", (ctx, width), ("n", 0.01))]
+    for i in range(layers):
+        p = "clip.transformer.resblocks.%d." % i
+        spec += [(p + "ln_1.weight", (width,), ("ln_w", 0.1)), (p + "ln_1.bias", (width,), ("n", 0.1)),
+                 (p + "attn.in_proj_weight", (3 * width, width), ("n16", s)),
+                 (p + "attn.in_proj_bias", (3 * width,), ("n16", 0.02)),
+                 (p + "attn.out_proj.weight", (width, width), ("n16", proj_std)),
+                 (p + "attn.out_proj.bias", (width,), ("n16", 0.02)),
+                 (p + "ln_2.weight", (width,), ("ln_w", 0.1)), (p + "ln_2.bias", (width,), ("n", 0.1)),
+                 (p + "mlp.c_fc.weight", (4 * width, width), ("n16", (2 * width) ** -0.5)),
+                 (p + "mlp.c_fc.bias", (4 * width,), ("n16", 0.02)),
+                 (p + "mlp.c_proj.weight", (width, 4 * width), ("n16", proj_std)),
+                 (p + "mlp.c_proj.bias", (width,), ("n16", 0.02))]
+    spec += [("clip.ln_final.weight", (width,), ("ln_w", 0.1)), ("clip.ln_final.bias", (width,), ("n", 0.1)),
+             ("clip.text_projection", (width, out_dim), ("n16", s)),
+             ("clip.logit_scale", (), ("n", 0.0))]
+    return spec
+
+
+def make_tensor(seed, name, shape, kind, map_lr_mul=0.01):
+    if isinstance(kind, tuple):
+        k, std = kind
+        if k == "ln_w":
+            return normal(seed, name, shape, std, 1.0)
+        t = normal(seed, name, shape, std)
+        if k == "n16":  # convert_weights (clip/model.py:339-360): stored as fp16
+            t = t.astype(np.float16).astype(np.float32)
+        return t
+    if kind == "w":
+        return normal(seed, name, shape, 1.0)
+    if kind == "w_map":
+        return normal(seed, name, shape, 1.0 / map_lr_mul)
+    if kind == "b":
+        return normal(seed, name, shape, 0.2)
+    if kind == "b_map":
+        return normal(seed, name, shape, 0.2 / map_lr_mul)
+    if kind == "b_style":
+        return normal(seed, name, shape, 0.2, 1.0)
+    if kind == "noise_strength":
+        return normal(seed, name, shape, 0.2)
+    if kind == "const":
+        return normal(seed, name, shape, 1.0)
+    raise ValueError(kind)
+
+
+def make_state(spec, seed=0):
+    return OrderedDict((name, make_tensor(seed, name, shape, kind)) for name, shape, kind in spec)
+
+
+# --------------------------------------------------------------------------
+# Counter-based noise: Philox4x32-10 + Box-Muller.  Numpy mirror of the device
+# generator in csrc/noise.hip, so the oracle can be fed bit-compatible noise
+# (up to libm differences ~1e-6 in log/cos).  Noise is a pure function of
+# (seed, generation, global minibatch index, layer, pixel) -> shard-invariant
+# (SURVEY 8(e)).  Reference draws `normal_()` per G call: modules.py:428-452.
+# --------------------------------------------------------------------------
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint32) for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0); k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for _ in range(10):
+            p0 = c0.astype(np.uint64) * _M0
+            p1 = c2.astype(np.uint64) * _M1
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32); lo0 = p0.astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32); lo1 = p1.astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32((int(k0) + int(_W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(_W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def noise_plane(seed, generation, minibatch, layer, h, w):
+    """N(0,1) plane [h,w] float32 — device-compatible (csrc/noise.hip)."""
+    n = h * w
+    nq = (n + 3) // 4
+    idx = np.arange(nq, dtype=np.uint32)
+    r = philox4x32(idx, np.uint32(layer), np.uint32(minibatch), np.uint32(generation),
+                   np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    u = [(x.astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -32) for x in r]
+    out = np.empty((nq, 4), dtype=np.float32)
+    two_pi = np.float32(6.283185307179586)
+    for j in (0, 1):
+        rad = np.sqrt(np.float32(-2.0) * np.log(u[2 * j])).astype(np.float32)
+        ang = (two_pi * u[2 * j + 1]).astype(np.float32)
+        out[:, 2 * j] = rad * np.cos(ang)
+        out[:, 2 * j + 1] = rad * np.sin(ang)
+    return out.reshape(-1)[:n].reshape(h, w)
+
+
+def g_noise_planes(seed, generation, minibatch, channels=FFHQ_CHANNELS):
+    """The 1+2*(n-1) noise planes of one G call (one minibatch), execution order."""
+    convs, _ = g_layers(channels)
+    return [noise_plane(seed, generation, minibatch, i, c["res"], c["res"]) for i, c in enumerate(convs)]
+
+
+def latents(seed, pop, dim=512):
+    """RandomState(seed).normal(size=(pop, dim)) float64 — matches NormalRandomSampling
+    (operators.py:24-25) and SURVEY 8(d)."""
+    return np.random.RandomState(seed).normal(size=(pop, dim))
