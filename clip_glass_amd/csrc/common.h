@@ -1,0 +1,61 @@
+// common.h — shared types for the gfx950 kernels (wave64, MFMA f16 -> f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16x __attribute__((ext_vector_type(16)));
+
+#define GLASS_SQRT2 1.41421356237309504880f
+
+// v_mfma_f32_32x32x16_f16: D[32x32] += A[32x16] * B[16x32].
+// lane l holds A[i = l&31][k = (l>>5)*8 + j] and B[k = (l>>5)*8 + j][n = l&31], j = 0..7;
+// D register r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31].
+__device__ __forceinline__ f16x mfma32(h8 a, h8 b, f16x c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * GLASS_SQRT2; }
+
+// Parameters of one convolution launch (implicit GEMM, NHWC fp16 activations).
+// GEMM view: M = B*Hc*Wc (conv grid), N = Neff, K = KS*KS*Cin.
+struct ConvParams {
+    const half_t* x;        // input  [B][H][W][Cin]
+    long long x_bstride;    // elements between images (0 = broadcast, e.g. the learned const)
+    int B, H, W, Cin;
+    int Hc, Wc;             // conv grid (== output grid unless up)
+    int KS, stride, pad;
+    const half_t* w;        // [KS*KS][Neff][Cin], Cin contiguous
+    int Neff, Cout;         // Neff = Cout * (up ? 4 : 1); n = phase*Cout + o
+    int up;                 // 1: depth-to-space 2x2 (folded transposed conv + FIR)
+    int Ho, Wo;             // output grid
+    const float* sn;        // [B][sn_stride] normalised style (nullable)
+    int sn_stride;
+    const float* dscale;    // [B][ds_stride] demod * smax (nullable)
+    int ds_stride;
+    const float* noise;     // [n_minibatch][Ho][Wo] (nullable)
+    float noise_strength;
+    int batch_size;         // candidates per noise plane
+    const float* bias;      // [Cout] (nullable)
+    int act;                // 1: leaky-relu(0.2) * sqrt(2)
+    const half_t* res;      // residual [B][Ho][Wo][Cout] added after activation (nullable)
+    float out_scale;
+    half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
+    float* y32;             // output fp32, same layout
+};
+
+struct GemmParams {
+    const half_t* a;  // [M][K]
+    const half_t* w;  // [N][K]
+    int M, N, K;
+    const float* bias;  // [N] nullable
+    int mode;           // 0: out16 = v ; 1: out16 = quickgelu(v) ; 2: x32 += v (in place) ; 3: out32 = v ; 4: out32 = lrelu(v)*sqrt2
+    half_t* out16;
+    float* out32;
+    int ldo;
+};

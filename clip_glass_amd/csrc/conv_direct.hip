@@ -1,0 +1,184 @@
+// conv_direct.hip — generic MFMA implicit-GEMM convolution / GEMM, operands straight
+// from global memory (no LDS).  This is the shape-agnostic path: it serves the
+// low-resolution layers (W < 32), odd shapes and every test as the in-library
+// cross-check of the LDS-tiled kernel (conv_tiled.hip).  Same epilogue contract.
+//
+// Replaces, per layer, the reference's per-sample weight materialisation + grouped
+// conv (stylegan2/modules.py:920-967) by activation-side modulation:
+//   conv(x, W*s*d) == d[b,o] * conv(x * s[b,i], W)      (SURVEY 8a note 1)
+// and the transposed conv + FIR (modules.py:1089-1139) by a 3x3 conv I -> 4*O with
+// the FIR folded into four phase kernels + depth-to-space (engine.cpp fold_upconv()).
+#include "common.h"
+#include "kernels.h"
+
+template <int NW>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const long long M = (long long)p.B * p.Hc * p.Wc;
+    const long long mw = (long long)blockIdx.x * 128 + wave * 32;  // first GEMM row of this wave
+    const int n0 = blockIdx.y * (32 * NW);
+    const long long m = mw + r;
+    const bool mvalid = m < M;
+    int b = 0, oy = 0, ox = 0;
+    if (mvalid) {
+        const int hw = p.Hc * p.Wc;
+        b = (int)(m / hw);
+        const int rem = (int)(m - (long long)b * hw);
+        oy = rem / p.Wc;
+        ox = rem - oy * p.Wc;
+    }
+    f16x acc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+    const half_t* xb = p.x + (long long)b * p.x_bstride;
+    const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + kh * 8 : nullptr;
+    for (int ty = 0; ty < p.KS; ++ty) {
+        for (int tx = 0; tx < p.KS; ++tx) {
+            const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
+            const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const half_t* xp = xb + ((long long)iy * p.W + ix) * p.Cin + kh * 8;
+            const half_t* wp = p.w + ((long long)(ty * p.KS + tx) * p.Neff + n0 + r) * p.Cin + kh * 8;
+            for (int i0 = 0; i0 < p.Cin; i0 += 16) {
+                h8 a;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = (half_t)0.f;
+                if (v) {
+                    a = *(const h8*)(xp + i0);
+                    if (snb) {
+                        const f4 s0 = *(const f4*)(snb + i0), s1 = *(const f4*)(snb + i0 + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            a[j] = (half_t)((float)a[j] * s0[j]);
+                            a[j + 4] = (half_t)((float)a[j + 4] * s1[j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nw = 0; nw < NW; ++nw) {
+                    h8 bf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[j] = (half_t)0.f;
+                    if (n0 + nw * 32 + r < p.Neff) bf = *(const h8*)(wp + (long long)nw * 32 * p.Cin + i0);
+                    acc[nw] = mfma32(a, bf, acc[nw]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: demod, noise, bias, activation, residual, store -------------
+    const int col = lane & 31;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = mfma32_row(reg, lane);
+        const int rb = __shfl(b, row), ry = __shfl(oy, row), rx = __shfl(ox, row);
+        const bool rvalid = (mw + row) < M;
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw) {
+            const int n = n0 + nw * 32 + col;
+            if (!rvalid || n >= p.Neff) continue;
+            int o = n, py = ry, px = rx;
+            if (p.up) {
+                const int ph = n / p.Cout;
+                o = n - ph * p.Cout;
+                py = 2 * ry + (ph >> 1);
+                px = 2 * rx + (ph & 1);
+            }
+            float val = acc[nw][reg];
+            if (p.dscale) val *= p.dscale[(long long)rb * p.ds_stride + o];
+            if (p.noise) val += p.noise_strength * p.noise[((long long)(rb / p.batch_size) * p.Ho + py) * p.Wo + px];
+            if (p.bias) val += p.bias[o];
+            if (p.act) val = lrelu_sqrt2(val);
+            const long long oidx = (((long long)rb * p.Ho + py) * p.Wo + px) * p.Cout + o;
+            if (p.res) val += (float)p.res[oidx];
+            val *= p.out_scale;
+            if (p.y32) p.y32[oidx] = val;
+            else p.y[oidx] = (half_t)val;
+        }
+    }
+}
+
+void launch_conv_direct(const ConvParams& p, hipStream_t st) {
+    const long long M = (long long)p.B * p.Hc * p.Wc;
+    const unsigned gx = (unsigned)((M + 127) / 128);
+    if (p.Neff > 64) {
+        dim3 g(gx, (p.Neff + 127) / 128);
+        hipLaunchKernelGGL(conv_direct_kernel<4>, g, dim3(256), 0, st, p);
+    } else if (p.Neff > 32) {
+        dim3 g(gx, 1);
+        hipLaunchKernelGGL(conv_direct_kernel<2>, g, dim3(256), 0, st, p);
+    } else {
+        dim3 g(gx, 1);
+        hipLaunchKernelGGL(conv_direct_kernel<1>, g, dim3(256), 0, st, p);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// GEMM  out[M][N] = A[M][K] * W[N][K]^T  (+bias, epilogue modes) — CLIP linears,
+// patch embedding, D dense0.  Replaces nn.Linear / conv1 of clip/model.py:166-235.
+// ---------------------------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int mw = blockIdx.x * 128 + wave * 32;
+    const int n0 = blockIdx.y * (32 * NW);
+    const int m = mw + r;
+    const bool mvalid = m < p.M;
+    f16x acc[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const half_t* ap = p.a + (long long)m * p.K + kh * 8;
+    const half_t* wp = p.w + (long long)(n0 + r) * p.K + kh * 8;
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+        h8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (half_t)0.f;
+        if (mvalid) a = *(const h8*)(ap + k0);
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw) {
+            h8 bf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = (half_t)0.f;
+            if (n0 + nw * 32 + r < p.N) bf = *(const h8*)(wp + (long long)nw * 32 * p.K + k0);
+            acc[nw] = mfma32(a, bf, acc[nw]);
+        }
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int mr = mw + mfma32_row(reg, lane);
+        if (mr >= p.M) continue;
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw) {
+            const int n = n0 + nw * 32 + col;
+            if (n >= p.N) continue;
+            float v = acc[nw][reg];
+            if (p.bias) v += p.bias[n];
+            const long long oi = (long long)mr * p.ldo + n;
+            switch (p.mode) {
+                case 0: p.out16[oi] = (half_t)v; break;
+                case 1: p.out16[oi] = (half_t)(v / (1.f + __expf(-1.702f * v))); break;  // QuickGELU
+                case 2: p.out32[oi] += v; break;
+                case 3: p.out32[oi] = v; break;
+                default: p.out32[oi] = lrelu_sqrt2(v); break;
+            }
+        }
+    }
+}
+
+void launch_gemm_direct(const GemmParams& p, hipStream_t st) {
+    const unsigned gx = (unsigned)((p.M + 127) / 128);
+    if (p.N > 64) {
+        hipLaunchKernelGGL(gemm_direct_kernel<4>, dim3(gx, (p.N + 127) / 128), dim3(256), 0, st, p);
+    } else if (p.N > 32) {
+        hipLaunchKernelGGL(gemm_direct_kernel<2>, dim3(gx, 1), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL(gemm_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
+    }
+}

@@ -1,0 +1,989 @@
+// engine.cpp — C ABI (include/glass.h) + orchestration of the fitness pass.
+//
+// Host-side mirror of problem.py:14-29 / generator.py:29-60 / models.py:108-129:
+//   latents -> mapping -> styles/demod -> [per chunk: synthesis -> toRGB/skip -> resize -> D] -> CLIP -> F
+// One engine per (process, GPU); one private stream; weights repacked once in finalize().
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+static thread_local std::string g_err;
+void glass_set_error(const std::string& s) { g_err = s; }
+extern "C" const char* glass_last_error(void) { return g_err.c_str(); }
+extern "C" const char* glass_version(void) { return "clip-glass-amd 0.1 (gfx950)"; }
+
+#define REQUIRE(cond, code, msg)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            glass_set_error(msg);         \
+            return code;                  \
+        }                                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// allocation / upload helpers
+// ------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(glass_engine* e, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (err != hipSuccess) {
+        glass_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_NOMEM;
+    }
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return GLASS_OK;
+}
+template <typename T>
+static int upload(glass_engine* e, T** p, const std::vector<T>& v) {
+    int rc = dev_alloc(e, p, v.size());
+    if (rc) return rc;
+    GLASS_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GLASS_OK;
+}
+
+static const HostTensor* find(glass_engine* e, const std::string& name) {
+    auto it = e->host.find(name);
+    return it == e->host.end() ? nullptr : &it->second;
+}
+#define GET(var, name)                                                            \
+    const HostTensor* var = find(e, name);                                        \
+    REQUIRE(var != nullptr, GLASS_ERR_STATE, std::string("missing tensor: ") + (name))
+
+static size_t numel(const HostTensor* t) {
+    size_t n = 1;
+    for (auto d : t->dims) n *= (size_t)d;
+    return n;
+}
+
+// ------------------------------------------------------------------------------------
+// weight repacking (reference layouts -> kernel layouts)
+// ------------------------------------------------------------------------------------
+// plain conv: W[o][i][ky][kx] * coef -> [tap][o][i_pad] fp16
+void glass_pack_conv(const float* W, int cout, int cin, int ks, int cin_pad, std::vector<_Float16>& out) {
+    const float coef = 1.0f / sqrtf((float)cin * ks * ks);  // modules.py:103-108 (gain 1, lr_mul 1)
+    out.assign((size_t)ks * ks * cout * cin_pad, (_Float16)0.f);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < ks * ks; ++t)
+                out[((size_t)t * cout + o) * cin_pad + i] = (_Float16)(W[((size_t)o * cin + i) * ks * ks + t] * coef);
+}
+
+// up conv: conv_transpose2d(stride 2, 3x3) followed by the 4x4 FIR (gain 4, pad 1)
+// (modules.py:1089-1139) == 3x3 conv (pad 1) with 4 phase kernels + depth-to-space.
+//   1-D: t[q] = sum_i x[i] w[q-2i];  out[p] = sum_j f[j] t[p+j-1]  =>  out[p] = sum_i x[i] g[p-2i],
+//   g[r] = sum_j f[j] w[r+j-1], r in [-2,3];  out[2m+ph] = sum_{d=0..2} x[m-1+d] g[(2+ph)-2d].
+// Output layout [tap = dy*3+dx][n = (py*2+px)*cout + o][i].
+int glass_fold_upconv(const float* W, int cout, int cin, std::vector<_Float16>& out) {
+    const float coef = 1.0f / sqrtf((float)cin * 9.f);
+    const float f1[4] = {1.f, 3.f, 3.f, 1.f};
+    float F[4][4];
+    for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) F[a][b] = f1[a] * f1[b] / 64.f * 4.f;  // modules.py:201-202, up_factor^2
+    out.assign((size_t)9 * 4 * cout * cin, (_Float16)0.f);
+    std::vector<float> g(36);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i) {
+            const float* w = W + ((size_t)o * cin + i) * 9;
+            for (int ry = -2; ry <= 3; ++ry)
+                for (int rx = -2; rx <= 3; ++rx) {
+                    float s = 0.f;
+                    for (int jy = 0; jy < 4; ++jy) {
+                        const int ky = ry + jy - 1;
+                        if (ky < 0 || ky > 2) continue;
+                        for (int jx = 0; jx < 4; ++jx) {
+                            const int kx = rx + jx - 1;
+                            if (kx < 0 || kx > 2) continue;
+                            s += F[jy][jx] * w[ky * 3 + kx];
+                        }
+                    }
+                    g[(ry + 2) * 6 + (rx + 2)] = s * coef;
+                }
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px)
+                    for (int dy = 0; dy < 3; ++dy)
+                        for (int dx = 0; dx < 3; ++dx) {
+                            const int ry = (2 + py) - 2 * dy, rx = (2 + px) - 2 * dx;
+                            out[((size_t)(dy * 3 + dx) * 4 * cout + (size_t)(py * 2 + px) * cout + o) * cin + i] =
+                                (_Float16)g[(ry + 2) * 6 + (rx + 2)];
+                        }
+        }
+    return 0;
+}
+
+static std::vector<_Float16> to_half(const float* p, size_t n, float scale = 1.f) {
+    std::vector<_Float16> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (_Float16)(p[i] * scale);
+    return v;
+}
+static std::vector<float> scaled(const float* p, size_t n, float scale) {
+    std::vector<float> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = p[i] * scale;
+    return v;
+}
+// W[N][K] * coef -> Wt[K][N]
+static std::vector<float> transposed(const float* W, int N, int K, float coef) {
+    std::vector<float> v((size_t)N * K);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) v[(size_t)k * N + n] = W[(size_t)n * K + k] * coef;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------
+// create / destroy / load
+// ------------------------------------------------------------------------------------
+extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) {
+    REQUIRE(cfg && out, GLASS_ERR_ARG, "null argument");
+    REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= GLASS_MAX_BLOCKS, GLASS_ERR_ARG, "n_blocks out of range");
+    for (int i = 0; i < cfg->n_blocks; ++i)
+        REQUIRE(cfg->channels[i] > 0 && cfg->channels[i] % 16 == 0, GLASS_ERR_ARG,
+                "channels must be positive multiples of 16");
+    REQUIRE(cfg->latent_size > 0 && cfg->latent_size % 4 == 0, GLASS_ERR_ARG, "latent_size must be a multiple of 4");
+    REQUIRE(cfg->batch_size > 0 && cfg->max_pop > 0, GLASS_ERR_ARG, "batch_size/max_pop must be positive");
+    REQUIRE(cfg->max_pop % cfg->batch_size == 0, GLASS_ERR_ARG, "max_pop must be a multiple of batch_size");
+    REQUIRE(cfg->n_obj == 1 || cfg->n_obj == 2, GLASS_ERR_ARG, "n_obj must be 1 or 2");
+    if (cfg->use_discriminator) {
+        REQUIRE(cfg->mbstd_group >= 2 && cfg->mbstd_group <= 8 && cfg->batch_size % cfg->mbstd_group == 0, GLASS_ERR_ARG,
+                "batch_size must be a multiple of mbstd_group (modules.py:716)");
+    }
+    REQUIRE(cfg->clip_width > 0 && cfg->clip_width % 16 == 0 && cfg->clip_heads > 0 &&
+                cfg->clip_width / cfg->clip_heads == 64 && cfg->clip_patch > 0 &&
+                cfg->clip_res % cfg->clip_patch == 0 && (3 * cfg->clip_patch * cfg->clip_patch) % 16 == 0,
+            GLASS_ERR_ARG, "unsupported CLIP geometry (head dim must be 64)");
+    REQUIRE(cfg->noise_mode >= 0 && cfg->noise_mode <= 2, GLASS_ERR_ARG, "noise_mode must be 0,1,2");
+    int ndev = 0;
+    GLASS_HIP(hipGetDeviceCount(&ndev));
+    REQUIRE(cfg->device >= 0 && cfg->device < ndev, GLASS_ERR_ARG, "no such HIP device");
+    GLASS_HIP(hipSetDevice(cfg->device));
+    glass_engine* e = new glass_engine();
+    e->cfg = *cfg;
+    e->R = 4 << (cfg->n_blocks - 1);
+    int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (8 / cfg->batch_size) * cfg->batch_size);
+    chunk = std::min(chunk, cfg->max_pop);
+    if (chunk % cfg->batch_size != 0) {
+        delete e;
+        glass_set_error("chunk must be a multiple of batch_size");
+        return GLASS_ERR_ARG;
+    }
+    e->chunk = chunk;
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev1);
+    if (err != hipSuccess) {
+        delete e;
+        glass_set_error(std::string("stream/event creation failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_HIP;
+    }
+    *out = e;
+    return GLASS_OK;
+}
+
+extern "C" void glass_engine_destroy(glass_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->cfg.device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (void* p : e->allocs) hipFree(p);
+    if (e->h_pinned) hipHostFree(e->h_pinned);
+    for (auto ev : e->event_pool) hipEventDestroy(ev);
+    if (e->ev0) hipEventDestroy(e->ev0);
+    if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int glass_engine_load_tensor(glass_engine* e, const char* name, const float* data, int32_t rank,
+                                        const int64_t* dims) {
+    REQUIRE(e && name && data && rank >= 0 && (rank == 0 || dims), GLASS_ERR_ARG, "null argument");
+    REQUIRE(!e->finalized, GLASS_ERR_STATE, "engine already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < rank; ++i) {
+        REQUIRE(dims[i] > 0, GLASS_ERR_ARG, "non-positive dimension");
+        t.dims.push_back(dims[i]);
+        n *= (size_t)dims[i];
+    }
+    t.data.assign(data, data + n);
+    e->host[name] = std::move(t);
+    return GLASS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// finalize: build every device-side tensor
+// ------------------------------------------------------------------------------------
+static int finalize_generator(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    const int L = c.latent_size;
+    char nm[256];
+    // mapping network (stylegan2/models.py:566-588): weight coef = lr_mul/sqrt(fan_in), bias coef = lr_mul
+    const float lr = 0.01f;
+    for (int i = 0; i < c.mapping_layers; ++i) {
+        snprintf(nm, sizeof nm, "G_mapping.main.%d.layer.weight", i);
+        GET(w, nm);
+        REQUIRE(numel(w) == (size_t)L * L, GLASS_ERR_ARG, std::string("bad shape: ") + nm);
+        snprintf(nm, sizeof nm, "G_mapping.main.%d.bias", i);
+        GET(b, nm);
+        REQUIRE(numel(b) == (size_t)L, GLASS_ERR_ARG, std::string("bad shape: ") + nm);
+        float *dw, *db;
+        int rc = upload(e, &dw, transposed(w->data.data(), L, L, lr / sqrtf((float)L)));
+        if (rc) return rc;
+        rc = upload(e, &db, scaled(b->data.data(), L, lr));
+        if (rc) return rc;
+        e->map_wt.push_back(dw);
+        e->map_b.push_back(db);
+    }
+    // layer list (stylegan2/models.py:812-896, 969-1014)
+    int style_idx = 0, soff = 0, dsoff = 0, noise_idx = 0;
+    for (int b = 0; b < c.n_blocks; ++b) {
+        const int res = 4 << b;
+        const int nl = b == 0 ? 1 : 2;
+        for (int l = 0; l < nl; ++l) {
+            GConv g;
+            g.up = (b > 0 && l == 0);
+            g.cin = (b == 0) ? c.channels[0] : (l == 0 ? c.channels[b - 1] : c.channels[b]);
+            g.cout = c.channels[b];
+            g.res_out = res;
+            g.res_in = g.up ? res / 2 : res;
+            g.style_idx = style_idx++;
+            g.style_off = soff;
+            soff += g.cin;
+            g.ds_off = dsoff;
+            dsoff += g.cout;
+            g.noise_idx = noise_idx++;
+            e->gconv.push_back(g);
+        }
+        GRgb r;
+        r.cin = c.channels[b];
+        r.res = res;
+        r.style_idx = style_idx++;
+        r.style_off = soff;
+        soff += r.cin;
+        e->grgb.push_back(r);
+    }
+    e->n_style = style_idx;
+    e->S_total = soff;
+    e->D_total = dsoff;
+    // style affines, concatenated: s = w @ (A/sqrt(L))^T + b   (modules.py:879-894, 936)
+    std::vector<float> swt((size_t)L * e->S_total), sb((size_t)e->S_total);
+    e->style_off.assign(e->n_style, 0);
+    e->style_len.assign(e->n_style, 0);
+    auto add_style = [&](const std::string& prefix, int sidx, int off, int cin) -> int {
+        GET(A, prefix + ".dense.layer.weight");
+        GET(Ab, prefix + ".dense.bias");
+        REQUIRE(numel(A) == (size_t)cin * L && numel(Ab) == (size_t)cin, GLASS_ERR_ARG, "bad style shape: " + prefix);
+        const float coef = 1.0f / sqrtf((float)L);
+        for (int i = 0; i < cin; ++i) {
+            for (int k = 0; k < L; ++k) swt[(size_t)k * e->S_total + off + i] = A->data[(size_t)i * L + k] * coef;
+            sb[off + i] = Ab->data[i];
+        }
+        e->style_off[sidx] = off;
+        e->style_len[sidx] = cin;
+        return GLASS_OK;
+    };
+    {
+        GET(cst, "G_synthesis.const");
+        const int C0 = c.channels[0];
+        REQUIRE(numel(cst) == (size_t)C0 * 16, GLASS_ERR_ARG, "bad shape: G_synthesis.const");
+        std::vector<_Float16> h((size_t)16 * C0);
+        for (int ch = 0; ch < C0; ++ch)
+            for (int p = 0; p < 16; ++p) h[(size_t)p * C0 + ch] = (_Float16)cst->data[(size_t)ch * 16 + p];
+        int rc = upload(e, &e->g_const, h);
+        if (rc) return rc;
+    }
+    int gi = 0;
+    for (int b = 0; b < c.n_blocks; ++b) {
+        const int nl = b == 0 ? 1 : 2;
+        for (int l = 0; l < nl; ++l, ++gi) {
+            GConv& g = e->gconv[gi];
+            snprintf(nm, sizeof nm, "G_synthesis.conv_blocks.%d.conv_block.%d", b, l);
+            const std::string p = nm;
+            GET(W, p + ".layer.layer.weight");
+            GET(bias, p + ".bias");
+            GET(ns, p + ".layer.weight");
+            REQUIRE(numel(W) == (size_t)g.cout * g.cin * 9 && numel(bias) == (size_t)g.cout && numel(ns) == 1,
+                    GLASS_ERR_ARG, "bad conv shape: " + p);
+            int rc = add_style(p + ".layer.layer", g.style_idx, g.style_off, g.cin);
+            if (rc) return rc;
+            std::vector<_Float16> packed;
+            if (g.up) glass_fold_upconv(W->data.data(), g.cout, g.cin, packed);
+            else glass_pack_conv(W->data.data(), g.cout, g.cin, 3, g.cin, packed);
+            rc = upload(e, &g.w, packed);
+            if (rc) return rc;
+            // demod table: Wsq[i][o] = sum_taps (W*coef)^2   (modules.py:943-954, SURVEY 8a note 1)
+            std::vector<float> wsq((size_t)g.cin * g.cout);
+            const float coef2 = 1.0f / ((float)g.cin * 9.f);
+            for (int o = 0; o < g.cout; ++o)
+                for (int i = 0; i < g.cin; ++i) {
+                    const float* w = W->data.data() + ((size_t)o * g.cin + i) * 9;
+                    float s = 0.f;
+                    for (int t = 0; t < 9; ++t) s += w[t] * w[t];
+                    wsq[(size_t)i * g.cout + o] = s * coef2;
+                }
+            rc = upload(e, &g.wsq, wsq);
+            if (rc) return rc;
+            rc = upload(e, &g.bias, bias->data);
+            if (rc) return rc;
+            g.noise_strength = ns->data[0];
+        }
+        GRgb& r = e->grgb[b];
+        snprintf(nm, sizeof nm, "G_synthesis.to_data_layers.%d", b);
+        const std::string p = nm;
+        GET(W, p + ".layer.weight");
+        GET(bias, p + ".bias");
+        REQUIRE(numel(W) == (size_t)3 * r.cin && numel(bias) == 3, GLASS_ERR_ARG, "bad toRGB shape: " + p);
+        int rc = add_style(p + ".layer", r.style_idx, r.style_off, r.cin);
+        if (rc) return rc;
+        rc = upload(e, &r.w, scaled(W->data.data(), (size_t)3 * r.cin, 1.0f / sqrtf((float)r.cin)));
+        if (rc) return rc;
+        rc = upload(e, &r.bias, bias->data);
+        if (rc) return rc;
+    }
+    int rc = upload(e, &e->style_wt, swt);
+    if (rc) return rc;
+    rc = upload(e, &e->style_b, sb);
+    if (rc) return rc;
+    rc = upload(e, &e->d_style_off, e->style_off);
+    if (rc) return rc;
+    rc = upload(e, &e->d_style_len, e->style_len);
+    return rc;
+}
+
+static int finalize_discriminator(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    const int n = c.n_blocks;
+    char nm[256];
+    auto chD = [&](int i) { return c.channels[n - 1 - i]; };  // D order: first (full res) -> last (4x4)
+    {
+        GET(W, "D.from_data_layers.0.layer.weight");
+        GET(b, "D.from_data_layers.0.bias");
+        REQUIRE(numel(W) == (size_t)chD(0) * 3 && numel(b) == (size_t)chD(0), GLASS_ERR_ARG, "bad fromRGB shape");
+        int rc = upload(e, &e->d_frgb_w, scaled(W->data.data(), numel(W), 1.0f / sqrtf(3.f)));
+        if (rc) return rc;
+        rc = upload(e, &e->d_frgb_b, b->data);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        DBlock d;
+        d.cin = chD(i);
+        d.cout = chD(i + 1);
+        d.res = e->R >> i;
+        snprintf(nm, sizeof nm, "D.conv_blocks.%d", i);
+        const std::string p = nm;
+        GET(W0, p + ".conv_block.0.layer.weight");
+        GET(B0, p + ".conv_block.0.bias");
+        GET(W1, p + ".conv_block.1.layer.weight");
+        GET(B1, p + ".conv_block.1.bias");
+        GET(WS, p + ".projection.weight");
+        REQUIRE(numel(W0) == (size_t)d.cin * d.cin * 9 && numel(W1) == (size_t)d.cout * d.cin * 9 &&
+                    numel(WS) == (size_t)d.cout * d.cin && numel(B0) == (size_t)d.cin && numel(B1) == (size_t)d.cout,
+                GLASS_ERR_ARG, "bad D block shape: " + p);
+        std::vector<_Float16> pk;
+        glass_pack_conv(W0->data.data(), d.cin, d.cin, 3, d.cin, pk);
+        int rc = upload(e, &d.w0, pk);
+        if (rc) return rc;
+        glass_pack_conv(W1->data.data(), d.cout, d.cin, 3, d.cin, pk);
+        rc = upload(e, &d.w1, pk);
+        if (rc) return rc;
+        glass_pack_conv(WS->data.data(), d.cout, d.cin, 1, d.cin, pk);
+        rc = upload(e, &d.wskip, pk);
+        if (rc) return rc;
+        rc = upload(e, &d.b0, B0->data);
+        if (rc) return rc;
+        rc = upload(e, &d.b1, B1->data);
+        if (rc) return rc;
+        e->dblk.push_back(d);
+    }
+    const int CL = chD(n - 1);
+    snprintf(nm, sizeof nm, "D.conv_blocks.%d.1.conv_block.0", n - 1);
+    const std::string p = nm;
+    GET(WF, p + ".layer.weight");
+    GET(BF, p + ".bias");
+    REQUIRE(numel(WF) == (size_t)CL * (CL + 1) * 9 && numel(BF) == (size_t)CL, GLASS_ERR_ARG, "bad D final conv shape");
+    e->d_final_cpad = ((CL + 1 + 15) / 16) * 16;
+    std::vector<_Float16> pk;
+    glass_pack_conv(WF->data.data(), CL, CL + 1, 3, e->d_final_cpad, pk);
+    int rc = upload(e, &e->d_final_w, pk);
+    if (rc) return rc;
+    rc = upload(e, &e->d_final_b, BF->data);
+    if (rc) return rc;
+    GET(W0, "D.dense.0.layer.weight");
+    GET(B0, "D.dense.0.bias");
+    GET(W1, "D.dense.1.layer.weight");
+    GET(B1, "D.dense.1.bias");
+    REQUIRE(numel(W0) == (size_t)CL * CL * 16 && numel(B0) == (size_t)CL && numel(W1) == (size_t)CL && numel(B1) == 1,
+            GLASS_ERR_ARG, "bad D dense shape");
+    // x.view(B,-1) flattens NCHW (models.py:1224): column c*16+p ; our activations are [p][c].
+    std::vector<_Float16> d0((size_t)CL * CL * 16);
+    const float coef0 = 1.0f / sqrtf((float)CL * 16.f);
+    for (int o = 0; o < CL; ++o)
+        for (int ch = 0; ch < CL; ++ch)
+            for (int px = 0; px < 16; ++px)
+                d0[(size_t)o * CL * 16 + (size_t)px * CL + ch] = (_Float16)(W0->data[(size_t)o * CL * 16 + ch * 16 + px] * coef0);
+    rc = upload(e, &e->d_dense0_w, d0);
+    if (rc) return rc;
+    rc = upload(e, &e->d_dense0_b, B0->data);
+    if (rc) return rc;
+    rc = upload(e, &e->d_dense1_wt, transposed(W1->data.data(), 1, CL, 1.0f / sqrtf((float)CL)));
+    if (rc) return rc;
+    return upload(e, &e->d_dense1_b, B1->data);
+}
+
+static int finalize_clip(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, E = c.clip_embed;
+    const std::string v = "clip.visual.";
+    GET(conv1, v + "conv1.weight");
+    GET(cls, v + "class_embedding");
+    GET(pos, v + "positional_embedding");
+    GET(lg, v + "ln_pre.weight");
+    GET(lb, v + "ln_pre.bias");
+    GET(pg, v + "ln_post.weight");
+    GET(pb, v + "ln_post.bias");
+    GET(proj, v + "proj");
+    REQUIRE(numel(conv1) == (size_t)W * 3 * ps * ps && numel(cls) == (size_t)W && numel(pos) == (size_t)T * W &&
+                numel(proj) == (size_t)W * E,
+            GLASS_ERR_ARG, "bad CLIP visual shapes");
+    int rc = upload(e, &e->c_patch_w, to_half(conv1->data.data(), numel(conv1)));
+    if (rc) return rc;
+    if ((rc = upload(e, &e->c_cls, cls->data))) return rc;
+    if ((rc = upload(e, &e->c_pos, pos->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpre_g, lg->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpre_b, lb->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpost_g, pg->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpost_b, pb->data))) return rc;
+    if ((rc = upload(e, &e->c_proj, proj->data))) return rc;  // already [K=W][N=E]
+    char nm[256];
+    for (int i = 0; i < c.clip_layers; ++i) {
+        snprintf(nm, sizeof nm, "clip.visual.transformer.resblocks.%d.", i);
+        const std::string p = nm;
+        ClipBlock b;
+        GET(l1g, p + "ln_1.weight");
+        GET(l1b, p + "ln_1.bias");
+        GET(l2g, p + "ln_2.weight");
+        GET(l2b, p + "ln_2.bias");
+        GET(wq, p + "attn.in_proj_weight");
+        GET(bq, p + "attn.in_proj_bias");
+        GET(wo, p + "attn.out_proj.weight");
+        GET(bo, p + "attn.out_proj.bias");
+        GET(wf, p + "mlp.c_fc.weight");
+        GET(bf, p + "mlp.c_fc.bias");
+        GET(wp, p + "mlp.c_proj.weight");
+        GET(bp, p + "mlp.c_proj.bias");
+        REQUIRE(numel(wq) == (size_t)3 * W * W && numel(wo) == (size_t)W * W && numel(wf) == (size_t)4 * W * W &&
+                    numel(wp) == (size_t)4 * W * W,
+                GLASS_ERR_ARG, "bad CLIP block shapes: " + p);
+        if ((rc = upload(e, &b.ln1_g, l1g->data))) return rc;
+        if ((rc = upload(e, &b.ln1_b, l1b->data))) return rc;
+        if ((rc = upload(e, &b.ln2_g, l2g->data))) return rc;
+        if ((rc = upload(e, &b.ln2_b, l2b->data))) return rc;
+        if ((rc = upload(e, &b.w_qkv, to_half(wq->data.data(), numel(wq))))) return rc;
+        if ((rc = upload(e, &b.w_out, to_half(wo->data.data(), numel(wo))))) return rc;
+        if ((rc = upload(e, &b.w_fc, to_half(wf->data.data(), numel(wf))))) return rc;
+        if ((rc = upload(e, &b.w_proj, to_half(wp->data.data(), numel(wp))))) return rc;
+        if ((rc = upload(e, &b.b_qkv, bq->data))) return rc;
+        if ((rc = upload(e, &b.b_out, bo->data))) return rc;
+        if ((rc = upload(e, &b.b_fc, bf->data))) return rc;
+        if ((rc = upload(e, &b.b_proj, bp->data))) return rc;
+        e->cblk.push_back(b);
+    }
+    return GLASS_OK;
+}
+
+static int alloc_buffers(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    const int P = c.max_pop, L = c.latent_size, CH = e->chunk;
+    int rc;
+    if ((rc = dev_alloc(e, &e->d_z, (size_t)P * L))) return rc;
+    if ((rc = dev_alloc(e, &e->d_w0, (size_t)P * L))) return rc;
+    if ((rc = dev_alloc(e, &e->d_w1, (size_t)P * L))) return rc;
+    if ((rc = dev_alloc(e, &e->d_s, (size_t)P * e->S_total))) return rc;
+    if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
+    if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
+    if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
+    if (c.noise_mode != 0) {
+        const int n_mb = P / c.batch_size;
+        for (auto& g : e->gconv) {
+            float* p;
+            if ((rc = dev_alloc(e, &p, (size_t)n_mb * g.res_out * g.res_out))) return rc;
+            e->d_noise.push_back(p);
+        }
+    }
+    size_t maxact = 0;
+    for (int b = 0; b < c.n_blocks; ++b) {
+        const size_t res = 4u << b;
+        size_t ch = c.channels[b];
+        if (b > 0) ch = std::max<size_t>(ch, c.channels[b - 1]);
+        maxact = std::max(maxact, (res + 1) * (res + 1) * ch);
+    }
+    maxact = std::max(maxact, (size_t)16 * (c.channels[0] + 16));
+    e->act_elems = maxact * CH;
+    const int n_act = c.use_discriminator ? 6 : 2;
+    for (int i = 0; i < n_act; ++i)
+        if ((rc = dev_alloc(e, &e->act[i], e->act_elems))) return rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(e, &e->ybuf[i], (size_t)CH * 3 * e->R * e->R))) return rc;
+    if ((rc = dev_alloc(e, &e->d_img, (size_t)CH * 3 * e->R * e->R))) return rc;
+    const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1;
+    if ((rc = dev_alloc(e, &e->d_patches, (size_t)P * G * G * 3 * ps * ps))) return rc;
+    if ((rc = dev_alloc(e, &e->d_pe, (size_t)P * G * G * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_x, (size_t)P * T * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_ln16, (size_t)P * T * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_qkv, (size_t)P * T * 3 * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_attn, (size_t)P * T * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_hid, (size_t)P * T * 4 * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_cls, (size_t)P * W))) return rc;
+    if ((rc = dev_alloc(e, &e->d_feat, (size_t)P * c.clip_embed))) return rc;
+    if ((rc = dev_alloc(e, &e->d_sim, (size_t)P))) return rc;
+    if ((rc = dev_alloc(e, &e->d_dis, (size_t)P))) return rc;
+    if ((rc = dev_alloc(e, &e->d_F, (size_t)P * 2))) return rc;
+    if ((rc = dev_alloc(e, &e->d_target, (size_t)c.clip_embed))) return rc;
+    if (c.use_discriminator) {
+        if ((rc = dev_alloc(e, &e->d_dfin, (size_t)CH * 16 * c.channels[0]))) return rc;
+        if ((rc = dev_alloc(e, &e->d_dh, (size_t)CH * c.channels[0]))) return rc;
+    }
+    GLASS_HIP(hipMemset(e->d_dis, 0, (size_t)P * sizeof(float)));
+    e->h_pinned_bytes = std::max((size_t)P * L, (size_t)P * (c.clip_embed + 8)) * sizeof(float);
+    GLASS_HIP(hipHostMalloc((void**)&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_finalize(glass_engine* e) {
+    REQUIRE(e, GLASS_ERR_ARG, "null engine");
+    REQUIRE(!e->finalized, GLASS_ERR_STATE, "engine already finalized");
+    GLASS_HIP(hipSetDevice(e->cfg.device));
+    int rc = finalize_generator(e);
+    if (rc) return rc;
+    if (e->cfg.use_discriminator && (rc = finalize_discriminator(e))) return rc;
+    if ((rc = finalize_clip(e))) return rc;
+    if ((rc = alloc_buffers(e))) return rc;
+    e->host.clear();  // host copies no longer needed
+    e->finalized = true;
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_set_target(glass_engine* e, const float* feat, int32_t n) {
+    REQUIRE(e && feat, GLASS_ERR_ARG, "null argument");
+    REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first");
+    REQUIRE(n == e->cfg.clip_embed, GLASS_ERR_ARG, "target feature length != clip_embed");
+    GLASS_HIP(hipSetDevice(e->cfg.device));
+    GLASS_HIP(hipMemcpy(e->d_target, feat, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    e->has_target = true;
+    return GLASS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// profiling scopes (hipEvent pair per launch when enabled)
+// ------------------------------------------------------------------------------------
+struct Prof {
+    glass_engine* e;
+    bool on;
+    ProfEvent pe;
+    Prof(glass_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
+        if (!on) return;
+        auto get = [&]() {
+            if (e->event_next == e->event_pool.size()) {
+                hipEvent_t ev;
+                hipEventCreate(&ev);
+                e->event_pool.push_back(ev);
+            }
+            return e->event_pool[e->event_next++];
+        };
+        pe.name = name;
+        pe.flops = flops;
+        pe.bytes = bytes;
+        pe.e0 = get();
+        pe.e1 = get();
+        hipEventRecord(pe.e0, e->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        hipEventRecord(pe.e1, e->stream);
+        e->prof_events.push_back(pe);
+    }
+};
+
+static void collect_profile(glass_engine* e) {
+    std::map<std::string, glass_prof_row> rows;
+    std::vector<std::string> order;
+    for (auto& pe : e->prof_events) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pe.e0, pe.e1);
+        auto it = rows.find(pe.name);
+        if (it == rows.end()) {
+            glass_prof_row r;
+            memset(&r, 0, sizeof r);
+            strncpy(r.name, pe.name.c_str(), sizeof(r.name) - 1);
+            it = rows.emplace(pe.name, r).first;
+            order.push_back(pe.name);
+        }
+        it->second.launches += 1;
+        it->second.total_ms += ms;
+        it->second.flops += pe.flops;
+        it->second.bytes += pe.bytes;
+    }
+    e->prof_rows.clear();
+    for (auto& n : order) e->prof_rows.push_back(rows[n]);
+    e->prof_events.clear();
+    e->event_next = 0;
+}
+
+static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
+    Prof pr(e, tag, flops, bytes);
+    if (!launch_conv_tiled(p, e->stream)) launch_conv_direct(p, e->stream);
+}
+static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
+    Prof pr(e, tag, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
+    if (!launch_gemm_tiled(p, e->stream)) launch_gemm_direct(p, e->stream);
+}
+
+static ConvParams conv_defaults() {
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.out_scale = 1.f;
+    p.batch_size = 1;
+    p.stride = 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------
+// the pass
+// ------------------------------------------------------------------------------------
+static int upload_noise(glass_engine* e, int P, int generation, int first_mb, const glass_noise* noise) {
+    const glass_config& c = e->cfg;
+    const int n_mb = P / c.batch_size;
+    if (c.noise_mode == 1) {
+        for (size_t l = 0; l < e->gconv.size(); ++l) {
+            const int hw = e->gconv[l].res_out * e->gconv[l].res_out;
+            Prof pr(e, "noise", 0, (double)n_mb * hw * 4);
+            launch_noise(e->d_noise[l], n_mb, hw, (uint32_t)l, (uint32_t)first_mb, (uint32_t)generation, c.noise_seed,
+                         e->stream);
+        }
+    } else if (c.noise_mode == 2) {
+        REQUIRE(noise && noise->planes, GLASS_ERR_ARG, "noise_mode 2 requires caller-provided noise planes");
+        REQUIRE(noise->n_layers == (int)e->gconv.size() && noise->n_minibatches >= n_mb, GLASS_ERR_ARG,
+                "noise: wrong number of layers / minibatches");
+        for (int m = 0; m < n_mb; ++m)
+            for (size_t l = 0; l < e->gconv.size(); ++l) {
+                const size_t hw = (size_t)e->gconv[l].res_out * e->gconv[l].res_out;
+                const float* src = noise->planes[(size_t)m * noise->n_layers + l];
+                REQUIRE(src, GLASS_ERR_ARG, "noise: null plane");
+                GLASS_HIP(hipMemcpyAsync(e->d_noise[l] + (size_t)m * hw, src, hw * sizeof(float), hipMemcpyHostToDevice,
+                                         e->stream));
+            }
+        GLASS_HIP(hipStreamSynchronize(e->stream));  // caller's planes may be freed after return
+    }
+    return GLASS_OK;
+}
+
+static void run_styles(glass_engine* e, int P) {
+    const glass_config& c = e->cfg;
+    const int L = c.latent_size;
+    {
+        Prof pr(e, "mapping", 2.0 * P * L * L * c.mapping_layers, 4.0 * L * L * c.mapping_layers);
+        launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->stream);
+        float *a = e->d_w0, *b = e->d_w1;
+        for (int i = 0; i < c.mapping_layers; ++i) {
+            launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->stream);
+            std::swap(a, b);
+        }
+        if (a != e->d_w0)  // result must end in d_w0
+            hipMemcpyAsync(e->d_w0, a, (size_t)P * L * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+    }
+    {
+        Prof pr(e, "styles", 2.0 * P * L * e->S_total, 4.0 * L * e->S_total);
+        launch_dense(e->d_w0, L, P, L, e->style_wt, e->S_total, e->style_b, e->d_s, e->S_total, 0, 0, nullptr, 0,
+                     e->stream);
+        launch_style_norm(e->d_s, e->S_total, P, e->n_style, e->d_style_off, e->d_style_len, e->d_smax, e->d_epsrow,
+                          1e-8f, e->stream);
+    }
+    {
+        Prof pr(e, "demod", 0, 0);
+        for (auto& g : e->gconv)
+            launch_dense(e->d_s + g.style_off, e->S_total, P, g.cin, g.wsq, g.cout, nullptr, e->d_dscale + g.ds_off,
+                         e->D_total, 1, 2, e->d_epsrow + g.style_idx, e->n_style, e->stream);
+    }
+}
+
+// synthesis for candidates [c0, c0+B): returns index of the ybuf holding the final image
+static int run_synthesis(glass_engine* e, int c0, int B) {
+    const glass_config& c = e->cfg;
+    int cur = 0, gi = 0, ycur = 0;
+    const half_t* x = e->g_const;
+    long long xbs = 0;
+    char tag[48];
+    for (int b = 0; b < c.n_blocks; ++b) {
+        const int nl = b == 0 ? 1 : 2;
+        for (int l = 0; l < nl; ++l, ++gi) {
+            const GConv& g = e->gconv[gi];
+            ConvParams p = conv_defaults();
+            p.x = x;
+            p.x_bstride = xbs;
+            p.B = B;
+            p.H = p.W = g.res_in;
+            p.Cin = g.cin;
+            p.Hc = p.Wc = g.res_in;
+            p.KS = 3;
+            p.pad = 1;
+            p.w = g.w;
+            p.Cout = g.cout;
+            p.up = g.up;
+            p.Neff = g.up ? 4 * g.cout : g.cout;
+            p.Ho = p.Wo = g.res_out;
+            p.sn = e->d_s + (size_t)c0 * e->S_total + g.style_off;
+            p.sn_stride = e->S_total;
+            p.dscale = e->d_dscale + (size_t)c0 * e->D_total + g.ds_off;
+            p.ds_stride = e->D_total;
+            if (c.noise_mode != 0) {
+                p.noise = e->d_noise[g.noise_idx] + (size_t)(c0 / c.batch_size) * g.res_out * g.res_out;
+                p.noise_strength = g.noise_strength;
+            }
+            p.batch_size = c.batch_size;
+            p.bias = g.bias;
+            p.act = 1;
+            half_t* out = e->act[(x == e->act[0]) ? 1 : 0];
+            p.y = out;
+            const double flops = 2.0 * B * (double)g.res_in * g.res_in * 9.0 * g.cin * g.cout;  // reference count
+            const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
+                                 2.0 * 9 * g.cin * p.Neff;
+            snprintf(tag, sizeof tag, "G.%s.r%d.%dx%d", g.up ? "upconv" : "conv", g.res_out, g.cin, g.cout);
+            run_conv(e, p, tag, flops, bytes);
+            x = out;
+            xbs = (long long)g.res_out * g.res_out * g.cout;
+            (void)cur;
+        }
+        const GRgb& r = e->grgb[b];
+        {
+            snprintf(tag, sizeof tag, "G.torgb.r%d", r.res);
+            Prof pr(e, tag, 2.0 * B * (double)r.res * r.res * 3 * r.cin,
+                    B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));
+            launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
+                         e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style,
+                         b ? e->ybuf[ycur ^ 1] : nullptr, e->ybuf[ycur], e->stream);
+        }
+        ycur ^= 1;
+    }
+    return ycur ^ 1;
+}
+
+static void run_discriminator(glass_engine* e, int c0, int B, const float* y) {
+    const glass_config& c = e->cfg;
+    const int n = c.n_blocks;
+    char tag[48];
+    half_t *X = e->act[0], *Hb = e->act[1], *HB = e->act[2], *XS = e->act[3], *S = e->act[4], *O = e->act[5];
+    {
+        Prof pr(e, "D.fromrgb", 2.0 * B * (double)e->R * e->R * 3 * c.channels[n - 1],
+                B * (double)e->R * e->R * (12.0 + 2.0 * c.channels[n - 1]));
+        launch_fromrgb(y, B, e->R, c.channels[n - 1], e->d_frgb_w, e->d_frgb_b, X, e->stream);
+    }
+    for (auto& d : e->dblk) {
+        const int r = d.res, r2 = r / 2;
+        ConvParams p = conv_defaults();
+        p.x = X; p.x_bstride = (long long)r * r * d.cin; p.B = B; p.H = p.W = r; p.Cin = d.cin;
+        p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
+        p.bias = d.b0; p.act = 1; p.y = Hb;
+        snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
+        run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
+        {
+            snprintf(tag, sizeof tag, "D.blur.r%d", r);
+            Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
+            launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->stream);
+        }
+        {
+            snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
+            Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);
+            launch_blur_down(X, B, r, r, d.cin, XS, e->stream);
+        }
+        ConvParams s = conv_defaults();
+        s.x = XS; s.x_bstride = (long long)r2 * r2 * d.cin; s.B = B; s.H = s.W = r2; s.Cin = d.cin;
+        s.Hc = s.Wc = r2; s.KS = 1; s.pad = 0; s.w = d.wskip; s.Cout = s.Neff = d.cout; s.Ho = s.Wo = r2; s.y = S;
+        snprintf(tag, sizeof tag, "D.skip.r%d.%dx%d", r2, d.cin, d.cout);
+        run_conv(e, s, tag, 2.0 * B * (double)r2 * r2 * d.cin * d.cout, 2.0 * B * (double)r2 * r2 * (d.cin + d.cout));
+        ConvParams q = conv_defaults();
+        q.x = HB; q.x_bstride = (long long)(r + 1) * (r + 1) * d.cin; q.B = B; q.H = q.W = r + 1; q.Cin = d.cin;
+        q.Hc = q.Wc = r2; q.KS = 3; q.stride = 2; q.pad = 0; q.w = d.w1; q.Cout = q.Neff = d.cout; q.Ho = q.Wo = r2;
+        q.bias = d.b1; q.act = 1; q.res = S; q.out_scale = 0.70710678118654752440f; q.y = O;
+        snprintf(tag, sizeof tag, "D.conv1.r%d.%dx%d", r2, d.cin, d.cout);
+        run_conv(e, q, tag, 2.0 * B * (double)r2 * r2 * 9 * d.cin * d.cout,
+                 2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + 2.0 * r2 * r2 * d.cout));
+        std::swap(X, O);
+    }
+    const int CL = c.channels[0];
+    {
+        Prof pr(e, "D.mbstd", 0, 4.0 * B * 16 * CL);
+        launch_mbstd(X, B, 16, CL, e->d_final_cpad, c.batch_size, c.mbstd_group, 1e-8f, Hb, e->stream);
+    }
+    ConvParams p = conv_defaults();
+    p.x = Hb; p.x_bstride = 16LL * e->d_final_cpad; p.B = B; p.H = p.W = 4; p.Cin = e->d_final_cpad; p.Hc = p.Wc = 4;
+    p.KS = 3; p.pad = 1; p.w = e->d_final_w; p.Cout = p.Neff = CL; p.Ho = p.Wo = 4; p.bias = e->d_final_b; p.act = 1;
+    p.y = e->d_dfin;
+    run_conv(e, p, "D.final_conv", 2.0 * B * 16 * 9.0 * (CL + 1) * CL, 2.0 * 9 * CL * (CL + 1));
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.a = e->d_dfin; g.w = e->d_dense0_w; g.M = B; g.N = CL; g.K = 16 * CL; g.bias = e->d_dense0_b; g.mode = 4;
+    g.out32 = e->d_dh; g.ldo = CL;
+    run_gemm(e, g, "D.dense0");
+    {
+        Prof pr(e, "D.dense1", 2.0 * B * CL, 0);
+        launch_dense(e->d_dh, CL, B, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis + c0, 1, 0, 0, nullptr, 0, e->stream);
+    }
+}
+
+static void run_clip(glass_engine* e, int P) {
+    const glass_config& c = e->cfg;
+    const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, M = P * T;
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.a = e->d_patches; g.w = e->c_patch_w; g.M = P * G * G; g.N = W; g.K = 3 * ps * ps; g.mode = 3; g.out32 = e->d_pe; g.ldo = W;
+    run_gemm(e, g, "clip.patch_embed");
+    {
+        Prof pr(e, "clip.embed_lnpre", 0, 8.0 * M * W);
+        launch_embed_lnpre(e->d_pe, e->c_cls, e->c_pos, e->c_lnpre_g, e->c_lnpre_b, P, T, W, e->d_x, e->stream);
+    }
+    for (auto& b : e->cblk) {
+        {
+            Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
+            launch_layernorm(e->d_x, W, M, W, b.ln1_g, b.ln1_b, e->d_ln16, nullptr, e->stream);
+        }
+        memset(&g, 0, sizeof g);
+        g.a = e->d_ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = e->d_qkv; g.ldo = 3 * W;
+        run_gemm(e, g, "clip.qkv");
+        {
+            Prof pr(e, "clip.attention", 4.0 * P * c.clip_heads * (double)T * T * 64, 8.0 * M * W);
+            launch_attention(e->d_qkv, P, T, c.clip_heads, 64, 0, e->d_attn, e->stream);
+        }
+        memset(&g, 0, sizeof g);
+        g.a = e->d_attn; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = e->d_x; g.ldo = W;
+        run_gemm(e, g, "clip.attn_out");
+        {
+            Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
+            launch_layernorm(e->d_x, W, M, W, b.ln2_g, b.ln2_b, e->d_ln16, nullptr, e->stream);
+        }
+        memset(&g, 0, sizeof g);
+        g.a = e->d_ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = e->d_hid; g.ldo = 4 * W;
+        run_gemm(e, g, "clip.mlp_fc");
+        memset(&g, 0, sizeof g);
+        g.a = e->d_hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = e->d_x; g.ldo = W;
+        run_gemm(e, g, "clip.mlp_proj");
+    }
+    {
+        Prof pr(e, "clip.head", 2.0 * P * W * c.clip_embed, 4.0 * W * c.clip_embed);
+        launch_layernorm(e->d_x, (long long)T * W, P, W, e->c_lnpost_g, e->c_lnpost_b, nullptr, e->d_cls, e->stream);
+        launch_dense(e->d_cls, W, P, W, e->c_proj, c.clip_embed, nullptr, e->d_feat, c.clip_embed, 0, 0, nullptr, 0,
+                     e->stream);
+        launch_cosine(e->d_feat, e->d_target, P, c.clip_embed, e->d_sim, e->stream);
+    }
+}
+
+static int run_pass(glass_engine* e, const float* latents, int P, int generation, int first_mb,
+                    const glass_noise* noise, float* out_F, float* images) {
+    REQUIRE(e && latents, GLASS_ERR_ARG, "null argument");
+    REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first (weights not loaded)");
+    const glass_config& c = e->cfg;
+    REQUIRE(P > 0 && P <= c.max_pop, GLASS_ERR_ARG, "population size out of range (max_pop)");
+    REQUIRE(P % c.batch_size == 0, GLASS_ERR_ARG,
+            "population size must be a multiple of batch_size (reference asserts: models.py:112)");
+    if (out_F) REQUIRE(e->has_target, GLASS_ERR_STATE, "set_target() first");
+    GLASS_HIP(hipSetDevice(c.device));
+    const int L = c.latent_size;
+    memcpy(e->h_pinned, latents, (size_t)P * L * sizeof(float));
+    GLASS_HIP(hipEventRecord(e->ev0, e->stream));
+    GLASS_HIP(hipMemcpyAsync(e->d_z, e->h_pinned, (size_t)P * L * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    run_styles(e, P);
+    int rc = upload_noise(e, P, generation, first_mb, noise);
+    if (rc) return rc;
+    const int ps = c.clip_patch, G = c.clip_res / ps;
+    const size_t img_elems = (size_t)3 * e->R * e->R;
+    for (int c0 = 0; c0 < P; c0 += e->chunk) {
+        const int B = std::min(e->chunk, P - c0);
+        const int yi = run_synthesis(e, c0, B);
+        const float* y = e->ybuf[yi];
+        if (images) {
+            launch_finalize_image(y, e->d_img, (long long)B * img_elems, e->stream);
+            GLASS_HIP(hipMemcpyAsync(images + (size_t)c0 * img_elems, e->d_img, (size_t)B * img_elems * sizeof(float),
+                                     hipMemcpyDeviceToHost, e->stream));
+        }
+        if (out_F) {
+            {
+                Prof pr(e, "clip.resize", 0, B * (16.0 * c.clip_res * c.clip_res * 3 + 2.0 * 3 * c.clip_res * c.clip_res));
+                launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
+                                      e->stream);
+            }
+            if (c.use_discriminator && c.n_obj == 2) run_discriminator(e, c0, B, y);
+        }
+    }
+    if (out_F) {
+        run_clip(e, P);
+        launch_assemble_F(e->d_sim, e->d_dis, P, c.n_obj, e->d_F, e->stream);
+        GLASS_HIP(hipMemcpyAsync(e->h_pinned, e->d_F, (size_t)P * c.n_obj * sizeof(float), hipMemcpyDeviceToHost,
+                                 e->stream));
+    }
+    GLASS_HIP(hipEventRecord(e->ev1, e->stream));
+    GLASS_HIP(hipStreamSynchronize(e->stream));
+    GLASS_HIP(hipGetLastError());
+    GLASS_HIP(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    if (out_F) memcpy(out_F, e->h_pinned, (size_t)P * c.n_obj * sizeof(float));
+    e->last_P = P;
+    if (e->profiling) collect_profile(e);
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_evaluate(glass_engine* e, const float* latents, int32_t P, int32_t generation,
+                                     int32_t first_minibatch, const glass_noise* noise, float* out_F) {
+    REQUIRE(out_F, GLASS_ERR_ARG, "null out_F");
+    return run_pass(e, latents, P, generation, first_minibatch, noise, out_F, nullptr);
+}
+
+extern "C" int glass_engine_generate(glass_engine* e, const float* latents, int32_t P, int32_t generation,
+                                     int32_t first_minibatch, const glass_noise* noise, float* images) {
+    REQUIRE(images, GLASS_ERR_ARG, "null images");
+    return run_pass(e, latents, P, generation, first_minibatch, noise, nullptr, images);
+}
+
+extern "C" int glass_engine_last_details(glass_engine* e, int32_t P, float* features, float* dis, float* sim) {
+    REQUIRE(e && e->finalized, GLASS_ERR_STATE, "engine not ready");
+    REQUIRE(P > 0 && P <= e->last_P, GLASS_ERR_ARG, "P exceeds the last evaluated population");
+    GLASS_HIP(hipSetDevice(e->cfg.device));
+    if (features)
+        GLASS_HIP(hipMemcpy(features, e->d_feat, (size_t)P * e->cfg.clip_embed * sizeof(float), hipMemcpyDeviceToHost));
+    if (dis) GLASS_HIP(hipMemcpy(dis, e->d_dis, (size_t)P * sizeof(float), hipMemcpyDeviceToHost));
+    if (sim) GLASS_HIP(hipMemcpy(sim, e->d_sim, (size_t)P * sizeof(float), hipMemcpyDeviceToHost));
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_last_gpu_ms(glass_engine* e, float* ms) {
+    REQUIRE(e && ms, GLASS_ERR_ARG, "null argument");
+    *ms = e->last_ms;
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_set_profiling(glass_engine* e, int32_t on) {
+    REQUIRE(e, GLASS_ERR_ARG, "null engine");
+    e->profiling = on != 0;
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_rows, int32_t* n_rows) {
+    REQUIRE(e && n_rows, GLASS_ERR_ARG, "null argument");
+    const int n = (int)e->prof_rows.size();
+    *n_rows = n;
+    if (rows)
+        for (int i = 0; i < std::min(n, (int)max_rows); ++i) rows[i] = e->prof_rows[i];
+    return GLASS_OK;
+}
+
+extern "C" int glass_device_info(int32_t device, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes) {
+    hipDeviceProp_t prop;
+    GLASS_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) {
+        strncpy(name, prop.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return GLASS_OK;
+}

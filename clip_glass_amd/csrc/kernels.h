@@ -1,0 +1,52 @@
+// kernels.h — host-callable launch wrappers (one per kernel family).
+#pragma once
+#include "common.h"
+
+void launch_conv_direct(const ConvParams& p, hipStream_t st);
+void launch_gemm_direct(const GemmParams& p, hipStream_t st);
+// LDS-tiled fast paths; return false when the shape is not supported (caller falls back to direct).
+bool launch_conv_tiled(const ConvParams& p, hipStream_t st);
+bool launch_gemm_tiled(const GemmParams& p, hipStream_t st);
+
+// --- small fp32 ops (mapping network, style affines, demodulation, heads) ---------
+void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipStream_t st);
+// out[p][n] = epi( sum_k f(x[p][k]) * wt[k][n] + bias[n] ); in_sq: f = square;
+// mode 0 none, 1 lrelu*sqrt2, 2 rsqrt(v + eps_row[p*eps_stride])
+void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
+                  float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
+                  hipStream_t st);
+// per (p, layer): smax = max|s|, s /= smax, eps_row = eps / smax^2
+void launch_style_norm(float* s, int ld, int P, int n_layers, const int* d_off, const int* d_len,
+                       float* smax, float* eps_row, float eps, hipStream_t st);
+void launch_noise(float* out, int n_mb, int hw, uint32_t layer, uint32_t mb0, uint32_t generation,
+                  uint64_t seed, hipStream_t st);
+
+// --- image-space ops ---------------------------------------------------------------
+// y[b][c][p] = bias[c] + smax[b]*sum_i wrgb[c][i]*sn[b][i]*x[b][p][i] + upfir(yprev)
+void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
+                  const float* sn, int sn_stride, const float* smax, int smax_stride,
+                  const float* yprev, float* yout, hipStream_t st);
+// img = clip((y+1)/2, 0, 1)
+void launch_finalize_image(const float* y, float* img, long long n, hipStream_t st);
+// bilinear (align_corners=False) resize of clip((y+1)/2,0,1) into the patch matrix [B*G*G][3*ps*ps] fp16
+void launch_resize_patches(const float* y, int B, int R, int clip_res, int ps, half_t* patches,
+                           hipStream_t st);
+void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, const float* bias,
+                    half_t* out, hipStream_t st);
+// 4x4 FIR [1,3,3,1]^2/64, zero pad 2, stride 1: [B,H,W,C] -> [B,H+1,W+1,C]
+void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st);
+// 4x4 FIR, zero pad 1, then ::2 subsample: [B,H,W,C] -> [B,H/2,W/2,C]
+void launch_blur_down(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st);
+// minibatch-std (reference quirk: features are group-mean subtracted): [B,hw,C] -> [B,hw,Cpad]
+void launch_mbstd(const half_t* x, int B, int hw, int C, int Cpad, int batch_size, int group, float eps,
+                  half_t* out, hipStream_t st);
+
+// --- CLIP --------------------------------------------------------------------------
+void launch_embed_lnpre(const float* patch_emb, const float* cls, const float* pos, const float* g,
+                        const float* b, int P, int T, int D, float* x, hipStream_t st);
+void launch_layernorm(const float* x, long long row_stride, int M, int D, const float* g, const float* b,
+                      half_t* out16, float* out32, hipStream_t st);
+void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,
+                      hipStream_t st);
+void launch_cosine(const float* feat, const float* target, int P, int D, float* sim, hipStream_t st);
+void launch_assemble_F(const float* sim, const float* dis, int P, int n_obj, float* F, hipStream_t st);

@@ -1,0 +1,153 @@
+// kernels_clip.hip — CLIP ViT glue kernels: token assembly + ln_pre, LayerNorm,
+// multi-head attention for short sequences (L <= 128: 50 visual tokens, 77 text tokens),
+// cosine similarity and objective assembly.  GEMMs live in conv_direct.hip / gemm_tiled.hip.
+// Reference: clip/model.py:152-187 (LayerNorm, QuickGELU, ResidualAttentionBlock),
+// :218-235 (VisualTransformer.forward), generator.py:51 (cosine), problem.py:21-27.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// One wave per row; two-pass mean/variance in fp32 (clip/model.py:152-158, eps 1e-5).
+template <typename LoadF>
+__device__ __forceinline__ void ln_row(LoadF load, int D, const float* g, const float* b, half_t* o16, float* o32) {
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) s += load(i);
+    const float mean = wsum(s) / (float)D;
+    float q = 0.f;
+    for (int i = lane; i < D; i += 64) { const float d = load(i) - mean; q += d * d; }
+    const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
+    for (int i = lane; i < D; i += 64) {
+        const float v = (load(i) - mean) * rstd * g[i] + b[i];
+        if (o16) o16[i] = (half_t)v;
+        if (o32) o32[i] = v;
+    }
+}
+
+// x[p][0] = class_embedding + pos[0]; x[p][1+t] = patch_emb[p*T0+t] + pos[1+t]; then ln_pre.
+__global__ __launch_bounds__(256) void embed_lnpre_kernel(const float* pe, const float* cls, const float* pos,
+                                                          const float* g, const float* b, int P, int T, int D,
+                                                          float* x) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= P * T) return;
+    const int p = row / T, t = row - p * T;
+    const float* src = t == 0 ? cls : pe + ((long long)p * (T - 1) + (t - 1)) * D;
+    const float* ps = pos + (long long)t * D;
+    ln_row([&](int i) { return src[i] + ps[i]; }, D, g, b, nullptr, x + (long long)row * D);
+}
+void launch_embed_lnpre(const float* patch_emb, const float* cls, const float* pos, const float* g,
+                        const float* b, int P, int T, int D, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(embed_lnpre_kernel, dim3((P * T + 3) / 4), dim3(256), 0, st, patch_emb, cls, pos, g, b, P,
+                       T, D, x);
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long row_stride, int M, int D,
+                                                        const float* g, const float* b, half_t* o16, float* o32) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long long)row * row_stride;
+    ln_row([&](int i) { return xr[i]; }, D, g, b, o16 ? o16 + (long long)row * D : nullptr,
+           o32 ? o32 + (long long)row * D : nullptr);
+}
+void launch_layernorm(const float* x, long long row_stride, int M, int D, const float* g, const float* b,
+                      half_t* out16, float* out32, hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, row_stride, M, D, g, b, out16,
+                       out32);
+}
+
+// nn.MultiheadAttention forward for one (image, head) per workgroup: softmax(q k^T / sqrt(hd) [+causal]) v.
+// qkv: [n_img*L][3*heads*hd] fp16 (q | k | v), out: [n_img*L][heads*hd] fp16.  hd == 64.
+__global__ __launch_bounds__(256) void attention_kernel(const half_t* qkv, int L, int heads, int causal,
+                                                        half_t* out) {
+    extern __shared__ float sm[];
+    const int hd = 64;
+    float* q = sm;                 // [L][hd+1]
+    float* k = q + L * (hd + 1);   // [L][hd+1]
+    float* v = k + L * (hd + 1);   // [L][hd+1]
+    float* s = v + L * (hd + 1);   // [L][L+1]
+    const int img = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int D = heads * hd;
+    const half_t* base = qkv + (long long)img * L * 3 * D + h * hd;
+    for (int e = threadIdx.x; e < L * hd; e += 256) {
+        const int t = e / hd, d = e - t * hd;
+        const half_t* rp = base + (long long)t * 3 * D + d;
+        q[t * (hd + 1) + d] = (float)rp[0] * 0.125f;  // q * hd^-0.5 (hd = 64)
+        k[t * (hd + 1) + d] = (float)rp[D];
+        v[t * (hd + 1) + d] = (float)rp[2 * D];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L * L; e += 256) {
+        const int i = e / L, j = e - i * L;
+        float a = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < hd; ++d) a += q[i * (hd + 1) + d] * k[j * (hd + 1) + d];
+        if (causal && j > i) a = -INFINITY;
+        s[i * (L + 1) + j] = a;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < L; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < L; j += 64) m = fmaxf(m, s[i * (L + 1) + j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float z = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float e2 = __expf(s[i * (L + 1) + j] - m);
+            s[i * (L + 1) + j] = e2;
+            z += e2;
+        }
+        z = wsum(z);
+        const float inv = 1.f / z;
+        for (int j = lane; j < L; j += 64) s[i * (L + 1) + j] *= inv;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < L * hd; e += 256) {
+        const int i = e / hd, d = e - i * hd;
+        float a = 0.f;
+        for (int j = 0; j < L; ++j) a += s[i * (L + 1) + j] * v[j * (hd + 1) + d];
+        out[((long long)img * L + i) * D + h * hd + d] = (half_t)a;
+    }
+}
+void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,
+                      hipStream_t st) {
+    (void)hd;  // 64 (asserted by the engine)
+    const size_t lds = (size_t)(3 * L * 65 + L * (L + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {  // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS
+        (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel, dim3(n_img * heads), dim3(256), lds, st, qkv, L, heads, causal, out);
+}
+
+// torch.cosine_similarity(feat[P,D], target[1,D]) (generator.py:51): x.y / max(|x||y|, 1e-8)
+__global__ void cosine_kernel(const float* feat, const float* target, int D, float* sim) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    float xy = 0.f, xx = 0.f, yy = 0.f;
+    for (int i = lane; i < D; i += 64) {
+        const float a = feat[(long long)p * D + i], b = target[i];
+        xy += a * b; xx += a * a; yy += b * b;
+    }
+    xy = wsum(xy); xx = wsum(xx); yy = wsum(yy);
+    if (lane == 0) sim[p] = xy / fmaxf(sqrtf(xx) * sqrtf(yy), 1e-8f);
+}
+void launch_cosine(const float* feat, const float* target, int P, int D, float* sim, hipStream_t st) {
+    hipLaunchKernelGGL(cosine_kernel, dim3(P), dim3(64), 0, st, feat, target, D, sim);
+}
+
+// problem.py:23-27: F = column_stack(-sim, relu(1 - dis)) or F = -sim
+__global__ void assemble_F_kernel(const float* sim, const float* dis, int P, int n_obj, float* F) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    F[(long long)p * n_obj] = -sim[p];
+    if (n_obj == 2) F[(long long)p * n_obj + 1] = fmaxf(1.f - dis[p], 0.f);
+}
+void launch_assemble_F(const float* sim, const float* dis, int P, int n_obj, float* F, hipStream_t st) {
+    hipLaunchKernelGGL(assemble_F_kernel, dim3((P + 63) / 64), dim3(64), 0, st, sim, dis, P, n_obj, F);
+}

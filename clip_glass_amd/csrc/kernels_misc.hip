@@ -1,0 +1,387 @@
+// kernels_misc.hip — the non-GEMM kernels of the fitness path (fp32 heads, image ops,
+// FIR filters, minibatch-std).  All memory-bound; vectorised 16-byte accesses on the
+// NHWC fp16 activations, wave64 reductions.
+#include "common.h"
+#include "kernels.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- mapping network input normalisation: stylegan2/models.py:625-626 --------------
+__global__ void pixelnorm_kernel(const float* z, float* out, int L, float eps) {
+    const int p = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) { const float v = z[(long long)p * L + i]; s += v * v; }
+    s = wave_sum(s);
+    const float k = rsqrtf(s / (float)L + eps);
+    for (int i = lane; i < L; i += 64) out[(long long)p * L + i] = z[(long long)p * L + i] * k;
+}
+void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3(P), dim3(64), 0, st, z, out, L, eps);
+}
+
+// ---- small-M fp32 dense: DenseLayer (modules.py:786-798) for the mapping network,
+// the 26 style affines (one launch), demodulation coefficients, CLIP proj, D dense1.
+#define DENSE_PB 16
+#define DENSE_KT 128
+__global__ __launch_bounds__(256) void dense_kernel(const float* x, int ldx, int P, int K, const float* wt,
+                                                    int N, const float* bias, float* out, int ldo, int in_sq,
+                                                    int mode, const float* eps_row, int eps_stride) {
+    __shared__ float xs[DENSE_PB][DENSE_KT];
+    const int t = threadIdx.x;
+    const int n = blockIdx.x * 64 + (t & 63);
+    const int pg = t >> 6;
+    const int p0 = blockIdx.y * DENSE_PB;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += DENSE_KT) {
+        for (int e = t; e < DENSE_PB * DENSE_KT; e += 256) {
+            const int pr = e / DENSE_KT, kk = e - pr * DENSE_KT;
+            float v = 0.f;
+            if (p0 + pr < P && k0 + kk < K) v = x[(long long)(p0 + pr) * ldx + k0 + kk];
+            xs[pr][kk] = in_sq ? v * v : v;
+        }
+        __syncthreads();
+        if (n < N) {
+            const int kmax = min(DENSE_KT, K - k0);
+            for (int kk = 0; kk < kmax; ++kk) {
+                const float w = wt[(long long)(k0 + kk) * N + n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += w * xs[pg * 4 + j][kk];
+            }
+        }
+        __syncthreads();
+    }
+    if (n >= N) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = p0 + pg * 4 + j;
+        if (p >= P) continue;
+        float v = acc[j] + (bias ? bias[n] : 0.f);
+        if (mode == 1) v = lrelu_sqrt2(v);
+        else if (mode == 2) v = rsqrtf(v + eps_row[(long long)p * eps_stride]);
+        out[(long long)p * ldo + n] = v;
+    }
+}
+void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
+                  float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
+                  hipStream_t st) {
+    dim3 g((N + 63) / 64, (P + DENSE_PB - 1) / DENSE_PB);
+    hipLaunchKernelGGL(dense_kernel, g, dim3(256), 0, st, x, ldx, P, K, wt, N, bias, out, ldo, in_sq, mode,
+                       eps_row, eps_stride);
+}
+
+// ---- style normalisation: keeps x*s inside fp16 range; exact algebra:
+//   d*conv(x*s) == (d*smax) * conv(x * (s/smax)),  d*smax = rsqrt(sum (s/smax)^2 Wsq + eps/smax^2)
+__global__ void style_norm_kernel(float* s, int ld, const int* off, const int* len, int n_layers, float* smax,
+                                  float* eps_row, float eps) {
+    const int p = blockIdx.x, l = blockIdx.y, lane = threadIdx.x;
+    float* sp = s + (long long)p * ld + off[l];
+    const int n = len[l];
+    float m = 0.f;
+    for (int i = lane; i < n; i += 64) m = fmaxf(m, fabsf(sp[i]));
+    m = fmaxf(wave_max(m), 1e-20f);
+    const float inv = 1.f / m;
+    for (int i = lane; i < n; i += 64) sp[i] *= inv;
+    if (lane == 0) {
+        smax[(long long)p * n_layers + l] = m;
+        eps_row[(long long)p * n_layers + l] = eps * inv * inv;
+    }
+}
+void launch_style_norm(float* s, int ld, int P, int n_layers, const int* d_off, const int* d_len, float* smax,
+                       float* eps_row, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(style_norm_kernel, dim3(P, n_layers), dim3(64), 0, st, s, ld, d_off, d_len, n_layers,
+                       smax, eps_row, eps);
+}
+
+// ---- noise planes: Philox4x32-10 + Box-Muller (numpy mirror: clip_glass_amd/synth.py) --
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)c[0] * 0xD2511F53ull, p1 = (uint64_t)c[2] * 0xCD9E8D57ull;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ void noise_kernel(float* out, int hw, uint32_t layer, uint32_t mb0, uint32_t generation, uint32_t k0,
+                             uint32_t k1) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nq = (hw + 3) / 4;
+    if (q >= nq) return;
+    const uint32_t mb = mb0 + blockIdx.y;
+    uint32_t c[4] = {(uint32_t)q, layer, mb, generation};
+    philox4x32_10(c, k0, k1);
+    float u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = ((float)c[j] + 0.5f) * 2.3283064365386963e-10f;
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float rad = sqrtf(-2.0f * logf(u[2 * j]));
+        const float ang = 6.283185307179586f * u[2 * j + 1];
+        o[2 * j] = rad * cosf(ang);
+        o[2 * j + 1] = rad * sinf(ang);
+    }
+    float* op = out + (long long)blockIdx.y * hw;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (q * 4 + j < hw) op[q * 4 + j] = o[j];
+}
+void launch_noise(float* out, int n_mb, int hw, uint32_t layer, uint32_t mb0, uint32_t generation, uint64_t seed,
+                  hipStream_t st) {
+    const int nq = (hw + 3) / 4;
+    hipLaunchKernelGGL(noise_kernel, dim3((nq + 255) / 256, n_mb), dim3(256), 0, st, out, hw, layer, mb0,
+                       generation, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
+}
+
+// ---- toRGB (1x1 modulated conv, no demod: stylegan2/models.py:852-870) fused with the
+// FIR-upsampled skip sum (models.py:1004-1013; Upsample.forward modules.py:580-602).
+// Upsample taps (zero-insert, pad [3,1], 4x4 FIR*4): out[2m] = .75 x[m-1] + .25 x[m],
+// out[2m+1] = .25 x[m-1] + .75 x[m]  (derived + checked in tests/test_host_math.py).
+__global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int W, int C, const float* wrgb,
+                                                    const float* bias, const float* sn, int sn_stride,
+                                                    const float* smax, int smax_stride, const float* yprev,
+                                                    float* yout) {
+    extern __shared__ float wl[];  // [3][C] modulated weights of this sample
+    const int b = blockIdx.y;
+    const float sm = smax[(long long)b * smax_stride];
+    for (int e = threadIdx.x; e < 3 * C; e += 256) {
+        const int i = e % C;
+        wl[e] = wrgb[e] * sn[(long long)b * sn_stride + i] * sm;
+    }
+    __syncthreads();
+    const int hw = H * W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    const half_t* xp = x + ((long long)b * hw + pix) * C;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = 0; i < C; i += 8) {
+        const h8 v = *(const h8*)(xp + i);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j];
+            a0 += f * wl[i + j];
+            a1 += f * wl[C + i + j];
+            a2 += f * wl[2 * C + i + j];
+        }
+    }
+    float r[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
+    if (yprev) {
+        const int py = pix / W, px = pix - py * W;
+        const int h2 = H >> 1, w2 = W >> 1;
+        const int my = py >> 1, mx = px >> 1;
+        const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2;
+            float s = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int sy = my - 1 + dy;
+                if (sy < 0) continue;
+                const float wy = dy ? 1.f - wy0 : wy0;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int sx = mx - 1 + dx;
+                    if (sx < 0) continue;
+                    const float wx = dx ? 1.f - wx0 : wx0;
+                    s += wy * wx * yp[sy * w2 + sx];
+                }
+            }
+            r[c] += s;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yout[((long long)b * 3 + c) * hw + pix] = r[c];
+}
+void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
+                  const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
+                  float* yout, hipStream_t st) {
+    dim3 g((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(torgb_kernel, g, dim3(256), 3 * C * sizeof(float), st, x, H, W, C, wrgb, bias, sn,
+                       sn_stride, smax, smax_stride, yprev, yout);
+}
+
+// ---- biggan_norm: utils.py:14-17 ---------------------------------------------------
+__global__ void finalize_image_kernel(const float* y, float* img, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) img[i] = fminf(fmaxf((y[i] + 1.f) * 0.5f, 0.f), 1.f);
+}
+void launch_finalize_image(const float* y, float* img, long long n, hipStream_t st) {
+    hipLaunchKernelGGL(finalize_image_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, img, n);
+}
+
+// ---- kornia.resize(x,(224,224)) (generator.py:45) on biggan_norm(y), written straight
+// into the patch-embedding GEMM operand: row = b*G*G + gy*G + gx, col = c*ps*ps + iy*ps + ix
+// (conv1.weight.reshape(width, -1) order, clip/model.py:206,219).
+__global__ void resize_patches_kernel(const float* y, int B, int R, int S, int ps, half_t* patches) {
+    const int G = S / ps;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over b, c, Y, X
+    const int X = (int)(idx % S);
+    const int Y = (int)((idx / S) % S);
+    const int c = (int)((idx / ((long long)S * S)) % 3);
+    const int b = (int)(idx / ((long long)S * S * 3));
+    if (b >= B) return;
+    const float scale = (float)R / (float)S;
+    float sy = scale * ((float)Y + 0.5f) - 0.5f, sx = scale * ((float)X + 0.5f) - 0.5f;
+    sy = fmaxf(sy, 0.f); sx = fmaxf(sx, 0.f);
+    const int y0 = min((int)sy, R - 1), x0 = min((int)sx, R - 1);
+    const int y1 = min(y0 + 1, R - 1), x1 = min(x0 + 1, R - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* yp = y + ((long long)b * 3 + c) * R * R;
+    auto nrm = [](float v) { return fminf(fmaxf((v + 1.f) * 0.5f, 0.f), 1.f); };
+    const float v00 = nrm(yp[(long long)y0 * R + x0]), v01 = nrm(yp[(long long)y0 * R + x1]);
+    const float v10 = nrm(yp[(long long)y1 * R + x0]), v11 = nrm(yp[(long long)y1 * R + x1]);
+    const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    const int gy = Y / ps, iy = Y - gy * ps, gx = X / ps, ix = X - gx * ps;
+    const long long row = ((long long)b * G + gy) * G + gx;
+    patches[row * (3LL * ps * ps) + ((long long)c * ps + iy) * ps + ix] = (half_t)v;
+}
+void launch_resize_patches(const float* y, int B, int R, int clip_res, int ps, half_t* patches, hipStream_t st) {
+    const long long n = 3LL * clip_res * clip_res;  // per image
+    const long long total = n * B;
+    hipLaunchKernelGGL(resize_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, B, R,
+                       clip_res, ps, patches);
+}
+
+// ---- D fromRGB: biggan_denorm (utils.py:19-21) + 1x1 conv 3->C + bias + lrelu*sqrt2
+// (stylegan2/models.py:1125-1143).  One thread per pixel, 16-byte NHWC stores.
+__global__ __launch_bounds__(256) void fromrgb_kernel(const float* y, int hw, int Cout, const float* w,
+                                                      const float* bias, half_t* out) {
+    extern __shared__ float wl[];  // [Cout][3] then bias[Cout]
+    for (int e = threadIdx.x; e < Cout * 3; e += 256) wl[e] = w[e];
+    for (int e = threadIdx.x; e < Cout; e += 256) wl[Cout * 3 + e] = bias[e];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= hw) return;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float n = fminf(fmaxf((y[((long long)b * 3 + c) * hw + pix] + 1.f) * 0.5f, 0.f), 1.f);
+        v[c] = n * 2.f - 1.f;
+    }
+    half_t* op = out + ((long long)b * hw + pix) * Cout;
+    for (int o = 0; o < Cout; o += 8) {
+        h8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wp = wl + (o + j) * 3;
+            r[j] = (half_t)lrelu_sqrt2(wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2] + wl[Cout * 3 + o + j]);
+        }
+        *(h8*)(op + o) = r;
+    }
+}
+void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, const float* bias, half_t* out,
+                    hipStream_t st) {
+    const int hw = R * R;
+    hipLaunchKernelGGL(fromrgb_kernel, dim3((hw + 255) / 256, B), dim3(256), Cout * 4 * sizeof(float), st, y, hw,
+                       Cout, w, bias, out);
+}
+
+// ---- FIR filters of the D down path (modules.py:1204-1220, 499-523) -----------------
+// separable [1,3,3,1]/8 per axis; thread = (pixel, 8-channel group).
+template <int PAD, int STRIDE>
+__global__ __launch_bounds__(256) void blur_kernel(const half_t* x, int H, int W, int C, int Ho, int Wo,
+                                                   half_t* out) {
+    const int cg = C >> 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)Ho * Wo * cg;
+    if (idx >= total) return;
+    const int b = blockIdx.y;
+    const int g = (int)(idx % cg);
+    const int ox = (int)((idx / cg) % Wo);
+    const int oy = (int)(idx / ((long long)cg * Wo));
+    const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const half_t* xb = x + (long long)b * H * W * C + g * 8;
+#pragma unroll
+    for (int jy = 0; jy < 4; ++jy) {
+        const int iy = oy * STRIDE + jy - PAD;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const int ix = ox * STRIDE + jx - PAD;
+            if (ix < 0 || ix >= W) continue;
+            const h8 v = *(const h8*)(xb + ((long long)iy * W + ix) * C);
+            const float wgt = f[jy] * f[jx];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)v[j];
+        }
+    }
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (half_t)acc[j];
+    *(h8*)(out + (((long long)b * Ho + oy) * Wo + ox) * C + g * 8) = r;
+}
+void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
+    const int Ho = H + 1, Wo = W + 1;
+    const long long total = (long long)Ho * Wo * (C >> 3);
+    hipLaunchKernelGGL((blur_kernel<2, 1>), dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, st, x, H, W, C,
+                       Ho, Wo, out);
+}
+void launch_blur_down(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)Ho * Wo * (C >> 3);
+    hipLaunchKernelGGL((blur_kernel<1, 2>), dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, st, x, H, W, C,
+                       Ho, Wo, out);
+}
+
+// ---- MinibatchStd (modules.py:701-747).  Per D call (minibatch of batch_size), groups of
+// `group`: sample s belongs to sub-group s % (batch_size/group).  Emits the group-mean-
+// subtracted features (reference in-place quirk, see oracle/stylegan2_ref.py) + std channel.
+__global__ __launch_bounds__(256) void mbstd_kernel(const half_t* x, int hw, int C, int Cpad, int batch_size,
+                                                    int group, float eps, half_t* out) {
+    __shared__ float red[4];
+    const int nsub = batch_size / group;
+    const int mb = blockIdx.x / nsub, j = blockIdx.x % nsub;
+    const int n = hw * C;
+    float sum = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        float v[8];
+        float mean = 0.f;
+        for (int g = 0; g < group; ++g) {
+            const int s = mb * batch_size + j + g * nsub;
+            v[g] = (float)x[(long long)s * n + e];
+            mean += v[g];
+        }
+        mean /= (float)group;
+        float var = 0.f;
+        const int pix = e / C, c = e - pix * C;
+        for (int g = 0; g < group; ++g) {
+            const int s = mb * batch_size + j + g * nsub;
+            const float d = v[g] - mean;
+            var += d * d;
+            out[((long long)s * hw + pix) * Cpad + c] = (half_t)d;
+        }
+        sum += sqrtf(var / (float)group + eps);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float stdv = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    for (int e = threadIdx.x; e < group * hw * (Cpad - C); e += 256) {
+        const int cc = e % (Cpad - C);
+        const int pix = (e / (Cpad - C)) % hw;
+        const int g = e / ((Cpad - C) * hw);
+        const int s = mb * batch_size + j + g * nsub;
+        out[((long long)s * hw + pix) * Cpad + C + cc] = (half_t)(cc == 0 ? stdv : 0.f);
+    }
+}
+void launch_mbstd(const half_t* x, int B, int hw, int C, int Cpad, int batch_size, int group, float eps,
+                  half_t* out, hipStream_t st) {
+    const int nsub = batch_size / group;
+    hipLaunchKernelGGL(mbstd_kernel, dim3((B / batch_size) * nsub), dim3(256), 0, st, x, hw, C, Cpad, batch_size,
+                       group, eps, out);
+}

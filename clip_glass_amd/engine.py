@@ -1,0 +1,198 @@
+"""ctypes binding of libglass.so (include/glass.h) — the drop-in boundary.
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C clip_glass_amd/csrc`.
+There is NO CPU fallback: if the shared library is missing or the HIP device is
+absent, construction raises (the reference would `sys.exit(1)` on missing weights,
+models.py:18-20,93-101; here errors surface as RuntimeError with glass_last_error()).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglass.so")
+MAX_BLOCKS = 12
+
+
+class GlassConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_blocks", C.c_int32), ("channels", C.c_int32 * MAX_BLOCKS),
+                ("latent_size", C.c_int32), ("mapping_layers", C.c_int32), ("batch_size", C.c_int32),
+                ("mbstd_group", C.c_int32), ("use_discriminator", C.c_int32), ("n_obj", C.c_int32),
+                ("max_pop", C.c_int32), ("chunk", C.c_int32),
+                ("clip_width", C.c_int32), ("clip_layers", C.c_int32), ("clip_heads", C.c_int32),
+                ("clip_patch", C.c_int32), ("clip_res", C.c_int32), ("clip_embed", C.c_int32),
+                ("noise_mode", C.c_int32), ("noise_seed", C.c_uint64)]
+
+
+class GlassNoise(C.Structure):
+    _fields_ = [("n_minibatches", C.c_int32), ("n_layers", C.c_int32),
+                ("planes", C.POINTER(C.POINTER(C.c_float)))]
+
+
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libglass.so; raises OSError/RuntimeError loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("libglass.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C clip_glass_amd/csrc` — there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    lib.glass_last_error.restype = C.c_char_p
+    lib.glass_version.restype = C.c_char_p
+    lib.glass_engine_create.argtypes = [C.POINTER(GlassConfig), C.POINTER(C.c_void_p)]
+    lib.glass_engine_destroy.argtypes = [C.c_void_p]
+    lib.glass_engine_destroy.restype = None
+    lib.glass_engine_load_tensor.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int32, C.POINTER(C.c_int64)]
+    lib.glass_engine_finalize.argtypes = [C.c_void_p]
+    lib.glass_engine_set_target.argtypes = [C.c_void_p, fp, C.c_int32]
+    lib.glass_engine_evaluate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
+    lib.glass_engine_generate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
+    lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
+    lib.glass_engine_last_gpu_ms.argtypes = [C.c_void_p, fp]
+    lib.glass_engine_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.glass_engine_get_profile.argtypes = [C.c_void_p, C.POINTER(ProfRow), C.c_int32, C.POINTER(C.c_int32)]
+    lib.glass_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise RuntimeError("libglass error %d: %s" % (rc, lib.glass_last_error().decode()))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def device_info(device=0):
+    lib = load_library()
+    name = C.create_string_buffer(256)
+    cus = C.c_int32()
+    mem = C.c_int64()
+    _check(lib, lib.glass_device_info(device, name, 256, C.byref(cus), C.byref(mem)))
+    return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=mem.value)
+
+
+class Engine:
+    """One engine per (process, GPU).  Not thread-safe; evaluate() is blocking."""
+
+    def __init__(self, channels, latent_size=512, mapping_layers=8, batch_size=4, use_discriminator=True,
+                 n_obj=2, max_pop=64, chunk=0, clip=(768, 12, 12, 32, 224, 512), noise_mode=1, noise_seed=0,
+                 mbstd_group=4, device=0):
+        self.lib = load_library()
+        cfg = GlassConfig()
+        cfg.device = device
+        cfg.n_blocks = len(channels)
+        for i, c in enumerate(channels):  # LOW -> HIGH resolution
+            cfg.channels[i] = int(c)
+        cfg.latent_size, cfg.mapping_layers, cfg.batch_size = latent_size, mapping_layers, batch_size
+        cfg.mbstd_group, cfg.use_discriminator, cfg.n_obj = mbstd_group, int(bool(use_discriminator)), n_obj
+        cfg.max_pop, cfg.chunk = max_pop, chunk
+        (cfg.clip_width, cfg.clip_layers, cfg.clip_heads, cfg.clip_patch, cfg.clip_res, cfg.clip_embed) = clip
+        cfg.noise_mode, cfg.noise_seed = noise_mode, noise_seed
+        self.cfg = cfg
+        self.channels = list(channels)
+        self.res = 4 << (len(channels) - 1)
+        self.n_noise = 1 + 2 * (len(channels) - 1)
+        self._h = C.c_void_p()
+        _check(self.lib, self.lib.glass_engine_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.glass_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- weights -------------------------------------------------------------
+    def load_tensor(self, name, array):
+        a = _f32(array)
+        dims = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+        _check(self.lib, self.lib.glass_engine_load_tensor(self._h, name.encode(), _fp(a), a.ndim, dims))
+
+    def load_state(self, state):
+        for k, v in state.items():
+            self.load_tensor(k, np.asarray(v))
+
+    def finalize(self):
+        _check(self.lib, self.lib.glass_engine_finalize(self._h))
+
+    def set_target(self, feat):
+        f = _f32(feat).reshape(-1)
+        _check(self.lib, self.lib.glass_engine_set_target(self._h, _fp(f), f.size))
+
+    # --- the pass ------------------------------------------------------------
+    def _noise_arg(self, noise):
+        """noise: list (per minibatch) of lists (per layer) of [res,res] float32 planes."""
+        if noise is None:
+            return None, None
+        flat = [_f32(p) for mb in noise for p in mb]
+        arr = (C.POINTER(C.c_float) * len(flat))(*[_fp(p) for p in flat])
+        gn = GlassNoise(len(noise), len(noise[0]), arr)
+        return gn, (flat, arr)
+
+    def evaluate(self, x, generation=0, first_minibatch=0, noise=None):
+        """problem.py:14-29 — returns F float32 [P, n_obj]."""
+        z = _f32(x)
+        P = z.shape[0]
+        out = np.empty((P, self.cfg.n_obj), dtype=np.float32)
+        gn, keep = self._noise_arg(noise)
+        _check(self.lib, self.lib.glass_engine_evaluate(self._h, _fp(z), P, generation, first_minibatch,
+                                                         C.byref(gn) if gn is not None else None, _fp(out)))
+        del keep
+        return out
+
+    def generate(self, x, generation=0, first_minibatch=0, noise=None):
+        """generator.py:29-34 — images float32 [P,3,R,R] in [0,1]."""
+        z = _f32(x)
+        P = z.shape[0]
+        out = np.empty((P, 3, self.res, self.res), dtype=np.float32)
+        gn, keep = self._noise_arg(noise)
+        _check(self.lib, self.lib.glass_engine_generate(self._h, _fp(z), P, generation, first_minibatch,
+                                                         C.byref(gn) if gn is not None else None, _fp(out)))
+        del keep
+        return out
+
+    def details(self, P):
+        feat = np.empty((P, self.cfg.clip_embed), dtype=np.float32)
+        dis = np.empty((P,), dtype=np.float32)
+        sim = np.empty((P,), dtype=np.float32)
+        _check(self.lib, self.lib.glass_engine_last_details(self._h, P, _fp(feat), _fp(dis), _fp(sim)))
+        return dict(features=feat, dis=dis, sim=sim)
+
+    def last_gpu_ms(self):
+        ms = C.c_float()
+        _check(self.lib, self.lib.glass_engine_last_gpu_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        _check(self.lib, self.lib.glass_engine_set_profiling(self._h, int(on)))
+
+    def profile(self):
+        n = C.c_int32()
+        _check(self.lib, self.lib.glass_engine_get_profile(self._h, None, 0, C.byref(n)))
+        rows = (ProfRow * max(n.value, 1))()
+        _check(self.lib, self.lib.glass_engine_get_profile(self._h, rows, n.value, C.byref(n)))
+        return [dict(name=r.name.decode(), launches=r.launches, total_ms=r.total_ms, flops=r.flops, bytes=r.bytes)
+                for r in rows[:n.value]]

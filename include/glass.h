@@ -1,0 +1,126 @@
+/* glass.h — C ABI of the MI355X CLIP-GLaSS fitness-evaluation engine (libglass.so).
+ *
+ * Drop-in boundary: the reference evaluates a population through
+ *   GenerationProblem._evaluate(x, out)            /root/reference/problem.py:14-29
+ *     -> Generator.generate / clip_similarity / discriminate   generator.py:29-60
+ *     -> models.StyleGAN2.generate / discriminate              models.py:108-129
+ * in one Python process on one device.  This library replaces everything below
+ * `_evaluate` with one engine object per (process, GPU); the Python shim
+ * clip_glass_amd/problem.py keeps the pymoo-facing signature and calls these
+ * entry points through ctypes (see INTEGRATION.md for the stub a reference
+ * maintainer would add).
+ *
+ * Conventions: plain pointers and sizes, host buffers owned by the caller, no
+ * aliasing retained after return.  Every function returns GLASS_OK (0) or a
+ * negative status; glass_last_error() gives the thread-local message.  The
+ * engine is not thread-safe; evaluate() is blocking.
+ */
+#ifndef GLASS_H
+#define GLASS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLASS_OK 0
+#define GLASS_ERR_ARG -1      /* bad argument / shape (reference: assert, models.py:112,124) */
+#define GLASS_ERR_STATE -2    /* call order (weights missing: reference sys.exit(1), models.py:93-101) */
+#define GLASS_ERR_HIP -3      /* HIP runtime failure */
+#define GLASS_ERR_NOMEM -4
+
+#define GLASS_MAX_BLOCKS 12
+
+typedef struct glass_engine glass_engine;
+
+/* Architecture + semantics.  Mirrors the fields the reference reads from its merged
+ * argparse/config Namespace (config.py:80-95; stylegan2/models.py kwargs). */
+typedef struct glass_config {
+    int32_t device;               /* HIP device ordinal (reference: --device, run.py:17) */
+    int32_t n_blocks;             /* number of resolutions, 4*2^(n_blocks-1) px output (9 -> 1024) */
+    int32_t channels[GLASS_MAX_BLOCKS]; /* channels per resolution, LOW -> HIGH res
+                                     (reference G order reversed: stylegan2/models.py:748-750) */
+    int32_t latent_size;          /* 512 */
+    int32_t mapping_layers;       /* 8   (stylegan2/models.py:547) */
+    int32_t batch_size;           /* config.batch_size: semantic minibatch — one noise plane per G call
+                                     (modules.py:428-452) and mbstd groups per D call (modules.py:726) */
+    int32_t mbstd_group;          /* 4   (stylegan2/models.py:1047) */
+    int32_t use_discriminator;    /* config.use_discriminator */
+    int32_t n_obj;                /* problem_args["n_obj"] (problem.py:21) */
+    int32_t max_pop;              /* capacity in candidates (rows of x) */
+    int32_t chunk;                /* candidates resident per pass at high resolution (multiple of batch_size; 0 = auto) */
+    int32_t clip_width, clip_layers, clip_heads, clip_patch, clip_res, clip_embed; /* 768,12,12,32,224,512 */
+    int32_t noise_mode;           /* 0 none, 1 device Philox N(0,1) planes, 2 caller-provided planes */
+    uint64_t noise_seed;
+} glass_config;
+
+/* Caller-provided noise (noise_mode 2): planes[m * n_layers + l] points at a host
+ * float32 [res_l, res_l] plane for global minibatch m and noise layer l in execution
+ * order (== G.static_noise(noise_tensors=...) order, stylegan2/models.py:945-959). */
+typedef struct glass_noise {
+    int32_t n_minibatches;
+    int32_t n_layers;
+    const float* const* planes;
+} glass_noise;
+
+const char* glass_last_error(void);
+const char* glass_version(void);
+
+int glass_engine_create(const glass_config* cfg, glass_engine** out);
+void glass_engine_destroy(glass_engine* e);
+
+/* Hand one reference tensor to the engine: `name` is the reference state-dict key
+ * prefixed with its sub-model ("G_mapping.", "G_synthesis.", "D.", "clip."), data is
+ * host float32, row-major, dims[rank].  Replaces stylegan2.models.load (models.py:183-196)
+ * + clip.load/build_model (clip/model.py:363-399).  Tensors are repacked into kernel
+ * layouts (pre-scaled, fp16, folded FIR) by glass_engine_finalize. */
+int glass_engine_load_tensor(glass_engine* e, const char* name, const float* data,
+                             int32_t rank, const int64_t* dims);
+int glass_engine_finalize(glass_engine* e);
+
+/* Target text feature, host float32 [clip_embed] (generator.py:23-24: encode_text once). */
+int glass_engine_set_target(glass_engine* e, const float* feat, int32_t n);
+
+/* THE HOT PATH — replaces GenerationProblem._evaluate (problem.py:14-29).
+ * latents: host float32 [P, latent_size] row-major (latent.py:37-38);
+ * generation: index folded into the device noise stream (noise_mode 1);
+ * first_minibatch: global index of this call's first minibatch (population shards);
+ * noise: nullable, used when noise_mode == 2;
+ * out_F: host float32 [P, n_obj]: F[:,0] = -cosine, F[:,1] = relu(1 - D) (problem.py:23-27).
+ * P must be a multiple of batch_size (reference asserts: models.py:112). */
+int glass_engine_evaluate(glass_engine* e, const float* latents, int32_t P, int32_t generation,
+                          int32_t first_minibatch, const glass_noise* noise, float* out_F);
+
+/* Extra outputs of the same pass (nullable each): CLIP image features [P, clip_embed],
+ * raw discriminator logits [P], cosine similarities [P]. Valid after evaluate(). */
+int glass_engine_last_details(glass_engine* e, int32_t P, float* features, float* dis, float* sim);
+
+/* Generator.generate (generator.py:29-34): images host float32 [P,3,R,R] NCHW after
+ * biggan_norm (utils.py:14-17).  Used by run.py's callbacks (run.py:45,118). */
+int glass_engine_generate(glass_engine* e, const float* latents, int32_t P, int32_t generation,
+                          int32_t first_minibatch, const glass_noise* noise, float* images);
+
+/* GPU time of the last evaluate() in ms, from hipEvents on the engine's stream. */
+int glass_engine_last_gpu_ms(glass_engine* e, float* ms);
+
+/* Per-kernel profile (hipEvent pairs around every launch while enabled).
+ * After evaluate(): n rows of {name, launches, total_ms, flops, bytes} — algorithmic
+ * flops/bytes per DESIGN.md.  Used by bench.py for the `roofline` object. */
+typedef struct glass_prof_row {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} glass_prof_row;
+int glass_engine_set_profiling(glass_engine* e, int32_t on);
+int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_rows, int32_t* n_rows);
+
+/* Device info for bench.py (CU count, name, HBM bytes). */
+int glass_device_info(int32_t device, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLASS_H */

@@ -1,0 +1,51 @@
+"""Model configurations used by the parity tests (test infrastructure).
+
+`channels` is in the reference's G order (last layer -> first layer, stylegan2/models.py:655-660);
+the engine takes them LOW -> HIGH resolution, i.e. reversed."""
+import numpy as np
+
+from clip_glass_amd import synth
+
+CONFIGS = {
+    # 32 px, everything tiny: runs through the reference/oracle in well under a second
+    "mini": dict(channels=[16, 16, 32, 32], latent=32, mapping=2, clip=(64, 2, 1, 8, 32, 32)),
+    # 64 px, channel counts that reach the LDS-tiled kernels (W >= 32), resize 64 -> 32
+    "mid": dict(channels=[32, 64, 64, 64, 64], latent=64, mapping=3, clip=(128, 2, 2, 8, 32, 64)),
+    # the real thing: StyleGAN2 ffhq config-f 1024 px + CLIP ViT-B/32
+    "ffhq": dict(channels=synth.FFHQ_CHANNELS, latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
+}
+
+
+def make_state(name, seed=0, with_d=True):
+    c = CONFIGS[name]
+    sd = synth.make_state(synth.stylegan2_g_spec(c["channels"], c["latent"], c["mapping"]), seed)
+    if with_d:
+        sd.update(synth.make_state(synth.stylegan2_d_spec(c["channels"]), seed))
+    w, layers, heads, patch, res, emb = c["clip"]
+    sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), seed))
+    return sd
+
+
+def make_engine(name, sd, *, batch_size=4, use_discriminator=True, max_pop=8, noise_mode=2, noise_seed=0, chunk=0):
+    from clip_glass_amd.engine import Engine
+    c = CONFIGS[name]
+    e = Engine(c["channels"][::-1], latent_size=c["latent"], mapping_layers=c["mapping"], batch_size=batch_size,
+               use_discriminator=use_discriminator, n_obj=2 if use_discriminator else 1, max_pop=max_pop,
+               chunk=chunk, clip=c["clip"], noise_mode=noise_mode, noise_seed=noise_seed)
+    e.load_state(sd)
+    e.finalize()
+    return e
+
+
+def noise_planes(name, seed, generation, n_mb, first_mb=0):
+    c = CONFIGS[name]
+    return [synth.g_noise_planes(seed, generation, first_mb + m, c["channels"]) for m in range(n_mb)]
+
+
+def make_target(feats, seed=0, spread=0.6):
+    """Target feature giving cosine sims well away from 0 (relative 1e-3 is
+    ill-conditioned near 0): unit(feats[0]) + spread * unit(random)."""
+    f0 = np.asarray(feats[0], dtype=np.float64)
+    r = synth.normal(seed, "target", f0.shape).astype(np.float64)
+    t = f0 / np.linalg.norm(f0) + spread * r / np.linalg.norm(r)
+    return t.astype(np.float32)

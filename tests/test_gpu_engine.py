@@ -1,0 +1,101 @@
+"""End-to-end parity through the drop-in C ABI (include/glass.h): engine.evaluate /
+generate vs the oracle's `_evaluate` restatement on the same seeded weights, latents
+and noise.  Tolerance on CLIP similarity: 1e-3 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from clip_glass_amd import synth
+from oracle import fitness_ref
+import models as M
+from util import check, diag
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(sd):
+    return {k: torch.as_tensor(v) for k, v in sd.items()}
+
+
+def _run_case(name, P, batch_size, use_d, noise_mode, chunk=0, seed=0):
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, seed, with_d=use_d)
+    x = synth.latents(seed + 1, P, c["latent"])
+    n_mb = P // batch_size
+    planes = M.noise_planes(name, 77, 3, n_mb)
+    tsd = _t(sd)
+    detail = {}
+    noise_fn = (lambda i: planes[i]) if noise_mode else None
+    # oracle pass 1 (features) -> target -> oracle F
+    Fo, Go = fitness_ref.evaluate(tsd, x, np.ones(c["clip"][5], np.float32), batch_size, use_d, noise_fn,
+                                  clip_size=c["clip"][4], detail=detail)
+    feats = detail["features"].numpy()
+    target = M.make_target(feats)
+    sim_o = torch.cosine_similarity(detail["features"], torch.tensor(target)[None]).numpy()
+    e = M.make_engine(name, sd, batch_size=batch_size, use_discriminator=use_d, max_pop=P,
+                      noise_mode=noise_mode, noise_seed=77, chunk=chunk)
+    e.set_target(target)
+    Fe = e.evaluate(x, generation=3, noise=planes if noise_mode == 2 else None)
+    det = e.details(P)
+    img = e.generate(x, generation=3, noise=planes if noise_mode == 2 else None)
+    e.close()
+    tag = "%s P%d bs%d d%d nm%d ch%d" % (name, P, batch_size, use_d, noise_mode, chunk)
+    check(tag + " image", img, detail["image"].numpy(), 5e-3)
+    check(tag + " clip features", det["features"], feats, 5e-3)
+    rel = np.abs(det["sim"] - sim_o) / np.abs(sim_o)
+    diag("[e2e] %s sim range [%.3f, %.3f] max rel err %.3e" % (tag, sim_o.min(), sim_o.max(), rel.max()))
+    assert rel.max() < 1e-3, "CLIP similarity relative error %.3e > 1e-3" % rel.max()
+    np.testing.assert_allclose(Fe[:, 0], -det["sim"], rtol=0, atol=1e-7)
+    if use_d:
+        dis_o = detail["dis"].numpy()[:, 0]
+        check(tag + " D logits", det["dis"], dis_o, 5e-3, atol=2e-3)
+        check(tag + " hinge", Fe[:, 1], np.maximum(1 - dis_o, 0), 5e-3, atol=2e-3)
+    return Fe
+
+
+@pytest.mark.parametrize("name", ["mini", "mid"])
+@pytest.mark.parametrize("use_d", [True, False])
+def test_evaluate_matches_oracle_explicit_noise(name, use_d):
+    _run_case(name, P=8, batch_size=4, use_d=use_d, noise_mode=2)
+
+
+def test_evaluate_device_noise_and_chunking():
+    """Device Philox noise == numpy mirror fed to the oracle; result independent of chunk size."""
+    F1 = _run_case("mini", P=16, batch_size=4, use_d=True, noise_mode=1, chunk=4)
+    F2 = _run_case("mini", P=16, batch_size=4, use_d=True, noise_mode=1, chunk=16)
+    np.testing.assert_allclose(F1, F2, rtol=0, atol=1e-6)
+
+
+def test_batch_size_semantics():
+    """batch_size is semantic (noise sharing + mbstd groups): bs=8 groups != bs=4 groups, both match the oracle."""
+    _run_case("mini", P=8, batch_size=8, use_d=True, noise_mode=2)
+
+
+def test_no_noise():
+    _run_case("mini", P=4, batch_size=4, use_d=True, noise_mode=0)
+
+
+def test_error_paths():
+    sd = M.make_state("mini", 0)
+    e = M.make_engine("mini", sd, max_pop=8, noise_mode=0)
+    x = synth.latents(1, 6, 32)
+    with pytest.raises(RuntimeError, match="multiple of batch_size"):
+        e.evaluate(x)            # reference: assert z.shape[0] % minibatch == 0 (models.py:112)
+    with pytest.raises(RuntimeError, match="set_target"):
+        e.evaluate(synth.latents(1, 8, 32))
+    with pytest.raises(RuntimeError, match="max_pop"):
+        e.generate(synth.latents(1, 12, 32))
+    e.close()
+    from clip_glass_amd.engine import Engine
+    e2 = Engine([32, 32, 16, 16], latent_size=32, mapping_layers=2, clip=M.CONFIGS["mini"]["clip"])
+    with pytest.raises(RuntimeError, match="missing tensor"):
+        e2.finalize()            # reference: sys.exit(1) on missing weights (models.py:93-101)
+    e2.close()
+
+
+def test_full_size_ffhq_one_minibatch():
+    """StyleGAN2 ffhq config-f 1024 px + D + CLIP ViT-B/32 at true sizes, P=4 (one minibatch)."""
+    import time
+    t = time.time()
+    _run_case("ffhq", P=4, batch_size=4, use_d=True, noise_mode=2, chunk=4)
+    diag("[e2e] full-size ffhq P=4 wall (oracle + engine + weight synthesis): %.1f s" % (time.time() - t))

@@ -1,0 +1,206 @@
+"""Per-kernel parity: each HIP kernel family (through the diagnostic C ABI,
+include/glass_ops.h) against the oracle's corresponding torch-CPU op."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from clip_glass_amd import synth
+from oracle import stylegan2_ref as sg
+from util import check, nchw, nhwc, style_tables
+
+pytestmark = pytest.mark.gpu
+ops = None
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib():
+    global ops
+    import os
+    if os.environ.get("GLASS_EMULATE"):      # CPU dry-run of the tests + kernel math (tests/emu_ops.py)
+        import emu_ops as _ops
+    else:
+        from clip_glass_amd import ops as _ops
+    ops = _ops
+    yield
+
+
+def rnd(seed, name, shape, std=1.0):
+    return synth.normal(seed, name, shape, std)
+
+
+def h16(a):
+    """Round to fp16 like the device does for activations / weights."""
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def test_mfma_fragment_layout():
+    a = rnd(1, "a", (32, 16)); b = rnd(1, "b", (16, 32))
+    d = ops.mfma_probe(a, b)
+    check("mfma32x32x16 layout", d, h16(a).astype(np.float64) @ h16(b).astype(np.float64), 1e-3)
+
+
+@pytest.mark.parametrize("impl", [1])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 12, 32, 48), (2, 5, 16, 16), (1, 33, 64, 160)])
+def test_conv_plain_bias_act(impl, B, H, Cin, Cout):
+    x = rnd(2, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3)); bias = rnd(2, "b", (Cout,), 0.3)
+    ref = sg._bias_act(sg._conv(torch.tensor(h16(x)), torch.tensor(w), padding=1), torch.tensor(bias)).numpy()
+    got = ops.conv(nhwc(x), w, bias=bias, act=True, impl=impl)
+    check("conv3x3 B%d H%d %d->%d impl%d" % (B, H, Cin, Cout, impl), nchw(got), ref, 4e-3)
+
+
+def _modconv_case(up, impl, B=4, H=8, Cin=32, Cout=48, L=24, batch_size=2, broadcast=False):
+    x = rnd(3, "x", (1 if broadcast else B, Cin, H, H)); w = rnd(3, "w", (Cout, Cin, 3, 3))
+    lat = rnd(3, "lat", (B, L)); A = rnd(3, "A", (Cin, L)); Ab = rnd(3, "Ab", (Cin,), 0.2) + 1
+    bias = rnd(3, "b", (Cout,), 0.3); strength = 0.37
+    Ho = 2 * H if up else H
+    noise = rnd(3, "noise", (B // batch_size, Ho, Ho))
+    xt = torch.tensor(h16(x)).expand(B, Cin, H, H)
+    ref = sg._mod_conv(xt, torch.tensor(lat), torch.tensor(w), torch.tensor(A), torch.tensor(Ab), demod=True, up=up)
+    ref = ref + strength * torch.tensor(noise).repeat_interleave(batch_size, dim=0)[:, None]
+    ref = sg._bias_act(ref, torch.tensor(bias)).numpy()
+    sn, smax, dscale = style_tables(lat, A, Ab, w, demod=True)
+    got = ops.conv(nhwc(x), w, up=up, sn=sn, dscale=dscale, noise=noise, noise_strength=strength,
+                   batch_size=batch_size, bias=bias, act=True, impl=impl, broadcast_x=broadcast, B=B)
+    return got, ref
+
+
+@pytest.mark.parametrize("impl", [1])
+def test_conv_modulated_demod_noise(impl):
+    got, ref = _modconv_case(False, impl)
+    check("modconv impl%d" % impl, nchw(got), ref, 5e-3)
+
+
+@pytest.mark.parametrize("impl", [1])
+def test_conv_modulated_up(impl):
+    got, ref = _modconv_case(True, impl)
+    check("modconv-up impl%d" % impl, nchw(got), ref, 5e-3)
+
+
+def test_conv_broadcast_const():
+    got, ref = _modconv_case(False, 1, B=4, H=4, Cin=32, Cout=32, broadcast=True)
+    check("modconv const-input", nchw(got), ref, 5e-3)
+
+
+@pytest.mark.parametrize("impl", [1])
+def test_d_block_pieces(impl):
+    """DiscriminatorConvBlock (modules.py:1587-1601): conv0, FIR+stride-2 conv1, FIR+1x1 skip, (h+s)/sqrt2."""
+    B, H, Cin, Cout = 2, 16, 32, 48
+    x = rnd(4, "x", (B, Cin, H, H)); w0 = rnd(4, "w0", (Cin, Cin, 3, 3)); b0 = rnd(4, "b0", (Cin,), 0.3)
+    w1 = rnd(4, "w1", (Cout, Cin, 3, 3)); b1 = rnd(4, "b1", (Cout,), 0.3); ws = rnd(4, "ws", (Cout, Cin, 1, 1))
+    xt = torch.tensor(h16(x))
+    h = sg._bias_act(sg._conv(xt, torch.tensor(w0), padding=1), torch.tensor(b0))
+    hb = sg._filter(h, sg._fir(), 2, 2)
+    h1 = sg._bias_act(sg._conv(hb, torch.tensor(w1), stride=2), torch.tensor(b1))
+    xs = sg._filter(xt, sg._fir(), 1, 1)[:, :, ::2, ::2]
+    s = sg._conv(xs, torch.tensor(ws))
+    ref = ((h1 + s) / math.sqrt(2)).numpy()
+    g_h = ops.conv(nhwc(x), w0, bias=b0, act=True, impl=impl)
+    check("D conv0", nchw(g_h), h.numpy(), 4e-3)
+    g_hb = ops.blur(g_h, 0)
+    check("D blur pad2", nchw(g_hb), hb.numpy(), 4e-3)
+    g_xs = ops.blur(nhwc(x), 1)
+    check("D blur-down", nchw(g_xs), xs.numpy(), 4e-3)
+    g_s = ops.conv(g_xs, ws, pad=0, impl=impl)
+    check("D skip 1x1", nchw(g_s), s.numpy(), 5e-3)
+    g_o = ops.conv(g_hb, w1, stride=2, pad=0, bias=b1, act=True, res=g_s, out_scale=1 / math.sqrt(2), impl=impl)
+    check("D conv1 s2 + res", nchw(g_o), ref, 6e-3)
+
+
+@pytest.mark.parametrize("impl", [1])
+def test_gemm_modes(impl):
+    M, N, K = 150, 200, 96
+    a = rnd(5, "a", (M, K)); w = rnd(5, "w", (N, K), K ** -0.5); bias = rnd(5, "b", (N,), 0.2)
+    base = h16(a).astype(np.float64) @ h16(w).astype(np.float64).T + bias
+    check("gemm f32", ops.gemm(a, w, bias, mode=3, impl=impl), base, 3e-3)
+    check("gemm f16", ops.gemm(a, w, bias, mode=0, impl=impl), base, 4e-3)
+    check("gemm quickgelu", ops.gemm(a, w, bias, mode=1, impl=impl), base / (1 + np.exp(-1.702 * base)), 4e-3)
+    acc = rnd(5, "acc", (M, N))
+    check("gemm residual", ops.gemm(a, w, bias, mode=2, impl=impl, acc=acc), acc + base, 3e-3)
+    check("gemm lrelu", ops.gemm(a, w, bias, mode=4, impl=impl), np.where(base > 0, base, 0.2 * base) * math.sqrt(2), 3e-3)
+
+
+def test_dense_modes():
+    P, K, N = 37, 200, 150
+    x = rnd(6, "x", (P, K)); wt = rnd(6, "wt", (K, N), K ** -0.5); bias = rnd(6, "b", (N,), 0.2)
+    v = x.astype(np.float64) @ wt + bias
+    check("dense", ops.dense(x, wt, bias), v, 1e-5)
+    check("dense lrelu", ops.dense(x, wt, bias, mode=1), np.where(v > 0, v, 0.2 * v) * math.sqrt(2), 1e-5)
+    eps = np.abs(rnd(6, "e", (P,))) + 0.1
+    wpos = np.abs(wt)
+    v2 = (x.astype(np.float64) ** 2) @ wpos
+    check("dense sq+rsqrt", ops.dense(x, wpos, None, in_sq=True, mode=2, eps_row=eps), 1 / np.sqrt(v2 + eps[:, None]), 1e-5)
+
+
+@pytest.mark.parametrize("H", [4, 16])
+def test_torgb_skip(H):
+    B, Cc, L = 3, 32, 24
+    x = rnd(7, "x", (B, Cc, H, H)); w = rnd(7, "w", (3, Cc, 1, 1)); lat = rnd(7, "lat", (B, L))
+    A = rnd(7, "A", (Cc, L)); Ab = rnd(7, "Ab", (Cc,), 0.2) + 1; bias = rnd(7, "b", (3,), 0.3)
+    yprev = rnd(7, "yp", (B, 3, H // 2, H // 2))
+    t = sg._mod_conv(torch.tensor(h16(x)), torch.tensor(lat), torch.tensor(w), torch.tensor(A), torch.tensor(Ab),
+                     demod=False, up=False)
+    ref = (sg._bias_act(t, torch.tensor(bias), act=False) + sg._upsample_skip(torch.tensor(yprev))).numpy()
+    sn, smax, _ = style_tables(lat, A, Ab, w, demod=False)
+    got = ops.torgb(nhwc(x), w.reshape(3, Cc) / math.sqrt(Cc), bias, sn, smax[:, 0], yprev)
+    check("torgb+skip H%d" % H, got, ref, 2e-3)
+    got0 = ops.torgb(nhwc(x), w.reshape(3, Cc) / math.sqrt(Cc), bias, sn, smax[:, 0], None)
+    check("torgb first H%d" % H, got0, sg._bias_act(t, torch.tensor(bias), act=False).numpy(), 2e-3)
+
+
+def test_fromrgb():
+    B, R, Cout = 2, 16, 32
+    y = rnd(8, "y", (B, 3, R, R), 0.8); w = rnd(8, "w", (Cout, 3, 1, 1)); bias = rnd(8, "b", (Cout,), 0.3)
+    img = ((torch.tensor(y) + 1) / 2).clip(0, 1) * 2 - 1
+    ref = sg._bias_act(sg._conv(img, torch.tensor(w)), torch.tensor(bias)).numpy()
+    got = ops.fromrgb(y, w.reshape(Cout, 3) / math.sqrt(3), bias)
+    check("fromrgb", nchw(got), ref, 2e-3)
+
+
+@pytest.mark.parametrize("batch_size", [4, 8])
+def test_mbstd(batch_size):
+    B, Cc = 8, 32
+    x = h16(rnd(9, "x", (B, Cc, 4, 4)))
+    ref = torch.cat([sg.minibatch_std(torch.tensor(x[i:i + batch_size])) for i in range(0, B, batch_size)]).numpy()
+    got = ops.mbstd(nhwc(x).reshape(B, 16, Cc), 48, batch_size)
+    got = got.reshape(B, 4, 4, 48)
+    check("mbstd bs%d features+std" % batch_size, nchw(got[..., :Cc + 1]), ref, 2e-3)
+    assert np.all(got[..., Cc + 1:] == 0)
+
+
+@pytest.mark.parametrize("R,S,ps", [(64, 32, 8), (32, 32, 8), (1024, 224, 32)])
+def test_resize_patches(R, S, ps):
+    B = 2
+    y = rnd(10, "y", (B, 3, R, R), 0.8)
+    img = ((torch.tensor(y) + 1) / 2).clip(0, 1)
+    ref = F.interpolate(img, size=(S, S), mode="bilinear", align_corners=False)
+    G = S // ps
+    ref = ref.view(B, 3, G, ps, G, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, 3 * ps * ps).numpy()
+    check("resize %d->%d" % (R, S), ops.resize(y, S, ps), ref, 1e-3)
+
+
+def test_layernorm_attention():
+    M, D = 23, 128
+    x = rnd(11, "x", (M, D), 2.0) + 0.5; g = rnd(11, "g", (D,), 0.1) + 1; b = rnd(11, "b", (D,), 0.1)
+    ref = F.layer_norm(torch.tensor(x), (D,), torch.tensor(g), torch.tensor(b), 1e-5).numpy()
+    check("layernorm", ops.layernorm(x, g, b), ref, 1e-5)
+    for L, causal in ((50, False), (17, False), (77, True)):
+        n_img, heads = 3, 2
+        qkv = h16(rnd(12, "qkv%d" % L, (n_img * L, 3 * heads * 64)))
+        t = torch.tensor(qkv).view(n_img, L, 3, heads, 64)
+        q, k, v = (t[:, :, i].transpose(1, 2) for i in range(3))
+        a = (q * 0.125) @ k.transpose(-1, -2)
+        if causal:
+            a = a + torch.full((L, L), float("-inf")).triu_(1)
+        o = (torch.softmax(a, -1) @ v).transpose(1, 2).reshape(n_img * L, heads * 64)
+        check("attention L%d causal%d" % (L, causal), ops.attention(qkv, n_img, L, heads, causal), o.numpy(), 2e-3)
+
+
+def test_noise_matches_numpy_mirror():
+    hw = 64 * 64
+    got = ops.noise(3, hw, layer=5, mb0=2, generation=7, seed=0x1234567890)
+    ref = np.stack([synth.noise_plane(0x1234567890, 7, 2 + m, 5, 64, 64).reshape(-1) for m in range(3)])
+    check("philox noise vs numpy", got, ref, 0, atol=2e-5)
+    assert abs(got.mean()) < 0.03 and abs(got.std() - 1) < 0.03
