@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py — candidates scored per second through the MI355X fitness engine.
+
+Workload (BASELINE.json configs[1]): StyleGAN2_ffhq_d — StyleGAN2 ffhq config-f 1024 px
+generator + discriminator + CLIP ViT-B/32, pop = 64 per GPU, batch_size = 4 (noise
+sharing / mbstd groups as in the reference config.py:80-95), n_obj = 2.  A "step" is
+one `_evaluate` of one population (problem.py:14-29).  Synthetic seeded weights of the
+true architecture (no checkpoints in this environment), fresh N(0,1) latents per step.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  Multi-GPU: the population shards across ranks (weak
+scaling, 64 candidates per GPU) and the only collective is one RCCL all-gather of the
+[P/N, n_obj] fitness rows per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "candidate latents scored/sec (GAN→CLIP fitness), StyleGAN2_ffhq_d pop=64"
+MFMA_PEAK_TFLOPS = 2500.0   # dense f16/bf16 MFMA peak, MI355X_MICROARCH.md
+POP, BATCH = 64, 4
+
+
+def cpu_baseline(sd, cfg, target):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload: one minibatch (P = 4) of StyleGAN2_ffhq_d."""
+    import torch
+    from clip_glass_amd import synth
+    from oracle import fitness_ref
+    tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
+    x = synth.latents(123, BATCH, cfg["latent"])
+    planes = synth.g_noise_planes(9, 0, 0, cfg["channels"])
+    best = None
+    for _ in range(2):
+        t = time.time()
+        fitness_ref.evaluate(tsd, x, target, BATCH, True, lambda i: planes, clip_size=cfg["clip"][4])
+        dt = time.time() - t
+        best = dt if best is None else min(best, dt)
+        if dt > 15:
+            break
+    return dict(value=BATCH / best, unit="candidates/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle/ (torch-CPU fp32 restatement) on P=4 (one minibatch) of the same workload, best of <=2 calls, %.2f s" % best)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="ffhq", help="model size key (tests/models.py naming); ffhq = the headline")
+    ap.add_argument("--pop", type=int, default=POP)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+
+    from clip_glass_amd import synth
+    from clip_glass_amd.engine import Engine, device_info
+    from clip_glass_amd.parallel import ShardedEvaluator
+
+    cfgs = {"ffhq": dict(channels=synth.FFHQ_CHANNELS, latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
+            "mid": dict(channels=[32, 64, 64, 64, 64], latent=64, mapping=3, clip=(128, 2, 2, 8, 32, 64))}
+    cfg = cfgs[args.config]
+    P = args.pop
+    sd = synth.make_state(synth.stylegan2_g_spec(cfg["channels"], cfg["latent"], cfg["mapping"]), 0)
+    sd.update(synth.make_state(synth.stylegan2_d_spec(cfg["channels"]), 0))
+    w, layers, heads, patch, res, emb = cfg["clip"]
+    sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), 0))
+
+    eng = Engine(cfg["channels"][::-1], latent_size=cfg["latent"], mapping_layers=cfg["mapping"], batch_size=BATCH,
+                 use_discriminator=True, n_obj=2, max_pop=P, chunk=args.chunk, clip=cfg["clip"], noise_mode=1,
+                 noise_seed=1234, device=local_rank)
+    eng.load_state(sd)
+    eng.finalize()
+    # synthetic target: a pass with a dummy target to get features, then sims in ~[0.5, 0.9]
+    eng.set_target(np.ones(emb, np.float32))
+    eng.evaluate(synth.latents(999, BATCH, cfg["latent"]))
+    target = synth.make_target(eng.details(BATCH)["features"])
+    eng.set_target(target)
+
+    ev = ShardedEvaluator(eng, dist, rank, world, BATCH)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        ev.evaluate_local(synth.latents(1000 * rank + s, P, cfg["latent"]), generation=s)
+    eng.set_profiling(True)
+    prof = {}
+    sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        F_all = ev.evaluate_local(synth.latents(1000 * rank + 100 + s, P, cfg["latent"]), generation=100 + s)
+        for r in eng.profile():
+            a = prof.setdefault(r["name"], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            for k in a:
+                a[k] += r[k]
+    sync()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert F_all.shape == (P * world, 2) and np.isfinite(F_all).all()
+
+    if rank == 0:
+        # dominant kernel = the kernel symbol with the largest share of device time
+        by_kernel = {}
+        for name, a in prof.items():
+            kern = name.split("@")[1] if "@" in name else name
+            b = by_kernel.setdefault(kern, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            for k in b:
+                b[k] += a[k]
+        kern, a = max(by_kernel.items(), key=lambda kv: kv[1]["total_ms"])
+        achieved = a["flops"] / (a["total_ms"] * 1e-3) / 1e12 if a["total_ms"] > 0 else 0.0
+        total_ms = sum(v["total_ms"] for v in by_kernel.values())
+        total_flops = sum(v["flops"] for v in prof.values())
+        roofline = dict(bound="mfma", kernel=kern, launches=a["launches"], avg_ms=a["total_ms"] / max(a["launches"], 1),
+                        achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_PEAK_TFLOPS,
+                        traffic=None, share_of_gpu_time=a["total_ms"] / total_ms if total_ms else None,
+                        whole_pass_tflops=total_flops / (total_ms * 1e-3) / 1e12 if total_ms else None)
+        out = dict(metric=METRIC, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
+                   config=dict(workload="StyleGAN2_ffhq_d: StyleGAN2 config-f %dpx G+D + CLIP ViT-B/32, pop=%d per GPU, "
+                                        "batch_size=%d, n_obj=2" % (4 << (len(cfg["channels"]) - 1), P, BATCH),
+                               pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,
+                               device=device_info(local_rank)["name"]),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, target)
+        if os.environ.get("GLASS_BENCH_DETAIL"):
+            with open(os.environ["GLASS_BENCH_DETAIL"], "w") as f:
+                json.dump(dict(per_tag=prof, per_kernel=by_kernel, seconds=dt), f, indent=1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

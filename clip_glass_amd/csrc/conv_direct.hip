@@ -101,19 +101,21 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
     }
 }
 
-void launch_conv_direct(const ConvParams& p, hipStream_t st) {
+const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
     const long long M = (long long)p.B * p.Hc * p.Wc;
     const unsigned gx = (unsigned)((M + 127) / 128);
     if (p.Neff > 64) {
         dim3 g(gx, (p.Neff + 127) / 128);
         hipLaunchKernelGGL(conv_direct_kernel<4>, g, dim3(256), 0, st, p);
+        return "conv_direct_kernel<4>";
     } else if (p.Neff > 32) {
         dim3 g(gx, 1);
         hipLaunchKernelGGL(conv_direct_kernel<2>, g, dim3(256), 0, st, p);
-    } else {
-        dim3 g(gx, 1);
-        hipLaunchKernelGGL(conv_direct_kernel<1>, g, dim3(256), 0, st, p);
+        return "conv_direct_kernel<2>";
     }
+    dim3 g(gx, 1);
+    hipLaunchKernelGGL(conv_direct_kernel<1>, g, dim3(256), 0, st, p);
+    return "conv_direct_kernel<1>";
 }
 
 // ---------------------------------------------------------------------------------
@@ -172,13 +174,15 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
     }
 }
 
-void launch_gemm_direct(const GemmParams& p, hipStream_t st) {
+const char* launch_gemm_direct(const GemmParams& p, hipStream_t st) {
     const unsigned gx = (unsigned)((p.M + 127) / 128);
     if (p.N > 64) {
         hipLaunchKernelGGL(gemm_direct_kernel<4>, dim3(gx, (p.N + 127) / 128), dim3(256), 0, st, p);
+        return "gemm_direct_kernel<4>";
     } else if (p.N > 32) {
         hipLaunchKernelGGL(gemm_direct_kernel<2>, dim3(gx, 1), dim3(256), 0, st, p);
-    } else {
-        hipLaunchKernelGGL(gemm_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
+        return "gemm_direct_kernel<2>";
     }
+    hipLaunchKernelGGL(gemm_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
+    return "gemm_direct_kernel<1>";
 }

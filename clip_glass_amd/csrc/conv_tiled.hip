@@ -2,5 +2,5 @@
 #include "common.h"
 #include "kernels.h"
 
-bool launch_conv_tiled(const ConvParams& p, hipStream_t st) { (void)p; (void)st; return false; }
-bool launch_gemm_tiled(const GemmParams& p, hipStream_t st) { (void)p; (void)st; return false; }
+const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) { (void)p; (void)st; return nullptr; }
+const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) { (void)p; (void)st; return nullptr; }

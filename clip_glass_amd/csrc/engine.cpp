@@ -634,11 +634,15 @@ static void collect_profile(glass_engine* e) {
 
 static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
     Prof pr(e, tag, flops, bytes);
-    if (!launch_conv_tiled(p, e->stream)) launch_conv_direct(p, e->stream);
+    const char* k = launch_conv_tiled(p, e->stream);
+    if (!k) k = launch_conv_direct(p, e->stream);
+    if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
 }
 static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
     Prof pr(e, tag, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
-    if (!launch_gemm_tiled(p, e->stream)) launch_gemm_direct(p, e->stream);
+    const char* k = launch_gemm_tiled(p, e->stream);
+    if (!k) k = launch_gemm_direct(p, e->stream);
+    if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
 }
 
 static ConvParams conv_defaults() {

@@ -2,11 +2,12 @@
 #pragma once
 #include "common.h"
 
-void launch_conv_direct(const ConvParams& p, hipStream_t st);
-void launch_gemm_direct(const GemmParams& p, hipStream_t st);
-// LDS-tiled fast paths; return false when the shape is not supported (caller falls back to direct).
-bool launch_conv_tiled(const ConvParams& p, hipStream_t st);
-bool launch_gemm_tiled(const GemmParams& p, hipStream_t st);
+// Each launcher returns the kernel symbol it launched (for the per-kernel profile).
+const char* launch_conv_direct(const ConvParams& p, hipStream_t st);
+const char* launch_gemm_direct(const GemmParams& p, hipStream_t st);
+// LDS-tiled fast paths; return nullptr when the shape is not supported (caller falls back to direct).
+const char* launch_conv_tiled(const ConvParams& p, hipStream_t st);
+const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
 
 // --- small fp32 ops (mapping network, style affines, demodulation, heads) ---------
 void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipStream_t st);

@@ -31,7 +31,7 @@ class GlassNoise(C.Structure):
 
 
 class ProfRow(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double),
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int64), ("total_ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 

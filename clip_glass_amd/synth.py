@@ -243,3 +243,12 @@ def latents(seed, pop, dim=512):
     """RandomState(seed).normal(size=(pop, dim)) float64 — matches NormalRandomSampling
     (operators.py:24-25) and SURVEY 8(d)."""
     return np.random.RandomState(seed).normal(size=(pop, dim))
+
+
+def make_target(feats, seed=0, spread=0.6):
+    """Synthetic target feature giving cosine sims well away from 0 (the 1e-3
+    *relative* bar is ill-conditioned near 0): unit(feats[0]) + spread * unit(random)."""
+    f0 = np.asarray(feats[0], dtype=np.float64)
+    r = normal(seed, "target", f0.shape).astype(np.float64)
+    t = f0 / np.linalg.norm(f0) + spread * r / np.linalg.norm(r)
+    return t.astype(np.float32)

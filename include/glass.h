@@ -108,7 +108,7 @@ int glass_engine_last_gpu_ms(glass_engine* e, float* ms);
  * After evaluate(): n rows of {name, launches, total_ms, flops, bytes} — algorithmic
  * flops/bytes per DESIGN.md.  Used by bench.py for the `roofline` object. */
 typedef struct glass_prof_row {
-    char name[48];
+    char name[96];             /* "<layer tag>@<kernel symbol>" */
     int64_t launches;
     double total_ms;
     double flops;

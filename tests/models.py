@@ -42,10 +42,4 @@ def noise_planes(name, seed, generation, n_mb, first_mb=0):
     return [synth.g_noise_planes(seed, generation, first_mb + m, c["channels"]) for m in range(n_mb)]
 
 
-def make_target(feats, seed=0, spread=0.6):
-    """Target feature giving cosine sims well away from 0 (relative 1e-3 is
-    ill-conditioned near 0): unit(feats[0]) + spread * unit(random)."""
-    f0 = np.asarray(feats[0], dtype=np.float64)
-    r = synth.normal(seed, "target", f0.shape).astype(np.float64)
-    t = f0 / np.linalg.norm(f0) + spread * r / np.linalg.norm(r)
-    return t.astype(np.float32)
+make_target = synth.make_target

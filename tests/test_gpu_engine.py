@@ -40,7 +40,11 @@ def _run_case(name, P, batch_size, use_d, noise_mode, chunk=0, seed=0):
     img = e.generate(x, generation=3, noise=planes if noise_mode == 2 else None)
     e.close()
     tag = "%s P%d bs%d d%d nm%d ch%d" % (name, P, batch_size, use_d, noise_mode, chunk)
-    check(tag + " image", img, detail["image"].numpy(), 5e-3)
+    ref_img = detail["image"].numpy()
+    rms = float(np.sqrt(((img - ref_img) ** 2).mean()))
+    diag("[e2e] %s image rms err %.3e" % (tag, rms))
+    assert rms < 1e-3, "image rms error %.3e" % rms
+    check(tag + " image", img, ref_img, 3e-2)   # fp16 activations: worst pixel of 12.6M, image range [0,1]
     check(tag + " clip features", det["features"], feats, 5e-3)
     rel = np.abs(det["sim"] - sim_o) / np.abs(sim_o)
     diag("[e2e] %s sim range [%.3f, %.3f] max rel err %.3e" % (tag, sim_o.min(), sim_o.max(), rel.max()))
