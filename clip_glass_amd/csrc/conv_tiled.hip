@@ -1,6 +1,268 @@
-// conv_tiled.hip — LDS-tiled MFMA implicit-GEMM convolution / GEMM (fast path).
+// conv_tiled.hip — LDS-tiled MFMA implicit-GEMM convolution for gfx950 (fast path).
+//
+// One workgroup (4 waves) computes a TH x 32 tile of the conv grid for NT output
+// channels.  K = KS*KS*Cin is walked in stages (32-channel chunk c, tap-row ty):
+//   * the input patch of the chunk ((TH-1)*S+KS) x (31*S+KS) pixels x 32 ch is staged
+//     ONCE per chunk in LDS (halo included -> every input element is fetched from
+//     HBM/L2 once per chunk, then re-used by all KS*KS taps out of LDS); the style
+//     modulation x*s[b,i] (activation-side, SURVEY 8a note 1) is applied in registers
+//     on the way in, so the main loop is a plain shared-weight GEMM;
+//   * the weight slice of the stage (KS taps x NT x 32 ch) is staged next to it;
+//   * global loads of stage s+1 are issued before the MFMA block of stage s and
+//     written to LDS after it (register-staged software pipeline, guide T14);
+//   * rows of both LDS images are 80 B (64 B of data + 16 B pad) so the ds_read_b128
+//     fragment reads (lane -> row, 16 B) are bank-conflict free.
+// MFMA operands are swapped (A = weights, B = pixels): D[n][pixel], so every lane ends
+// up with 4 consecutive output channels of ONE pixel per accumulator quad -> 8-byte
+// NHWC stores and per-lane (not per-register) pixel decoding in the epilogue.
+// Epilogue contract identical to conv_direct.hip (demod, noise, bias, lrelu, residual).
 #include "common.h"
 #include "kernels.h"
 
-const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) { (void)p; (void)st; return nullptr; }
+#define ROWB 80  // bytes per LDS row (32 halfs + 8 pad)
+
+template <int KS, int S, int TH, int NT>
+__global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
+    constexpr int RW = TH / 4;                 // tile rows per wave
+    constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
+    constexpr int PH = (TH - 1) * S + KS;      // patch rows
+    constexpr int PW = 31 * S + KS;            // patch cols
+    constexpr int NVA = PH * PW * 4;           // 16-byte vectors in the A patch
+    constexpr int NA = (NVA + 255) / 256;
+    constexpr int NVB = KS * NT * 4;           // 16-byte vectors in one weight stage
+    constexpr int NB = (NVB + 255) / 256;
+    constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + A_BYTES;
+
+    // ---- block -> (pixel tile, n tile); blocks sharing a pixel tile share an XCD (id % 8) ----
+    const int id = blockIdx.x;
+    const int lo = id & 7, rest = id >> 3;
+    const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
+    if (pt >= PT) return;
+    const int tpi = tiles_x * tiles_y;
+    const int b = pt / tpi;
+    const int trem = pt - b * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
+    const int n0 = nt * NT;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, kh = lane >> 5;
+    const int part = t & 3;
+
+    // ---- per-thread staging descriptors (independent of the channel chunk) -------------------
+    int a_goff[NA];   // element offset into the image (without chunk offset), -1 = zero fill
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int v = t + 256 * k;
+        const int pix = v >> 2;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int iy = ty0 * S - p.pad + pr, ix = tx0 * S - p.pad + pc;
+        const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
+    }
+    const half_t* xb = p.x + (long long)b * p.x_bstride;
+    const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
+
+    h8 ra[NA], rb[NB];
+    f4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = {1.f, 1.f, 1.f, 1.f};
+
+    auto load_a = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
+            if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
+        }
+        if (snb) {
+            s0 = *(const f4*)(snb + c0);
+            s1 = *(const f4*)(snb + c0 + 4);
+        }
+    };
+    auto load_b = [&](int c0, int ty) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int u = t + 256 * k;
+            if (NVB % 256 == 0 || u < NVB) {
+                const int tx = u / (NT * 4);
+                const int n = (u >> 2) % NT;
+                rb[k] = *(const h8*)(p.w + ((long long)(ty * KS + tx) * p.Neff + n0 + n) * p.Cin + c0 + part * 8);
+            }
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int v = t + 256 * k;
+            if (NVA % 256 == 0 || v < NVA) {
+                h8 a = ra[k];
+                if (snb) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        a[j] = (half_t)((float)a[j] * s0[j]);
+                        a[j + 4] = (half_t)((float)a[j + 4] * s1[j]);
+                    }
+                }
+                *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
+            }
+        }
+    };
+    auto store_b = [&]() {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int u = t + 256 * k;
+            if (NVB % 256 == 0 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
+        }
+    };
+
+    f16x acc[RW][NJ];
+#pragma unroll
+    for (int i = 0; i < RW; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int n_chunks = p.Cin >> 5;
+    const int n_stages = n_chunks * KS;
+    load_a(0);
+    load_b(0, 0);
+    int c = 0, ty = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        if (s > 0) __syncthreads();  // previous stage's fragment reads are done
+        if (ty == 0) store_a();
+        store_b();
+        __syncthreads();
+        int nc = c, nty = ty + 1;
+        if (nty == KS) { nty = 0; nc = c + 1; }
+        if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
+            if (nty == 0) load_a(nc * 32);
+            load_b(nc * 32, nty);
+        }
+        // ---- MFMA block: KS taps x 2 k16 steps x RW x NJ --------------------------------
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h8 wf[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    wf[j] = *(const h8*)(Bs + (tx * NT + j * 32 + lr) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const int prow = (wave * RW + i) * S + ty;
+                    const h8 xf = *(const h8*)(As + (prow * PW + lr * S + tx) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                }
+            }
+        }
+        c = nc;
+        ty = nty;
+    }
+
+    // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ----
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        const int oy = ty0 + wave * RW + i, ox = tx0 + lr;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + j * 32 + 8 * g + 4 * kh;  // first of 4 consecutive n
+                int o = nb, py = oy, px = ox;
+                if (p.up) {
+                    const int ph = nb / p.Cout;
+                    o = nb - ph * p.Cout;
+                    py = 2 * oy + (ph >> 1);
+                    px = 2 * ox + (ph & 1);
+                }
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                if (p.dscale) {
+                    const f4 d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= d[q];
+                }
+                if (p.noise) {
+                    const float nz = p.noise_strength *
+                                     p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += nz;
+                }
+                if (p.bias) {
+                    const f4 bb = *(const f4*)(p.bias + o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += bb[q];
+                }
+                if (p.act) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                }
+                const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
+                if (p.res) {
+                    const h4 r = *(const h4*)(p.res + oidx);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
+                }
+                h4 out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                *(h4*)(p.y + oidx) = out;
+            }
+        }
+    }
+}
+
+template <int KS, int S, int TH, int NT>
+static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
+    constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
+    constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
+    constexpr int LDS = A_BYTES + KS * NT * ROWB;
+    static bool attr = false;
+    if (!attr) {
+        if (LDS > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
+    const int PT = p.B * tiles_x * tiles_y;
+    const int NTn = p.Neff / NT;
+    const int PT8 = (PT + 7) / 8 * 8;
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT>), dim3(PT8 * NTn), dim3(256), LDS, st, p, NTn, tiles_x,
+                       tiles_y, PT);
+    return name;
+}
+
+const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
+    if (p.y32 || !p.y) return nullptr;
+    if (p.x_bstride == 0 && p.B > 1) return nullptr;  // broadcast input (4x4 const): direct path
+    if (p.Cin % 32 != 0 || p.Wc % 32 != 0 || p.Cout % 4 != 0) return nullptr;
+    if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
+    const int KS = p.KS, S = p.stride;
+    if (KS == 3 && S == 1 && p.pad == 1) {
+        if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
+        if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64>(p, st, "conv_tiled_kernel<3,1,8,64>");
+        if (p.Neff % 32 == 0 && p.Hc % 16 == 0) return launch_inst<3, 1, 16, 32>(p, st, "conv_tiled_kernel<3,1,16,32>");
+        if (p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32>(p, st, "conv_tiled_kernel<3,1,8,32>");
+        return nullptr;
+    }
+    if (KS == 3 && S == 2 && p.pad == 0) {
+        if (p.Neff % 128 == 0 && p.Hc % 4 == 0) return launch_inst<3, 2, 4, 128>(p, st, "conv_tiled_kernel<3,2,4,128>");
+        if (p.Neff % 64 == 0 && p.Hc % 4 == 0) return launch_inst<3, 2, 4, 64>(p, st, "conv_tiled_kernel<3,2,4,64>");
+        if (p.Neff % 32 == 0 && p.Hc % 4 == 0) return launch_inst<3, 2, 4, 32>(p, st, "conv_tiled_kernel<3,2,4,32>");
+        return nullptr;
+    }
+    if (KS == 1 && S == 1 && p.pad == 0) {
+        if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<1, 1, 8, 128>(p, st, "conv_tiled_kernel<1,1,8,128>");
+        if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<1, 1, 8, 64>(p, st, "conv_tiled_kernel<1,1,8,64>");
+        return nullptr;
+    }
+    return nullptr;
+}
+
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) { (void)p; (void)st; return nullptr; }

@@ -42,8 +42,14 @@ def test_mfma_fragment_layout():
     check("mfma32x32x16 layout", d, h16(a).astype(np.float64) @ h16(b).astype(np.float64), 1e-3)
 
 
-@pytest.mark.parametrize("impl", [1])
-@pytest.mark.parametrize("B,H,Cin,Cout", [(3, 12, 32, 48), (2, 5, 16, 16), (1, 33, 64, 160)])
+@pytest.mark.parametrize("impl,B,H,Cin,Cout", [
+    (1, 3, 12, 32, 48), (1, 2, 5, 16, 16), (1, 1, 33, 64, 160),
+    (2, 2, 32, 64, 128),    # conv_tiled<3,1,8,128>
+    (2, 1, 64, 32, 256),    # conv_tiled<3,1,8,128>, 2 n-tiles, 16 pixel tiles
+    (2, 2, 32, 64, 64),     # conv_tiled<3,1,8,64>
+    (2, 3, 32, 32, 32),     # conv_tiled<3,1,16,32>
+    (2, 1, 64, 96, 96),     # conv_tiled<3,1,16,32>, 3 n-tiles, 3 chunks
+])
 def test_conv_plain_bias_act(impl, B, H, Cin, Cout):
     x = rnd(2, "x", (B, Cin, H, H)); w = rnd(2, "w", (Cout, Cin, 3, 3)); bias = rnd(2, "b", (Cout,), 0.3)
     ref = sg._bias_act(sg._conv(torch.tensor(h16(x)), torch.tensor(w), padding=1), torch.tensor(bias)).numpy()
@@ -52,6 +58,8 @@ def test_conv_plain_bias_act(impl, B, H, Cin, Cout):
 
 
 def _modconv_case(up, impl, B=4, H=8, Cin=32, Cout=48, L=24, batch_size=2, broadcast=False):
+    if impl == 2:
+        H, Cout = 32, (32 if up else 64)
     x = rnd(3, "x", (1 if broadcast else B, Cin, H, H)); w = rnd(3, "w", (Cout, Cin, 3, 3))
     lat = rnd(3, "lat", (B, L)); A = rnd(3, "A", (Cin, L)); Ab = rnd(3, "Ab", (Cin,), 0.2) + 1
     bias = rnd(3, "b", (Cout,), 0.3); strength = 0.37
@@ -67,13 +75,13 @@ def _modconv_case(up, impl, B=4, H=8, Cin=32, Cout=48, L=24, batch_size=2, broad
     return got, ref
 
 
-@pytest.mark.parametrize("impl", [1])
+@pytest.mark.parametrize("impl", [1, 2])
 def test_conv_modulated_demod_noise(impl):
     got, ref = _modconv_case(False, impl)
     check("modconv impl%d" % impl, nchw(got), ref, 5e-3)
 
 
-@pytest.mark.parametrize("impl", [1])
+@pytest.mark.parametrize("impl", [1, 2])
 def test_conv_modulated_up(impl):
     got, ref = _modconv_case(True, impl)
     check("modconv-up impl%d" % impl, nchw(got), ref, 5e-3)
@@ -84,10 +92,10 @@ def test_conv_broadcast_const():
     check("modconv const-input", nchw(got), ref, 5e-3)
 
 
-@pytest.mark.parametrize("impl", [1])
-def test_d_block_pieces(impl):
+@pytest.mark.parametrize("impl,H,Cin,Cout", [(1, 16, 32, 48), (2, 64, 32, 64), (2, 64, 32, 128), (2, 64, 64, 64)])
+def test_d_block_pieces(impl, H, Cin, Cout):
     """DiscriminatorConvBlock (modules.py:1587-1601): conv0, FIR+stride-2 conv1, FIR+1x1 skip, (h+s)/sqrt2."""
-    B, H, Cin, Cout = 2, 16, 32, 48
+    B = 2
     x = rnd(4, "x", (B, Cin, H, H)); w0 = rnd(4, "w0", (Cin, Cin, 3, 3)); b0 = rnd(4, "b0", (Cin,), 0.3)
     w1 = rnd(4, "w1", (Cout, Cin, 3, 3)); b1 = rnd(4, "b1", (Cout,), 0.3); ws = rnd(4, "ws", (Cout, Cin, 1, 1))
     xt = torch.tensor(h16(x))
