@@ -11,12 +11,16 @@
 #include "common.h"
 #include "kernels.h"
 
+// Block = one 32 x (32*NW) output tile; the K loop (taps x 16-channel steps) is split
+// round-robin over the 4 waves (split-K, summed through LDS) and software-pipelined one
+// step ahead, so the small-M layers are no longer a single wave chasing load latency.
 template <int NW>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
+    __shared__ float red[3][NW][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const long long M = (long long)p.B * p.Hc * p.Wc;
-    const long long mw = (long long)blockIdx.x * 128 + wave * 32;  // first GEMM row of this wave
+    const long long mw = (long long)blockIdx.x * 32;  // first GEMM row of this block
     const int n0 = blockIdx.y * (32 * NW);
     const long long m = mw + r;
     const bool mvalid = m < M;
@@ -34,40 +38,72 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-    const half_t* xb = p.x + (long long)b * p.x_bstride;
+    const half_t* xb = p.x + (long long)b * p.x_bstride + kh * 8;
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + kh * 8 : nullptr;
-    for (int ty = 0; ty < p.KS; ++ty) {
-        for (int tx = 0; tx < p.KS; ++tx) {
-            const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
-            const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const half_t* xp = xb + ((long long)iy * p.W + ix) * p.Cin + kh * 8;
-            const half_t* wp = p.w + ((long long)(ty * p.KS + tx) * p.Neff + n0 + r) * p.Cin + kh * 8;
-            for (int i0 = 0; i0 < p.Cin; i0 += 16) {
-                h8 a;
+    const int cps = p.Cin >> 4;                 // 16-channel steps per tap
+    const int total = p.KS * p.KS * cps;
+    bool nvalid[NW];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = (half_t)0.f;
-                if (v) {
-                    a = *(const h8*)(xp + i0);
-                    if (snb) {
-                        const f4 s0 = *(const f4*)(snb + i0), s1 = *(const f4*)(snb + i0 + 4);
+    for (int nw = 0; nw < NW; ++nw) nvalid[nw] = n0 + nw * 32 + r < p.Neff;
+
+    struct Frag { h8 a; h8 bf[NW]; f4 s0, s1; };
+    auto load = [&](int s, Frag& f) {
+        const int tap = s / cps, i0 = (s - tap * cps) << 4;
+        const int ty = tap / p.KS, tx = tap - ty * p.KS;
+        const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
+        const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            a[j] = (half_t)((float)a[j] * s0[j]);
-                            a[j + 4] = (half_t)((float)a[j + 4] * s1[j]);
-                        }
-                    }
-                }
+        for (int j = 0; j < 8; ++j) f.a[j] = (half_t)0.f;
+        if (v) f.a = *(const h8*)(xb + ((long long)iy * p.W + ix) * p.Cin + i0);
+        if (snb) {
+            f.s0 = *(const f4*)(snb + i0);
+            f.s1 = *(const f4*)(snb + i0 + 4);
+        }
+        const half_t* wp = p.w + ((long long)tap * p.Neff + n0 + r) * p.Cin + kh * 8 + i0;
 #pragma unroll
-                for (int nw = 0; nw < NW; ++nw) {
-                    h8 bf;
+        for (int nw = 0; nw < NW; ++nw) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) bf[j] = (half_t)0.f;
-                    if (n0 + nw * 32 + r < p.Neff) bf = *(const h8*)(wp + (long long)nw * 32 * p.Cin + i0);
-                    acc[nw] = mfma32(a, bf, acc[nw]);
-                }
+            for (int j = 0; j < 8; ++j) f.bf[nw][j] = (half_t)0.f;
+            if (nvalid[nw]) f.bf[nw] = *(const h8*)(wp + (long long)nw * 32 * p.Cin);
+        }
+    };
+    auto compute = [&](Frag& f) {
+        h8 a = f.a;
+        if (snb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (half_t)((float)a[j] * f.s0[j]);
+                a[j + 4] = (half_t)((float)a[j + 4] * f.s1[j]);
             }
         }
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw) acc[nw] = mfma32(a, f.bf[nw], acc[nw]);
+    };
+    Frag f0, f1;
+    int s = wave;
+    if (s < total) load(s, f0);
+    for (; s < total; s += 8) {          // two steps per iteration: static register double buffer
+        if (s + 4 < total) load(s + 4, f1);
+        compute(f0);
+        if (s + 4 < total) {
+            if (s + 8 < total) load(s + 8, f0);
+            compute(f1);
+        }
     }
+    // ---- split-K reduction: waves 1..3 -> LDS -> wave 0 --------------------------------------
+    if (wave > 0) {
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[wave - 1][nw][reg][lane] = acc[nw][reg];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int nw = 0; nw < NW; ++nw)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            acc[nw][reg] += red[0][nw][reg][lane] + red[1][nw][reg][lane] + red[2][nw][reg][lane];
 
     // ---- epilogue: demod, noise, bias, activation, residual, store -------------
     const int col = lane & 31;
@@ -103,18 +139,17 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
     const long long M = (long long)p.B * p.Hc * p.Wc;
-    const unsigned gx = (unsigned)((M + 127) / 128);
-    if (p.Neff > 64) {
-        dim3 g(gx, (p.Neff + 127) / 128);
-        hipLaunchKernelGGL(conv_direct_kernel<4>, g, dim3(256), 0, st, p);
+    const unsigned gx = (unsigned)((M + 31) / 32);
+    // wide n tiles re-use the activation fragment; narrow ones give small problems more blocks
+    if (p.Neff > 64 && (long long)gx * ((p.Neff + 127) / 128) >= 512) {
+        hipLaunchKernelGGL(conv_direct_kernel<4>, dim3(gx, (p.Neff + 127) / 128), dim3(256), 0, st, p);
         return "conv_direct_kernel<4>";
-    } else if (p.Neff > 32) {
-        dim3 g(gx, 1);
-        hipLaunchKernelGGL(conv_direct_kernel<2>, g, dim3(256), 0, st, p);
+    }
+    if (p.Neff > 32) {
+        hipLaunchKernelGGL(conv_direct_kernel<2>, dim3(gx, (p.Neff + 63) / 64), dim3(256), 0, st, p);
         return "conv_direct_kernel<2>";
     }
-    dim3 g(gx, 1);
-    hipLaunchKernelGGL(conv_direct_kernel<1>, g, dim3(256), 0, st, p);
+    hipLaunchKernelGGL(conv_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
     return "conv_direct_kernel<1>";
 }
 

@@ -264,5 +264,3 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
     }
     return nullptr;
 }
-
-const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) { (void)p; (void)st; return nullptr; }

@@ -527,6 +527,22 @@ static int alloc_buffers(glass_engine* e) {
         if ((rc = dev_alloc(e, &e->act[i], e->act_elems))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(e, &e->ybuf[i], (size_t)CH * 3 * e->R * e->R))) return rc;
+    // whole-population buffers for the low-resolution phases (res <= low_res)
+    {
+        e->n_low = 0;
+        while (e->n_low < c.n_blocks && (4 << e->n_low) <= e->low_res) ++e->n_low;
+        if (e->n_low < 1) e->n_low = 1;
+        const size_t rl = 4u << (e->n_low - 1);
+        size_t cmax = 16;
+        for (int b = 0; b < e->n_low; ++b) cmax = std::max<size_t>(cmax, c.channels[b]);
+        if (e->n_low < c.n_blocks) cmax = std::max<size_t>(cmax, c.channels[e->n_low]);
+        const size_t low_elems = (size_t)P * (rl + 1) * (rl + 1) * (cmax + 16);
+        const int n_lowbuf = c.use_discriminator ? 6 : 2;
+        for (int i = 0; i < n_lowbuf; ++i)
+            if ((rc = dev_alloc(e, &e->low[i], low_elems))) return rc;
+        for (int i = 0; i < 2; ++i)
+            if ((rc = dev_alloc(e, &e->ylow[i], (size_t)P * 3 * rl * rl))) return rc;
+    }
     if ((rc = dev_alloc(e, &e->d_img, (size_t)CH * 3 * e->R * e->R))) return rc;
     const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1;
     if ((rc = dev_alloc(e, &e->d_patches, (size_t)P * G * G * 3 * ps * ps))) return rc;
@@ -543,8 +559,8 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_F, (size_t)P * 2))) return rc;
     if ((rc = dev_alloc(e, &e->d_target, (size_t)c.clip_embed))) return rc;
     if (c.use_discriminator) {
-        if ((rc = dev_alloc(e, &e->d_dfin, (size_t)CH * 16 * c.channels[0]))) return rc;
-        if ((rc = dev_alloc(e, &e->d_dh, (size_t)CH * c.channels[0]))) return rc;
+        if ((rc = dev_alloc(e, &e->d_dfin, (size_t)P * 16 * c.channels[0]))) return rc;
+        if ((rc = dev_alloc(e, &e->d_dh, (size_t)P * c.channels[0]))) return rc;
     }
     GLASS_HIP(hipMemset(e->d_dis, 0, (size_t)P * sizeof(float)));
     e->h_pinned_bytes = std::max((size_t)P * L, (size_t)P * (c.clip_embed + 8)) * sizeof(float);
@@ -713,14 +729,22 @@ static void run_styles(glass_engine* e, int P) {
     }
 }
 
-// synthesis for candidates [c0, c0+B): returns index of the ybuf holding the final image
-static int run_synthesis(glass_engine* e, int c0, int B) {
+// ------------------------------------------------------------------------------------
+// Synthesis blocks [b_lo, b_hi) for candidates [c0, c0+B).  Low-resolution blocks
+// (res <= low_res) run once for the whole population (launch-/latency-bound otherwise),
+// high-resolution blocks run per chunk so the working set stays near the caches.
+//   x/xbs: input feature map (bstride 0 = the learned const); pp[2]: ping-pong outputs;
+//   yprev: skip image of the previous block (nullptr for block 0); yb[2]: skip ping-pong.
+// Returns the final feature map / skip image through the out parameters.
+// ------------------------------------------------------------------------------------
+static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, const half_t* x, long long xbs,
+                         half_t* const pp[2], const float* yprev, float* const yb[2], const half_t** x_out,
+                         const float** y_out) {
     const glass_config& c = e->cfg;
-    int cur = 0, gi = 0, ycur = 0;
-    const half_t* x = e->g_const;
-    long long xbs = 0;
     char tag[48];
-    for (int b = 0; b < c.n_blocks; ++b) {
+    int gi = b_lo == 0 ? 0 : 1 + 2 * (b_lo - 1);
+    int yi = 0;
+    for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
         for (int l = 0; l < nl; ++l, ++gi) {
             const GConv& g = e->gconv[gi];
@@ -749,7 +773,7 @@ static int run_synthesis(glass_engine* e, int c0, int B) {
             p.batch_size = c.batch_size;
             p.bias = g.bias;
             p.act = 1;
-            half_t* out = e->act[(x == e->act[0]) ? 1 : 0];
+            half_t* out = pp[(x == pp[0]) ? 1 : 0];
             p.y = out;
             const double flops = 2.0 * B * (double)g.res_in * g.res_in * 9.0 * g.cin * g.cout;  // reference count
             const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
@@ -758,7 +782,6 @@ static int run_synthesis(glass_engine* e, int c0, int B) {
             run_conv(e, p, tag, flops, bytes);
             x = out;
             xbs = (long long)g.res_out * g.res_out * g.cout;
-            (void)cur;
         }
         const GRgb& r = e->grgb[b];
         {
@@ -766,25 +789,23 @@ static int run_synthesis(glass_engine* e, int c0, int B) {
             Prof pr(e, tag, 2.0 * B * (double)r.res * r.res * 3 * r.cin,
                     B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));
             launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
-                         e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style,
-                         b ? e->ybuf[ycur ^ 1] : nullptr, e->ybuf[ycur], e->stream);
+                         e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style, yprev, yb[yi],
+                         e->stream);
         }
-        ycur ^= 1;
+        yprev = yb[yi];
+        yi ^= 1;
     }
-    return ycur ^ 1;
+    *x_out = x;
+    *y_out = yprev;
 }
 
-static void run_discriminator(glass_engine* e, int c0, int B, const float* y) {
-    const glass_config& c = e->cfg;
-    const int n = c.n_blocks;
+// Discriminator conv blocks [i_lo, i_hi) (D order: block i works at resolution R >> i).
+// bufs: six scratch feature maps; X enters in `X`; the result pointer is returned.
+static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* X, half_t* const bufs[5]) {
     char tag[48];
-    half_t *X = e->act[0], *Hb = e->act[1], *HB = e->act[2], *XS = e->act[3], *S = e->act[4], *O = e->act[5];
-    {
-        Prof pr(e, "D.fromrgb", 2.0 * B * (double)e->R * e->R * 3 * c.channels[n - 1],
-                B * (double)e->R * e->R * (12.0 + 2.0 * c.channels[n - 1]));
-        launch_fromrgb(y, B, e->R, c.channels[n - 1], e->d_frgb_w, e->d_frgb_b, X, e->stream);
-    }
-    for (auto& d : e->dblk) {
+    half_t *Hb = bufs[0], *HB = bufs[1], *XS = bufs[2], *S = bufs[3], *O = bufs[4];
+    for (int i = i_lo; i < i_hi; ++i) {
+        const DBlock& d = e->dblk[i];
         const int r = d.res, r2 = r / 2;
         ConvParams p = conv_defaults();
         p.x = X; p.x_bstride = (long long)r * r * d.cin; p.B = B; p.H = p.W = r; p.Cin = d.cin;
@@ -816,24 +837,38 @@ static void run_discriminator(glass_engine* e, int c0, int B, const float* y) {
                  2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + 2.0 * r2 * r2 * d.cout));
         std::swap(X, O);
     }
+    return X;
+}
+
+static void run_fromrgb(glass_engine* e, int B, const float* y, half_t* X) {
+    const glass_config& c = e->cfg;
+    const int n = c.n_blocks;
+    Prof pr(e, "D.fromrgb", 2.0 * B * (double)e->R * e->R * 3 * c.channels[n - 1],
+            B * (double)e->R * e->R * (12.0 + 2.0 * c.channels[n - 1]));
+    launch_fromrgb(y, B, e->R, c.channels[n - 1], e->d_frgb_w, e->d_frgb_b, X, e->stream);
+}
+
+// mbstd + final conv + dense head for the whole population: X is [P][4][4][C0]
+static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch) {
+    const glass_config& c = e->cfg;
     const int CL = c.channels[0];
     {
-        Prof pr(e, "D.mbstd", 0, 4.0 * B * 16 * CL);
-        launch_mbstd(X, B, 16, CL, e->d_final_cpad, c.batch_size, c.mbstd_group, 1e-8f, Hb, e->stream);
+        Prof pr(e, "D.mbstd", 0, 4.0 * P * 16 * CL);
+        launch_mbstd(X, P, 16, CL, e->d_final_cpad, c.batch_size, c.mbstd_group, 1e-8f, scratch, e->stream);
     }
     ConvParams p = conv_defaults();
-    p.x = Hb; p.x_bstride = 16LL * e->d_final_cpad; p.B = B; p.H = p.W = 4; p.Cin = e->d_final_cpad; p.Hc = p.Wc = 4;
+    p.x = scratch; p.x_bstride = 16LL * e->d_final_cpad; p.B = P; p.H = p.W = 4; p.Cin = e->d_final_cpad; p.Hc = p.Wc = 4;
     p.KS = 3; p.pad = 1; p.w = e->d_final_w; p.Cout = p.Neff = CL; p.Ho = p.Wo = 4; p.bias = e->d_final_b; p.act = 1;
     p.y = e->d_dfin;
-    run_conv(e, p, "D.final_conv", 2.0 * B * 16 * 9.0 * (CL + 1) * CL, 2.0 * 9 * CL * (CL + 1));
+    run_conv(e, p, "D.final_conv", 2.0 * P * 16 * 9.0 * (CL + 1) * CL, 2.0 * 9 * CL * (CL + 1));
     GemmParams g;
     memset(&g, 0, sizeof g);
-    g.a = e->d_dfin; g.w = e->d_dense0_w; g.M = B; g.N = CL; g.K = 16 * CL; g.bias = e->d_dense0_b; g.mode = 4;
+    g.a = e->d_dfin; g.w = e->d_dense0_w; g.M = P; g.N = CL; g.K = 16 * CL; g.bias = e->d_dense0_b; g.mode = 4;
     g.out32 = e->d_dh; g.ldo = CL;
     run_gemm(e, g, "D.dense0");
     {
-        Prof pr(e, "D.dense1", 2.0 * B * CL, 0);
-        launch_dense(e->d_dh, CL, B, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis + c0, 1, 0, 0, nullptr, 0, e->stream);
+        Prof pr(e, "D.dense1", 2.0 * P * CL, 0);
+        launch_dense(e->d_dh, CL, P, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis, 1, 0, 0, nullptr, 0, e->stream);
     }
 }
 
@@ -902,10 +937,35 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     if (rc) return rc;
     const int ps = c.clip_patch, G = c.clip_res / ps;
     const size_t img_elems = (size_t)3 * e->R * e->R;
+    const bool want_d = out_F && c.use_discriminator && c.n_obj == 2;
+    const int n = c.n_blocks;
+    const int nlow = std::min(n, e->n_low);           // G blocks 0..nlow-1 run for the whole population
+    const int nd = (int)e->dblk.size();               // D conv blocks (n - 1)
+    const int d_hi = want_d ? std::max(0, n - nlow) : 0;  // D blocks 0..d_hi-1 (res > low_res) run per chunk
+    // ---- phase A: low-resolution synthesis, whole population ------------------------------
+    const half_t* xlow = nullptr;
+    const float* ylow = nullptr;
+    {
+        half_t* const pp[2] = {e->low[0], e->low[1]};
+        float* const yb[2] = {e->ylow[0], e->ylow[1]};
+        run_g_blocks(e, 0, P, 0, nlow, e->g_const, 0, pp, nullptr, yb, &xlow, &ylow);
+    }
+    const int res_low = 4 << (nlow - 1);
+    const long long xlow_bs = (long long)res_low * res_low * c.channels[nlow - 1];
+    // D feature map handed from the chunked phase to the whole-population phase
+    half_t* dmid = e->low[5];
+    const int res_mid = d_hi < nd ? e->dblk[d_hi].res : 4;
+    const long long dmid_bs = (long long)res_mid * res_mid * (d_hi < nd ? e->dblk[d_hi].cin : c.channels[0]);
+    // ---- phase B: high-resolution synthesis (+ high-resolution D) per chunk -----------------
     for (int c0 = 0; c0 < P; c0 += e->chunk) {
         const int B = std::min(e->chunk, P - c0);
-        const int yi = run_synthesis(e, c0, B);
-        const float* y = e->ybuf[yi];
+        const float* y = ylow + (size_t)c0 * 3 * res_low * res_low;
+        if (nlow < n) {
+            half_t* const pp[2] = {e->act[0], e->act[1]};
+            float* const yb[2] = {e->ybuf[0], e->ybuf[1]};
+            const half_t* xo;
+            run_g_blocks(e, c0, B, nlow, n, xlow + (size_t)c0 * xlow_bs, xlow_bs, pp, y, yb, &xo, &y);
+        }
         if (images) {
             launch_finalize_image(y, e->d_img, (long long)B * img_elems, e->stream);
             GLASS_HIP(hipMemcpyAsync(images + (size_t)c0 * img_elems, e->d_img, (size_t)B * img_elems * sizeof(float),
@@ -917,8 +977,24 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
                 launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
                                       e->stream);
             }
-            if (c.use_discriminator && c.n_obj == 2) run_discriminator(e, c0, B, y);
+            if (want_d) {
+                if (d_hi > 0) {
+                    run_fromrgb(e, B, y, e->act[0]);
+                    half_t* const bufs[5] = {e->act[1], e->act[2], e->act[3], e->act[4], e->act[5]};
+                    half_t* Xo = run_d_blocks(e, B, 0, d_hi, e->act[0], bufs);
+                    GLASS_HIP(hipMemcpyAsync(dmid + (size_t)c0 * dmid_bs, Xo, (size_t)B * dmid_bs * sizeof(half_t),
+                                             hipMemcpyDeviceToDevice, e->stream));
+                } else {
+                    run_fromrgb(e, B, y, dmid + (size_t)c0 * dmid_bs);
+                }
+            }
         }
+    }
+    // ---- phase C: low-resolution discriminator + head, whole population ----------------------
+    if (want_d) {
+        half_t* const bufs[5] = {e->low[0], e->low[1], e->low[2], e->low[3], e->low[4]};
+        half_t* Xo = run_d_blocks(e, P, d_hi, nd, dmid, bufs);
+        run_d_head(e, P, Xo, Xo == e->low[0] ? e->low[1] : e->low[0]);
     }
     if (out_F) {
         run_clip(e, P);

@@ -97,7 +97,10 @@ struct glass_engine {
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;
     std::vector<float*> d_noise;  // per noise layer: [n_mb_max][res*res]
-    half_t* act[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    half_t* act[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per-chunk, high resolution
+    half_t* low[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // whole population, res <= low_res
+    float* ylow[2] = {nullptr, nullptr};
+    int low_res = 32, n_low = 0;
     size_t act_elems = 0;
     float* ybuf[2] = {nullptr, nullptr};
     float* d_img = nullptr;

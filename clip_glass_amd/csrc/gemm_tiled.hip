@@ -1,0 +1,131 @@
+// gemm_tiled.hip — LDS-tiled MFMA GEMM  out[M][N] = A[M][K] * W[N][K]^T (+bias, epilogue)
+// for the CLIP ViT linears / patch embedding (clip/model.py:166-235) and the D dense head.
+// 128 x BN block tile, 4 waves as 2(M) x 2(N), 64-deep K stages staged through LDS with a
+// register-prefetch pipeline; rows are 144 B (128 B data + 16 B pad) -> conflict-free
+// ds_read_b128 fragment reads.  Operands swapped (A-role = W rows) so each lane owns 4
+// consecutive output columns of one output row per accumulator quad (16/8-byte stores).
+#include "common.h"
+#include "kernels.h"
+
+#define GROWB 144
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
+    constexpr int NJ = BN / 64;                  // 32-wide n tiles per wave
+    constexpr int NVA = 128 * 8, NVB = BN * 8;   // 16-byte vectors per stage
+    constexpr int NA = NVA / 256, NB = NVB / 256;
+    __shared__ __attribute__((aligned(16))) char smem[(128 + BN) * GROWB];
+    char* As = smem;
+    char* Bs = smem + 128 * GROWB;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, kh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    const int part = t & 7;                      // which 16-byte piece of the 128-byte row chunk
+
+    h8 ra[NA], rb[NB];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int row = (t >> 3) + 32 * k;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
+            if (m0 + row < p.M) ra[k] = *(const h8*)(p.a + (long long)(m0 + row) * p.K + k0 + part * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int row = (t >> 3) + 32 * k;
+            rb[k] = *(const h8*)(p.w + (long long)(n0 + row) * p.K + k0 + part * 8);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) *(h8*)(As + ((t >> 3) + 32 * k) * GROWB + part * 16) = ra[k];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) *(h8*)(Bs + ((t >> 3) + 32 * k) * GROWB + part * 16) = rb[k];
+    };
+
+    f16x acc[2][NJ];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    load(0);
+    for (int k0 = 0; k0 < p.K; k0 += 64) {
+        if (k0 > 0) __syncthreads();
+        store();
+        __syncthreads();
+        if (k0 + 64 < p.K) load(k0 + 64);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            h8 wf[NJ], xf[2];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                wf[j] = *(const h8*)(Bs + (wn * (BN / 2) + j * 32 + lr) * GROWB + kk * 32 + kh * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                xf[i] = *(const h8*)(As + (wm * 64 + i * 32 + lr) * GROWB + kk * 32 + kh * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
+        }
+    }
+    // epilogue: lane = output row m, quads of 4 consecutive n
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + lr;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * kh;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                if (p.bias) {
+                    const f4 bb = *(const f4*)(p.bias + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += bb[q];
+                }
+                const long long oi = (long long)m * p.ldo + n;
+                if (p.mode <= 1) {
+                    h4 o;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = (half_t)(p.mode == 1 ? v[q] / (1.f + __expf(-1.702f * v[q])) : v[q]);
+                    *(h4*)(p.out16 + oi) = o;
+                } else {
+                    f4 o;
+                    if (p.mode == 2) {
+                        o = *(const f4*)(p.out32 + oi);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] += v[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = p.mode == 4 ? lrelu_sqrt2(v[q]) : v[q];
+                    }
+                    *(f4*)(p.out32 + oi) = o;
+                }
+            }
+        }
+    }
+}
+
+const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
+    if (p.K % 64 != 0 || p.ldo % 4 != 0 || p.M < 64) return nullptr;
+    const unsigned gx = (unsigned)((p.M + 127) / 128);
+    if (p.N % 128 == 0) {
+        hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128), dim3(256), 0, st, p);
+        return "gemm_tiled_kernel<128>";
+    }
+    if (p.N % 64 == 0) {
+        hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(gx, p.N / 64), dim3(256), 0, st, p);
+        return "gemm_tiled_kernel<64>";
+    }
+    return nullptr;
+}

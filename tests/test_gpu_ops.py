@@ -117,9 +117,8 @@ def test_d_block_pieces(impl, H, Cin, Cout):
     check("D conv1 s2 + res", nchw(g_o), ref, 6e-3)
 
 
-@pytest.mark.parametrize("impl", [1])
-def test_gemm_modes(impl):
-    M, N, K = 150, 200, 96
+@pytest.mark.parametrize("impl,M,N,K", [(1, 150, 200, 96), (2, 150, 256, 192), (2, 400, 192, 64), (2, 128, 128, 128)])
+def test_gemm_modes(impl, M, N, K):
     a = rnd(5, "a", (M, K)); w = rnd(5, "w", (N, K), K ** -0.5); bias = rnd(5, "b", (N,), 0.2)
     base = h16(a).astype(np.float64) @ h16(w).astype(np.float64).T + bias
     check("gemm f32", ops.gemm(a, w, bias, mode=3, impl=impl), base, 3e-3)
