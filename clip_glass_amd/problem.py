@@ -1,0 +1,47 @@
+"""Fitness problem — drop-in for /root/reference/problem.py.
+
+Same class name, constructor and `_evaluate(x, out)` contract: `out["F"]` float32 [P] or
+[P,2] = column_stack(-sim, relu(1-D)), `out["G"]` zeros [P] (problem.py:14-29).  The base
+class is pymoo's Problem when pymoo is importable (0.4.2.1 layout first), otherwise a
+minimal stand-in with the attributes pymoo reads.
+"""
+import numpy as np
+
+try:
+    from pymoo.model.problem import Problem            # pymoo==0.4.2.1 (requirements.txt:29)
+except ImportError:
+    try:
+        from pymoo.core.problem import Problem          # newer pymoo
+    except ImportError:
+        class Problem:                                  # attribute bag (pymoo not installed)
+            def __init__(self, n_var=-1, n_obj=-1, n_constr=0, xl=None, xu=None, **kwargs):
+                self.n_var, self.n_obj, self.n_constr = n_var, n_obj, n_constr
+                self.xl = np.full(n_var, xl, dtype=float) if np.isscalar(xl) else xl
+                self.xu = np.full(n_var, xu, dtype=float) if np.isscalar(xu) else xu
+
+            def evaluate(self, x, *args, **kwargs):
+                out = {}
+                self._evaluate(np.atleast_2d(x), out, *args, **kwargs)
+                return out
+
+from .generator import Generator
+
+
+class GenerationProblem(Problem):
+    def __init__(self, config, dist=None):
+        self.generator = Generator(config)
+        self.config = config
+        self._dist = dist
+        super().__init__(**self.config.problem_args)
+
+    def _evaluate(self, x, out, *args, **kwargs):
+        ls = self.config.latent(self.config)
+        ls.set_from_population(x)
+        P = np.asarray(x).shape[0]
+        assert P % self.config.batch_size == 0          # models.py:112 (reference asserts inside generate)
+        F = self.generator.evaluate(ls)
+        if self.config.problem_args["n_obj"] == 2 and self.config.use_discriminator:
+            out["F"] = F                                # column_stack((-sim, hinge)) (problem.py:25)
+        else:
+            out["F"] = F[:, 0]                          # -sim (problem.py:27)
+        out["G"] = np.zeros((P))

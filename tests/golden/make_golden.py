@@ -1,0 +1,124 @@
+"""Generate the committed golden fixtures by running the REFERENCE itself (imported from
+/root/reference in the build container, see ref_harness.py).  Build container only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures hold inputs' seeds and expected outputs only (no reference code, no weights:
+weights/latents/noise are regenerated from (seed, name) by clip_glass_amd/synth.py).
+
+  mini_problem.npz : the WHOLE reference path — problem.GenerationProblem._evaluate
+                     (problem.py:14-29) with config StyleGAN2_ffhq_d semantics on the
+                     "mini" architecture, P=8, batch_size=4, static noise.
+  mid_modules.npz  : G / D / CLIP modules called directly, 64 px "mid" architecture,
+                     per-minibatch noise planes.
+  ffhq_modules.npz : the true 1024 px config-f + ViT-B/32 architecture, P=4.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+
+import ref_harness as rh  # noqa: E402
+import glass_models as M  # noqa: E402
+from clip_glass_amd import synth  # noqa: E402
+
+
+def modules_case(name, P, bs, seed, noise_seed, generation):
+    """Reference G/D/CLIP nn.Modules driven like models.py:108-129 + generator.py:29-60."""
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, seed)
+    sd.update(synth.make_state(synth.clip_text_spec(width=c["clip"][0] if name != "ffhq" else 512,
+                                                    layers=2 if name != "ffhq" else 12, out_dim=c["clip"][5]), seed))
+    G = rh.build_ref_G(sd, c["channels"], c["latent"], c["mapping"])
+    D = rh.build_ref_D(sd, c["channels"])
+    clip_model = rh.build_ref_clip(sd)
+    x = synth.latents(seed + 1, P, c["latent"])
+    z = torch.tensor(x.astype(float)).float()
+    imgs, dis = [], []
+    with torch.no_grad():
+        G(z[:1])  # lets the noise layers learn their shapes
+        for i in range(P // bs):
+            planes = synth.g_noise_planes(noise_seed, generation, i, c["channels"])
+            G.static_noise(noise_tensors=[torch.tensor(p)[None, None] for p in planes])
+            imgs.append(G(z[i * bs:(i + 1) * bs]))
+        img = torch.cat(imgs)
+        img = ((img + 1) / 2.0).clip(0, 1)                                   # utils.py:14-17
+        small = torch.nn.functional.interpolate(img, size=(c["clip"][4],) * 2, mode="bilinear", align_corners=False)
+        feats = clip_model.encode_image(small)
+        for i in range(P // bs):
+            dis.append(D(img[i * bs:(i + 1) * bs] * 2 - 1))                  # utils.py:19-21
+        dis = torch.cat(dis)
+    target = synth.make_target(feats.numpy())
+    sim = torch.cosine_similarity(feats, torch.tensor(target)[None]).numpy()
+    return dict(config=name, P=P, batch_size=bs, seed=seed, noise_seed=noise_seed, generation=generation,
+                target=target, features=feats.numpy(), sim=sim, dis=dis.numpy()[:, 0],
+                hinge=np.maximum(1 - dis.numpy()[:, 0], 0),
+                image_mean=img.mean(dim=(1, 2, 3)).numpy(), image_std=img.std(dim=(1, 2, 3)).numpy(),
+                image_small=small[:2].numpy().astype(np.float16))
+
+
+def problem_case(seed=0, noise_seed=5):
+    """The reference's own problem.py / generator.py / models.py / latent.py driven end to end."""
+    name, P, bs = "mini", 8, 4
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, seed)
+    sd.update(synth.make_state(synth.clip_text_spec(width=64, layers=2, out_dim=c["clip"][5]), seed))
+    R = rh.load_reference()
+    A = rh.load_author_modules()
+    tmp = tempfile.mkdtemp(prefix="glass_golden_")
+    rh.build_ref_G(sd, c["channels"], c["latent"], c["mapping"]).save(os.path.join(tmp, "G.pth"))
+    rh.build_ref_D(sd, c["channels"]).save(os.path.join(tmp, "D.pth"))
+    clip_model = rh.build_ref_clip(sd)
+    R["clip_clip"].load = lambda *a, **k: (clip_model, None)                 # no download (clip.py:24-78)
+    cfg = types.SimpleNamespace(device="cpu", config="StyleGAN2_ffhq_d", target="a wolf at night with the moon in the background")
+    vars(cfg).update(A["config"].get_config("StyleGAN2_ffhq_d"))
+    cfg.weights = tmp
+    cfg.dim_z = c["latent"]
+    cfg.batch_size = bs
+    cfg.problem_args = dict(cfg.problem_args, n_var=c["latent"], n_constr=c["latent"])
+    prob = A["problem"].GenerationProblem(cfg)
+    text_features = prob.generator.text_features.numpy()[0]
+    # kornia.resize stub interpolates to (224,224) as generator.py:45 asks; the mini CLIP takes 32 px
+    # images, so give the stub the model's resolution instead (the call site itself is unchanged)
+    import kornia
+    kornia.resize = lambda x, size: torch.nn.functional.interpolate(x, size=(c["clip"][4],) * 2, mode="bilinear", align_corners=False)
+    planes = synth.g_noise_planes(noise_seed, 0, 0, c["channels"])
+    with torch.no_grad():
+        prob.generator.model.G(torch.zeros(1, c["latent"]))
+        prob.generator.model.G.static_noise(noise_tensors=[torch.tensor(p)[None, None] for p in planes])
+    x = synth.latents(seed + 1, P, c["latent"])
+    out = {}
+    prob._evaluate(x, out)
+    return dict(config=name, P=P, batch_size=bs, seed=seed, noise_seed=noise_seed, text_features=text_features,
+                F=np.asarray(out["F"], dtype=np.float32), G=np.asarray(out["G"]),
+                tokens=R["clip_clip"].tokenize([cfg.target]).numpy()[0])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-ffhq", action="store_true")
+    args = ap.parse_args()
+    assert rh.available(), "needs /root/reference"
+    np.savez_compressed(os.path.join(HERE, "mini_problem.npz"), **problem_case())
+    print("mini_problem.npz")
+    np.savez_compressed(os.path.join(HERE, "mid_modules.npz"), **modules_case("mid", 8, 4, 0, 11, 2))
+    print("mid_modules.npz")
+    np.savez_compressed(os.path.join(HERE, "mini_modules.npz"), **modules_case("mini", 8, 4, 0, 11, 2))
+    print("mini_modules.npz")
+    if not args.skip_ffhq:
+        np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 4, 4, 0, 11, 2))
+        print("ffhq_modules.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -7,7 +7,7 @@ import torch
 
 from clip_glass_amd import synth
 from oracle import fitness_ref
-import models as M
+import glass_models as M
 from util import check, diag
 
 pytestmark = pytest.mark.gpu
@@ -103,3 +103,43 @@ def test_full_size_ffhq_one_minibatch():
     t = time.time()
     _run_case("ffhq", P=4, batch_size=4, use_d=True, noise_mode=2, chunk=4)
     diag("[e2e] full-size ffhq P=4 wall (oracle + engine + weight synthesis): %.1f s" % (time.time() - t))
+
+
+def test_generation_problem_drop_in():
+    """The reference-facing surface: config -> GenerationProblem(config)._evaluate(x, out) -> out["F"], out["G"]
+    plus problem.generator.generate()/save() as run.py's callbacks use them (run.py:45-51,118-125)."""
+    import types
+    from clip_glass_amd import config as gconfig
+    from clip_glass_amd.problem import GenerationProblem
+    name = "mini"
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, 0)
+    tsd = _t(sd)
+    x = synth.latents(1, 8, c["latent"])
+    planes = [synth.g_noise_planes(42, 0, m, c["channels"]) for m in range(2)]
+    detail = {}
+    fitness_ref.evaluate(tsd, x, np.ones(c["clip"][5], np.float32), 4, True, lambda i: planes[i], clip_size=c["clip"][4], detail=detail)
+    target = M.make_target(detail["features"].numpy())
+    Fo, Go = fitness_ref.evaluate(tsd, x, target, 4, True, lambda i: planes[i], clip_size=c["clip"][4])
+    cfg = types.SimpleNamespace(config="StyleGAN2_ffhq_d", device="cuda", target="unused")
+    vars(cfg).update(gconfig.get_config("StyleGAN2_ffhq_d"))
+    vars(cfg).update(weights="synthetic:0", clip_weights="synthetic:0", channels=c["channels"], dim_z=c["latent"],
+                     mapping_layers=c["mapping"], clip_geometry=c["clip"], target_features=target, noise_mode=1,
+                     noise_seed=42, problem_args=dict(cfg.problem_args, n_var=c["latent"], n_constr=c["latent"]))
+    prob = GenerationProblem(cfg)
+    out = {}
+    prob._evaluate(x, out)
+    assert out["F"].shape == (8, 2) and out["F"].dtype == np.float32 and out["G"].shape == (8,) and not out["G"].any()
+    rel = np.abs(out["F"][:, 0] - Fo[:, 0]) / np.abs(Fo[:, 0])
+    diag("[e2e] GenerationProblem drop-in: sim rel err %.3e, hinge abs err %.3e" % (rel.max(), np.abs(out["F"][:, 1] - Fo[:, 1]).max()))
+    assert rel.max() < 1e-3
+    check("drop-in hinge", out["F"][:, 1], Fo[:, 1], 5e-3, atol=2e-3)
+    ls = cfg.latent(cfg)
+    ls.set_from_population(x[:3])
+    img = prob.generator.generate(ls)                      # run.py:118 — no minibatch argument
+    assert img.shape == (3, 3, 32, 32) and img.min() >= 0 and img.max() <= 1
+    import tempfile, os
+    p = os.path.join(tempfile.mkdtemp(), "o.png")
+    prob.generator.save(img, p)
+    assert os.path.getsize(p) > 0
+    prob.generator.engine.close()

@@ -1,0 +1,207 @@
+"""CPU-side tests: C-ABI surface, host logic, the kernels' arithmetic (emulated), sharding
+over a 2-process gloo group.  No GPU needed (`-m "not gpu"`)."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from clip_glass_amd import config as gconfig
+from clip_glass_amd import engine, operators, parallel, synth
+import glass_models as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = engine.load_library()
+    names = set()
+    for hdr in ("glass.h", "glass_ops.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(glass_[a-z0-9_]+)\s*\(", src))
+    assert len(names) >= 25
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+    assert b"gfx950" in lib.glass_version()
+
+
+def test_no_cpu_fallback_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="libglass error"):
+        engine.Engine([32, 32, 16, 16], latent_size=32, mapping_layers=2, clip=M.CONFIGS["mini"]["clip"])
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "clip_glass_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".cpp", ".hip", ".h")):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+            assert not re.search(r"#include\s+[\"<].*oracle", src), f
+            assert "import_module(\"oracle" not in src and "__import__(\"oracle" not in src, f
+
+
+def test_synth_param_counts_and_determinism():
+    g = synth.make_state(synth.stylegan2_g_spec(), 0)
+    d = synth.make_state(synth.stylegan2_d_spec(), 0)
+    assert sum(v.size for v in g.values()) == 30370060            # G = 30.370 M
+    assert sum(v.size for v in d.values()) == 29012513            # D = 29.013 M
+    c = synth.clip_visual_spec()
+    assert sum(int(np.prod(s)) for _, s, _ in c) == 87849216      # CLIP visual = 87.85 M
+    a = synth.make_state(synth.stylegan2_g_spec([16, 16, 32, 32], 32, 2), 3)
+    b = synth.make_state(synth.stylegan2_g_spec([16, 16, 32, 32], 32, 2), 3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert np.array_equal(synth.latents(0, 4, 8), np.random.RandomState(0).normal(size=(4, 8)))
+
+
+def test_noise_plane_is_pure_function_of_its_key():
+    p = synth.noise_plane(7, 3, 5, 2, 64, 64)
+    assert np.array_equal(p, synth.noise_plane(7, 3, 5, 2, 64, 64))
+    assert not np.array_equal(p, synth.noise_plane(7, 3, 6, 2, 64, 64))     # other global minibatch
+    assert not np.array_equal(p, synth.noise_plane(7, 4, 5, 2, 64, 64))     # other generation
+    big = synth.noise_plane(1, 0, 0, 0, 256, 256)
+    assert abs(big.mean()) < 0.02 and abs(big.std() - 1) < 0.02
+    # known-answer: Philox4x32-10 test vector (Random123 kat_vectors: counter 0, key 0)
+    r = synth.philox4x32(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in r] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+
+
+def test_shard_bounds():
+    assert parallel.shard_bounds(512, 8, 4) == [(i * 64, (i + 1) * 64) for i in range(8)]
+    b = parallel.shard_bounds(40, 3, 4)          # 10 minibatches over 3 ranks: 4,3,3
+    assert b == [(0, 16), (16, 28), (28, 40)]
+    assert all((hi - lo) % 4 == 0 for lo, hi in b)
+    assert parallel.shard_bounds(8, 4, 4) == [(0, 4), (4, 8), (8, 8), (8, 8)]
+
+
+def test_config_table_matches_reference_values():
+    c = gconfig.get_config("StyleGAN2_ffhq_d")
+    assert c["pop_size"] == 16 and c["batch_size"] == 4 and c["algorithm"] == "nsga2"      # config.py:85-86,82
+    assert c["problem_args"] == dict(n_var=512, n_obj=2, n_constr=512, xl=-10, xu=10)      # config.py:87-93
+    n = gconfig.get_config("StyleGAN2_ffhq_nod")
+    assert n["problem_args"]["n_obj"] == 1 and n["algorithm"] == "ga" and not n["use_discriminator"]
+    assert set(gconfig.configs) == {"GPT2", "DeepMindBigGAN256", "DeepMindBigGAN512", "StyleGAN2_ffhq_d",
+                                    "StyleGAN2_car_d", "StyleGAN2_church_d", "StyleGAN2_ffhq_nod",
+                                    "StyleGAN2_car_nod", "StyleGAN2_church_nod"}
+    try:
+        import ref_harness as rh
+        if rh.available():
+            ref = rh.load_author_modules()["config"].configs
+            for name in ("StyleGAN2_ffhq_d", "StyleGAN2_church_nod"):
+                for k in ("task", "dim_z", "use_discriminator", "weights", "algorithm", "pop_size", "batch_size", "problem_args"):
+                    assert ref[name][k] == gconfig.configs[name][k], (name, k)
+    except ImportError:
+        pass
+
+
+def test_operators_surface():
+    cfg = types.SimpleNamespace(config="StyleGAN2_ffhq_d")
+    ops = operators.get_operators(cfg)
+    assert set(ops) == {"sampling", "crossover", "mutation"}
+    prob = types.SimpleNamespace(n_var=512)
+    x = ops["sampling"]._do(prob, 16)
+    assert x.shape == (16, 512) and x.dtype == np.float64
+    t = operators.TruncatedNormalRandomSampling()._do(prob, 4)
+    assert t.dtype == np.float32 and np.abs(t).max() <= 2
+    b = operators.BinaryRandomSampling(prob=0.005)._do(types.SimpleNamespace(n_var=1000), 8)
+    assert b.dtype == bool
+    with pytest.raises(Exception, match="Unknown config"):
+        operators.get_operators(types.SimpleNamespace(config="nope"))
+
+
+def test_generation_problem_contract_with_stub_generator(monkeypatch):
+    """`_evaluate` writes out["F"] / out["G"] exactly as problem.py:14-29 does."""
+    from clip_glass_amd import problem
+
+    class FakeGen:
+        def __init__(self, config):
+            self.config = config
+
+        def evaluate(self, ls):
+            (z,) = ls()
+            assert z.dtype == np.float32
+            return np.stack([-z[:, 0], np.maximum(1 - z[:, 1], 0)], axis=1).astype(np.float32)
+    monkeypatch.setattr(problem, "Generator", FakeGen)
+    for name, n_obj in (("StyleGAN2_ffhq_d", 2), ("StyleGAN2_ffhq_nod", 1)):
+        cfg = types.SimpleNamespace(config=name)
+        vars(cfg).update(gconfig.get_config(name))
+        p = problem.GenerationProblem(cfg)
+        assert p.n_var == 512 and p.n_obj == n_obj and p.n_constr == 512
+        x = synth.latents(0, 8, 512)
+        out = {}
+        p._evaluate(x, out)
+        assert out["F"].shape == ((8, 2) if n_obj == 2 else (8,)) and out["F"].dtype == np.float32
+        assert out["G"].shape == (8,) and not out["G"].any()
+        with pytest.raises(AssertionError):
+            p._evaluate(x[:6], {})                # P % batch_size != 0 (models.py:112)
+
+
+def test_kernel_arithmetic_emulated_on_cpu():
+    """The per-kernel parity tests, run against tests/emu_ops.py (numpy/torch emulation of the
+    kernels' arithmetic incl. the C++ weight repacking) — validates the maths without a GPU."""
+    import emu_ops
+    import test_gpu_ops as T
+    T.ops = emu_ops
+    T.test_conv_plain_bias_act(2, 2, 32, 64, 128)
+    T.test_conv_modulated_demod_noise(1)
+    T.test_conv_modulated_up(2)
+    T.test_conv_broadcast_const()
+    T.test_d_block_pieces(2, 64, 32, 64)
+    T.test_torgb_skip(16)
+    T.test_mbstd(8)
+    T.test_resize_patches(64, 32, 8)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class FakeEngine:
+        cfg = types.SimpleNamespace(n_obj=2)
+
+        def evaluate(self, x, generation=0, first_minibatch=0, noise=None):
+            x = np.asarray(x, np.float32)
+            return np.stack([x[:, 0] + 1000 * first_minibatch, x[:, 1] * generation], 1).astype(np.float32)
+    ev = parallel.ShardedEvaluator(FakeEngine(), dist, rank, world, 4)
+    x = synth.latents(0, 24, 8).astype(np.float32)          # 6 minibatches over 2 ranks: 3 + 3
+    Fg = ev.evaluate_global(x, generation=2)
+    xl = synth.latents(10 + rank, 8, 8).astype(np.float32)
+    Fl = ev.evaluate_local(xl, generation=3)
+    x5 = synth.latents(1, 20, 8).astype(np.float32)         # 5 minibatches: ragged 3 + 2
+    Fr = ev.evaluate_global(x5, generation=1)
+    q.put((rank, Fg, Fl, Fr))
+    dist.destroy_process_group()
+
+
+def test_population_sharding_two_process_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    x = synth.latents(0, 24, 8).astype(np.float32)
+    mb = np.repeat(np.array([0, 0, 0, 3, 3, 3]), 4)        # first_minibatch of the shard each row ran in
+    expect = np.stack([x[:, 0] + 1000 * mb, x[:, 1] * 2], 1)
+    for rank, Fg, Fl, Fr in res:
+        np.testing.assert_allclose(Fg, expect, rtol=1e-6)
+        assert Fl.shape == (16, 2)
+        np.testing.assert_allclose(Fl[:8, 0], synth.latents(10, 8, 8)[:, 0].astype(np.float32), rtol=1e-6)
+        np.testing.assert_allclose(Fl[8:, 0], synth.latents(11, 8, 8)[:, 0].astype(np.float32) + 2000, rtol=1e-6)
+        assert Fr.shape == (20, 2)
+        x5 = synth.latents(1, 20, 8).astype(np.float32)
+        np.testing.assert_allclose(Fr[:, 1], x5[:, 1], rtol=1e-6)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
