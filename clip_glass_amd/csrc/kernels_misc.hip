@@ -3,6 +3,7 @@
 // NHWC fp16 activations, wave64 reductions.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -147,42 +148,101 @@ void launch_noise(float* out, int n_mb, int hw, uint32_t layer, uint32_t mb0, ui
 // FIR-upsampled skip sum (models.py:1004-1013; Upsample.forward modules.py:580-602).
 // Upsample taps (zero-insert, pad [3,1], 4x4 FIR*4): out[2m] = .75 x[m-1] + .25 x[m],
 // out[2m+1] = .25 x[m-1] + .75 x[m]  (derived + checked in tests/test_host_math.py).
+// Layout: LPP = C/8 lanes per pixel, each lane reads ONE 16-byte vector (8 channels), so a
+// wave's loads are 1 KiB contiguous; the 3 partial dot products are reduced over the LPP
+// lanes with xor-shuffles and lane 0 of the group writes the pixel (+ upsampled skip).
+template <int LPP>
 __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int W, int C, const float* wrgb,
                                                     const float* bias, const float* sn, int sn_stride,
                                                     const float* smax, int smax_stride, const float* yprev,
                                                     float* yout) {
+    const int b = blockIdx.y;
+    const int sub = threadIdx.x % LPP;                   // which 8-channel group of the pixel
+    const float sm = smax[(long long)b * smax_stride];
+    float w0[8], w1[8], w2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float s = sn[(long long)b * sn_stride + sub * 8 + j] * sm;
+        w0[j] = wrgb[sub * 8 + j] * s;
+        w1[j] = wrgb[C + sub * 8 + j] * s;
+        w2[j] = wrgb[2 * C + sub * 8 + j] * s;
+    }
+    const int hw = H * W;
+    constexpr int PPB = 256 / LPP;                       // pixels per block per iteration
+    for (int pix = blockIdx.x * PPB + threadIdx.x / LPP; pix < hw; pix += gridDim.x * PPB) {
+        const h8 v = *(const h8*)(x + ((long long)b * hw + pix) * C + sub * 8);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j];
+            a0 += f * w0[j]; a1 += f * w1[j]; a2 += f * w2[j];
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o);
+        }
+        if (sub != 0) continue;
+        float r[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
+        if (yprev) {
+            const int py = pix / W, px = pix - py * W;
+            const int h2 = H >> 1, w2_ = W >> 1;
+            const int my = py >> 1, mx = px >> 1;
+            const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2_;
+                float s = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    const int sy = my - 1 + dy;
+                    if (sy < 0) continue;
+                    const float wy = dy ? 1.f - wy0 : wy0;
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int sx = mx - 1 + dx;
+                        if (sx < 0) continue;
+                        const float wx = dx ? 1.f - wx0 : wx0;
+                        s += wy * wx * yp[sy * w2_ + sx];
+                    }
+                }
+                r[c] += s;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) yout[((long long)b * 3 + c) * hw + pix] = r[c];
+    }
+}
+// Thread-per-pixel variant: best for C <= 64 (a pixel's channels are <= 128 contiguous bytes).
+__global__ __launch_bounds__(256) void torgb_pix_kernel(const half_t* x, int H, int W, int C, const float* wrgb,
+                                                        const float* bias, const float* sn, int sn_stride,
+                                                        const float* smax, int smax_stride, const float* yprev,
+                                                        float* yout) {
     extern __shared__ float wl[];  // [3][C] modulated weights of this sample
     const int b = blockIdx.y;
     const float sm = smax[(long long)b * smax_stride];
-    for (int e = threadIdx.x; e < 3 * C; e += 256) {
-        const int i = e % C;
-        wl[e] = wrgb[e] * sn[(long long)b * sn_stride + i] * sm;
-    }
+    for (int e = threadIdx.x; e < 3 * C; e += 256) wl[e] = wrgb[e] * sn[(long long)b * sn_stride + e % C] * sm;
     __syncthreads();
     const int hw = H * W;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= hw) return;
     const half_t* xp = x + ((long long)b * hw + pix) * C;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float r[3] = {bias[0], bias[1], bias[2]};
     for (int i = 0; i < C; i += 8) {
         const h8 v = *(const h8*)(xp + i);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float f = (float)v[j];
-            a0 += f * wl[i + j];
-            a1 += f * wl[C + i + j];
-            a2 += f * wl[2 * C + i + j];
+            r[0] += f * wl[i + j]; r[1] += f * wl[C + i + j]; r[2] += f * wl[2 * C + i + j];
         }
     }
-    float r[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
     if (yprev) {
         const int py = pix / W, px = pix - py * W;
-        const int h2 = H >> 1, w2 = W >> 1;
+        const int h2 = H >> 1, w2_ = W >> 1;
         const int my = py >> 1, mx = px >> 1;
         const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2;
+            const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2_;
             float s = 0.f;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
@@ -193,8 +253,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int 
                 for (int dx = 0; dx < 2; ++dx) {
                     const int sx = mx - 1 + dx;
                     if (sx < 0) continue;
-                    const float wx = dx ? 1.f - wx0 : wx0;
-                    s += wy * wx * yp[sy * w2 + sx];
+                    s += wy * (dx ? 1.f - wx0 : wx0) * yp[sy * w2_ + sx];
                 }
             }
             r[c] += s;
@@ -203,12 +262,30 @@ __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int 
 #pragma unroll
     for (int c = 0; c < 3; ++c) yout[((long long)b * 3 + c) * hw + pix] = r[c];
 }
+template <int LPP>
+static void launch_torgb_t(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
+                           const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
+                           float* yout, hipStream_t st) {
+    const int ppb = 256 / LPP;
+    int gx = (H * W + ppb - 1) / ppb;
+    if (gx > 2048) gx = 2048;                            // grid-stride the rest
+    hipLaunchKernelGGL(torgb_kernel<LPP>, dim3(gx, B), dim3(256), 0, st, x, H, W, C, wrgb, bias, sn, sn_stride, smax,
+                       smax_stride, yprev, yout);
+}
 void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                   const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
                   float* yout, hipStream_t st) {
-    dim3 g((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(torgb_kernel, g, dim3(256), 3 * C * sizeof(float), st, x, H, W, C, wrgb, bias, sn,
-                       sn_stride, smax, smax_stride, yprev, yout);
+    if (C <= 64) {
+        hipLaunchKernelGGL(torgb_pix_kernel, dim3((H * W + 255) / 256, B), dim3(256), 3 * C * sizeof(float), st, x, H, W,
+                           C, wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout);
+        return;
+    }
+#define TORGB_CASE(L) case L: launch_torgb_t<L>(x, B, H, W, C, wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout, st); break;
+    switch (C / 8) {
+        TORGB_CASE(2) TORGB_CASE(4) TORGB_CASE(8) TORGB_CASE(16) TORGB_CASE(32) TORGB_CASE(64)
+        default: abort();  // channels are powers of two >= 16 (checked at engine creation for C % 16)
+    }
+#undef TORGB_CASE
 }
 
 // ---- biggan_norm: utils.py:14-17 ---------------------------------------------------
@@ -290,52 +367,73 @@ void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, cons
 
 // ---- FIR filters of the D down path (modules.py:1204-1220, 499-523) -----------------
 // separable [1,3,3,1]/8 per axis; thread = (pixel, 8-channel group).
-template <int PAD, int STRIDE>
+// Each thread owns one (output column, 8-channel group) and walks RS output rows with a
+// sliding window: per input row 4 loads -> horizontal sum, the last 4 horizontal sums ->
+// vertical sum.  (RS + 3) * 4 loads per RS outputs instead of 16 per output.
+template <int PAD, int STRIDE, int RS>
 __global__ __launch_bounds__(256) void blur_kernel(const half_t* x, int H, int W, int C, int Ho, int Wo,
                                                    half_t* out) {
     const int cg = C >> 3;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = (long long)Ho * Wo * cg;
-    if (idx >= total) return;
-    const int b = blockIdx.y;
-    const int g = (int)(idx % cg);
-    const int ox = (int)((idx / cg) % Wo);
-    const int oy = (int)(idx / ((long long)cg * Wo));
+    const int idx = blockIdx.x * 256 + threadIdx.x;      // over (ox, channel group)
+    if (idx >= Wo * cg) return;
+    const int b = blockIdx.z;
+    const int g = idx % cg, ox = idx / cg;
+    const int oy0 = blockIdx.y * RS;
     const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
     const half_t* xb = x + (long long)b * H * W * C + g * 8;
+    half_t* ob = out + (long long)b * Ho * Wo * C + g * 8;
+    int ixs[4];
+    bool xok[4];
 #pragma unroll
-    for (int jy = 0; jy < 4; ++jy) {
-        const int iy = oy * STRIDE + jy - PAD;
-        if (iy < 0 || iy >= H) continue;
+    for (int jx = 0; jx < 4; ++jx) {
+        ixs[jx] = ox * STRIDE + jx - PAD;
+        xok[jx] = ixs[jx] >= 0 && ixs[jx] < W;
+    }
+    constexpr int NR = (RS - 1) * STRIDE + 4;            // input rows touched by this strip
+    float hs[4][8];                                      // sliding window of horizontal sums
+    const int iy0 = oy0 * STRIDE - PAD;
 #pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const int ix = ox * STRIDE + jx - PAD;
-            if (ix < 0 || ix >= W) continue;
-            const h8 v = *(const h8*)(xb + ((long long)iy * W + ix) * C);
-            const float wgt = f[jy] * f[jx];
+    for (int r = 0; r < NR; ++r) {
+        const int iy = iy0 + r;
+        float h[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += wgt * (float)v[j];
+        for (int j = 0; j < 8; ++j) h[j] = 0.f;
+        if (iy >= 0 && iy < H) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                if (!xok[jx]) continue;
+                const h8 v = *(const h8*)(xb + ((long long)iy * W + ixs[jx]) * C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] += f[jx] * (float)v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hs[r & 3][j] = h[j];
+        // output row whose 4-row window ends at input row r
+        if (r >= 3 && (r - 3) % STRIDE == 0) {
+            const int oy = oy0 + (r - 3) / STRIDE;
+            if (oy < Ho) {
+                h8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (half_t)(f[0] * hs[(r - 3) & 3][j] + f[1] * hs[(r - 2) & 3][j] + f[2] * hs[(r - 1) & 3][j] +
+                                    f[3] * hs[r & 3][j]);
+                *(h8*)(ob + ((long long)oy * Wo + ox) * C) = o;
+            }
         }
     }
-    h8 r;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = (half_t)acc[j];
-    *(h8*)(out + (((long long)b * Ho + oy) * Wo + ox) * C + g * 8) = r;
 }
 void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
     const int Ho = H + 1, Wo = W + 1;
-    const long long total = (long long)Ho * Wo * (C >> 3);
-    hipLaunchKernelGGL((blur_kernel<2, 1>), dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, st, x, H, W, C,
-                       Ho, Wo, out);
+    constexpr int RS = 16;
+    dim3 g((Wo * (C >> 3) + 255) / 256, (Ho + RS - 1) / RS, B);
+    hipLaunchKernelGGL((blur_kernel<2, 1, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out);
 }
 void launch_blur_down(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 2;
-    const long long total = (long long)Ho * Wo * (C >> 3);
-    hipLaunchKernelGGL((blur_kernel<1, 2>), dim3((unsigned)((total + 255) / 256), B), dim3(256), 0, st, x, H, W, C,
-                       Ho, Wo, out);
+    constexpr int RS = 8;
+    dim3 g((Wo * (C >> 3) + 255) / 256, (Ho + RS - 1) / RS, B);
+    hipLaunchKernelGGL((blur_kernel<1, 2, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out);
 }
 
 // ---- MinibatchStd (modules.py:701-747).  Per D call (minibatch of batch_size), groups of
