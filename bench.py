@@ -105,9 +105,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        ev.evaluate_local(synth.latents(1000 * rank + s, P, cfg["latent"]), generation=s)
+    # warm-up passes are profiled per launch (every kernel): they pick the dominant kernel symbol;
+    # the timed region then carries hipEvent pairs only around THAT kernel's launches, so the
+    # event overhead (~7 % with every launch instrumented) stays out of `value`.
     eng.set_profiling(True)
+    warm = {}
+    for s in range(max(args.warmup, 1)):
+        ev.evaluate_local(synth.latents(1000 * rank + s, P, cfg["latent"]), generation=s)
+        warm = {}
+        for r in eng.profile():
+            kern = r["name"].split("@")[1] if "@" in r["name"] else r["name"]
+            a = warm.setdefault(kern, 0.0)
+            warm[kern] = a + r["total_ms"]
+    full_prof = {r["name"]: dict(launches=r["launches"], total_ms=r["total_ms"], flops=r["flops"], bytes=r["bytes"])
+                 for r in eng.profile()}
+    dominant = max(warm.items(), key=lambda kv: kv[1])[0]
+    if os.environ.get("GLASS_BENCH_NOPROF"):
+        eng.set_profiling(False)
+    elif not os.environ.get("GLASS_BENCH_FULLPROF"):
+        eng.set_profile_filter(dominant)
     prof = {}
     sync()
     t0 = time.perf_counter()
@@ -134,13 +150,16 @@ def main():
             b = by_kernel.setdefault(kern, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
             for k in b:
                 b[k] += a[k]
+        if not by_kernel:
+            by_kernel = {"(profiling off)": dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0)}
         kern, a = max(by_kernel.items(), key=lambda kv: kv[1]["total_ms"])
         achieved = a["flops"] / (a["total_ms"] * 1e-3) / 1e12 if a["total_ms"] > 0 else 0.0
-        total_ms = sum(v["total_ms"] for v in by_kernel.values())
-        total_flops = sum(v["flops"] for v in prof.values())
+        warm_total = sum(warm.values())
+        total_ms = sum(v["total_ms"] for v in full_prof.values())
+        total_flops = sum(v["flops"] for v in full_prof.values())
         roofline = dict(bound="mfma", kernel=kern, launches=a["launches"], avg_ms=a["total_ms"] / max(a["launches"], 1),
                         achieved=achieved, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_PEAK_TFLOPS,
-                        traffic=None, share_of_gpu_time=a["total_ms"] / total_ms if total_ms else None,
+                        traffic=None, share_of_gpu_time=warm.get(kern, 0.0) / warm_total if warm_total else None,
                         whole_pass_tflops=total_flops / (total_ms * 1e-3) / 1e12 if total_ms else None)
         out = dict(metric=METRIC, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
@@ -154,7 +173,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, cfg, target)
         if os.environ.get("GLASS_BENCH_DETAIL"):
             with open(os.environ["GLASS_BENCH_DETAIL"], "w") as f:
-                json.dump(dict(per_tag=prof, per_kernel=by_kernel, seconds=dt), f, indent=1)
+                wk = {}
+                for name, a2 in full_prof.items():
+                    kk = name.split("@")[1] if "@" in name else name
+                    b2 = wk.setdefault(kk, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+                    for k2 in b2:
+                        b2[k2] += a2[k2]
+                json.dump(dict(per_tag=full_prof, per_kernel=wk, seconds=dt / args.steps, note="per_tag/per_kernel: ONE fully "
+                               "instrumented warm-up pass; timed region instruments only the dominant kernel"), f, indent=1)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

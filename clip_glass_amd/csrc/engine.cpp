@@ -164,7 +164,7 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     glass_engine* e = new glass_engine();
     e->cfg = *cfg;
     e->R = 4 << (cfg->n_blocks - 1);
-    int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (8 / cfg->batch_size) * cfg->batch_size);
+    int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (16 / cfg->batch_size) * cfg->batch_size);
     chunk = std::min(chunk, cfg->max_pop);
     if (chunk % cfg->batch_size != 0) {
         delete e;
@@ -314,6 +314,11 @@ static int finalize_generator(glass_engine* e) {
             else glass_pack_conv(W->data.data(), g.cout, g.cin, 3, g.cin, packed);
             rc = upload(e, &g.w, packed);
             if (rc) return rc;
+            if (g.up) {
+                glass_pack_conv(W->data.data(), g.cout, g.cin, 3, g.cin, packed);
+                rc = upload(e, &g.w_up, packed);
+                if (rc) return rc;
+            }
             // demod table: Wsq[i][o] = sum_taps (W*coef)^2   (modules.py:943-954, SURVEY 8a note 1)
             std::vector<float> wsq((size_t)g.cin * g.cout);
             const float coef2 = 1.0f / ((float)g.cin * 9.f);
@@ -600,6 +605,10 @@ struct Prof {
     bool on;
     ProfEvent pe;
     Prof(glass_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
+        if (on && !e->prof_filter.empty()) {   // only launches whose kernel symbol (as of the previous pass) matches
+            auto it = e->tag_kernel.find(name);
+            on = it != e->tag_kernel.end() && it->second.find(e->prof_filter) != std::string::npos;
+        }
         if (!on) return;
         auto get = [&]() {
             if (e->event_next == e->event_pool.size()) {
@@ -650,15 +659,18 @@ static void collect_profile(glass_engine* e) {
 
 static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
     Prof pr(e, tag, flops, bytes);
-    const char* k = launch_conv_tiled(p, e->stream);
+    const char* k = p.up ? launch_upconv_fused(p, e->stream) : nullptr;
+    if (!k) k = launch_conv_tiled(p, e->stream);
     if (!k) k = launch_conv_direct(p, e->stream);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+    if (e->profiling) e->tag_kernel[tag] = k;
 }
 static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
     Prof pr(e, tag, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
     const char* k = launch_gemm_tiled(p, e->stream);
     if (!k) k = launch_gemm_direct(p, e->stream);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+    if (e->profiling) e->tag_kernel[tag] = k;
 }
 
 static ConvParams conv_defaults() {
@@ -758,6 +770,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             p.KS = 3;
             p.pad = 1;
             p.w = g.w;
+            p.w_up = g.w_up;
             p.Cout = g.cout;
             p.up = g.up;
             p.Neff = g.up ? 4 * g.cout : g.cout;
@@ -1044,6 +1057,12 @@ extern "C" int glass_engine_last_gpu_ms(glass_engine* e, float* ms) {
 extern "C" int glass_engine_set_profiling(glass_engine* e, int32_t on) {
     REQUIRE(e, GLASS_ERR_ARG, "null engine");
     e->profiling = on != 0;
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_set_profile_filter(glass_engine* e, const char* kernel_substr) {
+    REQUIRE(e, GLASS_ERR_ARG, "null engine");
+    e->prof_filter = kernel_substr ? kernel_substr : "";
     return GLASS_OK;
 }
 

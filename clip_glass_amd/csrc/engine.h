@@ -29,6 +29,7 @@ struct GConv {  // one modulated 3x3 conv of the synthesis network
     int cin, cout, res_in, res_out, up;
     int style_idx, style_off, ds_off, noise_idx;
     half_t* w = nullptr;   // [9][Neff][cin]
+    half_t* w_up = nullptr;  // up layers: un-folded [9][cout][cin]
     float* wsq = nullptr;  // [cin][cout]
     float* bias = nullptr;
     float noise_strength = 0.f;
@@ -113,6 +114,8 @@ struct glass_engine {
 
     // ---- profiling ----
     bool profiling = false;
+    std::string prof_filter;                       // non-empty: only launches of kernels containing this substring
+    std::map<std::string, std::string> tag_kernel;  // layer tag -> kernel symbol used in the previous pass
     std::vector<ProfEvent> prof_events;
     std::vector<glass_prof_row> prof_rows;
     std::vector<hipEvent_t> event_pool;

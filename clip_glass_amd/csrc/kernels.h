@@ -8,6 +8,8 @@ const char* launch_gemm_direct(const GemmParams& p, hipStream_t st);
 // LDS-tiled fast paths; return nullptr when the shape is not supported (caller falls back to direct).
 const char* launch_conv_tiled(const ConvParams& p, hipStream_t st);
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
+// fused transposed-conv + FIR + epilogue (upfir.hip); nullptr when unsupported
+const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);
 
 // --- small fp32 ops (mapping network, style affines, demodulation, heads) ---------
 void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipStream_t st);

@@ -85,6 +85,11 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         glass_pack_conv(d->w, d->Cout, d->Cin, d->KS, d->Cin, pk);
     }
     p.w = dv.up16v(pk);
+    if (d->up) {
+        std::vector<_Float16> pk2;
+        glass_pack_conv(d->w, d->Cout, d->Cin, 3, d->Cin, pk2);
+        p.w_up = dv.up16v(pk2);
+    }
     p.sn = dv.up32(d->sn, (size_t)d->B * d->Cin); p.sn_stride = d->Cin;
     p.dscale = dv.up32(d->dscale, (size_t)d->B * d->Cout); p.ds_stride = d->Cout;
     p.batch_size = d->batch_size > 0 ? d->batch_size : 1;
@@ -99,9 +104,11 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     p.y = y;
     OPREQ(p.x && p.w && y, "device allocation failed");
     if (d->impl == 1) launch_conv_direct(p, 0);
-    else if (d->impl == 2) {
+    else if (d->impl == 3) {
+        if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
+    } else if (d->impl == 2) {
         if (!launch_conv_tiled(p, 0)) { glass_set_error("tiled conv: unsupported shape"); return GLASS_ERR_ARG; }
-    } else if (!launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
+    } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
     int rc = finish();
     if (rc) return rc;
     return down16(d->y, y, nout);

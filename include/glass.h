@@ -115,6 +115,10 @@ typedef struct glass_prof_row {
     double bytes;
 } glass_prof_row;
 int glass_engine_set_profiling(glass_engine* e, int32_t on);
+/* Restrict the per-launch events to launches of kernels whose symbol contains `kernel_substr`
+ * (as resolved in the previous profiled pass); NULL/"" = every launch.  Keeps the event overhead
+ * out of a timed region that only needs the dominant kernel. */
+int glass_engine_set_profile_filter(glass_engine* e, const char* kernel_substr);
 int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_rows, int32_t* n_rows);
 
 /* Device info for bench.py (CU count, name, HBM bytes). */

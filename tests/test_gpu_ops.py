@@ -60,6 +60,8 @@ def test_conv_plain_bias_act(impl, B, H, Cin, Cout):
 def _modconv_case(up, impl, B=4, H=8, Cin=32, Cout=48, L=24, batch_size=2, broadcast=False):
     if impl == 2:
         H, Cout = 32, (32 if up else 64)
+    if isinstance(impl, tuple):           # (3, H, Cin, Cout): fused up-conv shapes
+        impl, H, Cin, Cout = impl
     x = rnd(3, "x", (1 if broadcast else B, Cin, H, H)); w = rnd(3, "w", (Cout, Cin, 3, 3))
     lat = rnd(3, "lat", (B, L)); A = rnd(3, "A", (Cin, L)); Ab = rnd(3, "Ab", (Cin,), 0.2) + 1
     bias = rnd(3, "b", (Cout,), 0.3); strength = 0.37
@@ -81,10 +83,10 @@ def test_conv_modulated_demod_noise(impl):
     check("modconv impl%d" % impl, nchw(got), ref, 5e-3)
 
 
-@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("impl", [1, 2, (3, 32, 32, 32), (3, 16, 64, 32), (3, 64, 32, 64), (3, 40, 32, 96)])
 def test_conv_modulated_up(impl):
     got, ref = _modconv_case(True, impl)
-    check("modconv-up impl%d" % impl, nchw(got), ref, 5e-3)
+    check("modconv-up impl%s" % (impl,), nchw(got), ref, 5e-3)
 
 
 def test_conv_broadcast_const():
