@@ -32,6 +32,7 @@ struct ConvParams {
     int KS, stride, pad;
     const half_t* w;        // [KS*KS][Neff][Cin], Cin contiguous
     const half_t* w_up;     // up only: un-folded weights [9][Cout][Cin] for the fused path (nullable)
+    long long w_bstride;    // elements between per-sample weight sets (0 = shared weights); pre-modulated path
     int Neff, Cout;         // Neff = Cout * (up ? 4 : 1); n = phase*Cout + o
     int up;                 // 1: depth-to-space 2x2 (folded transposed conv + FIR)
     int Ho, Wo;             // output grid

@@ -10,6 +10,7 @@
 // the FIR folded into four phase kernels + depth-to-space (engine.cpp fold_upconv()).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 // Block = one 32 x (32*NW) output tile; the K loop (taps x 16-channel steps) is split
 // round-robin over the 4 waves (split-K, summed through LDS) and software-pipelined one
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 }
 
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
+    if (p.w_bstride != 0) abort();  // per-sample weights are a tiled/upfir-only path (engine guarantees it)
     const long long M = (long long)p.B * p.Hc * p.Wc;
     const unsigned gx = (unsigned)((M + 31) / 32);
     // wide n tiles re-use the activation fragment; narrow ones give small problems more blocks

@@ -18,6 +18,7 @@
 // Epilogue contract identical to conv_direct.hip (demod, noise, bias, lrelu, residual).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define ROWB 80  // bytes per LDS row (32 halfs + 8 pad)
 
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
     }
     const half_t* xb = p.x + (long long)b * p.x_bstride;
+    const half_t* wb = p.w + (long long)b * p.w_bstride;
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
 
     h8 ra[NA], rb[NB];
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             if (NVB % 256 == 0 || u < NVB) {
                 const int tx = u / (NT * 4);
                 const int n = (u >> 2) % NT;
-                rb[k] = *(const h8*)(p.w + ((long long)(ty * KS + tx) * p.Neff + n0 + n) * p.Cin + c0 + part * 8);
+                rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + n0 + n) * p.Cin + c0 + part * 8);
             }
         }
     };
@@ -245,9 +247,12 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     const int KS = p.KS, S = p.stride;
     if (KS == 3 && S == 1 && p.pad == 1) {
+        static const int th4 = getenv("GLASS_TH4") ? atoi(getenv("GLASS_TH4")) : 0;   // experiment knob
         if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
+        if ((th4 & 2) && p.Neff % 64 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 64>(p, st, "conv_tiled_kernel<3,1,4,64>");
         if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64>(p, st, "conv_tiled_kernel<3,1,8,64>");
-        if (p.Neff % 32 == 0 && p.Hc % 16 == 0) return launch_inst<3, 1, 16, 32>(p, st, "conv_tiled_kernel<3,1,16,32>");
+        // memory-bound, tiny K: small tiles = more workgroups per CU = more bytes in flight
+        if ((th4 & 1) && p.Neff % 32 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 32>(p, st, "conv_tiled_kernel<3,1,4,32>");
         if (p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32>(p, st, "conv_tiled_kernel<3,1,8,32>");
         return nullptr;
     }

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -510,6 +511,14 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
+    for (auto& g : e->gconv) {
+        // per-sample weights where the tensor is tiny and the tiled / fused kernels (one sample per block) apply
+        const bool fused_ok = g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in >= 16;
+        const bool tiled_ok = !g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in % 32 == 0;
+        g.welems = 9LL * g.cin * g.cout;
+        g.premod = (fused_ok || tiled_ok) && g.welems * 2 <= (1200 << 10) && !getenv("GLASS_NO_PREMOD");
+        if (g.premod && (rc = dev_alloc(e, &g.wm, (size_t)P * g.welems))) return rc;
+    }
     if (c.noise_mode != 0) {
         const int n_mb = P / c.batch_size;
         for (auto& g : e->gconv) {
@@ -739,6 +748,13 @@ static void run_styles(glass_engine* e, int P) {
             launch_dense(e->d_s + g.style_off, e->S_total, P, g.cin, g.wsq, g.cout, nullptr, e->d_dscale + g.ds_off,
                          e->D_total, 1, 2, e->d_epsrow + g.style_idx, e->n_style, e->stream);
     }
+    {
+        Prof pr(e, "premod_weights", 0, 0);
+        for (auto& g : e->gconv)
+            if (g.premod)
+                launch_modulate_weights(g.up ? g.w_up : g.w, g.welems, g.cin, g.cout, e->d_s + g.style_off, e->S_total,
+                                        e->d_dscale + g.ds_off, e->D_total, P, g.wm, e->stream);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -786,6 +802,13 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             p.batch_size = c.batch_size;
             p.bias = g.bias;
             p.act = 1;
+            if (g.premod) {   // weights already carry style and demod of each sample
+                p.sn = nullptr;
+                p.dscale = nullptr;
+                p.w_bstride = g.welems;
+                if (g.up) { p.w_up = g.wm + (size_t)c0 * g.welems; p.w = nullptr; }
+                else p.w = g.wm + (size_t)c0 * g.welems;
+            }
             half_t* out = pp[(x == pp[0]) ? 1 : 0];
             p.y = out;
             const double flops = 2.0 * B * (double)g.res_in * g.res_in * 9.0 * g.cin * g.cout;  // reference count

@@ -30,6 +30,9 @@ struct GConv {  // one modulated 3x3 conv of the synthesis network
     int style_idx, style_off, ds_off, noise_idx;
     half_t* w = nullptr;   // [9][Neff][cin]
     half_t* w_up = nullptr;  // up layers: un-folded [9][cout][cin]
+    half_t* wm = nullptr;    // pre-modulated per-sample weights [P][welems] (small high-res layers only)
+    long long welems = 0;
+    bool premod = false;
     float* wsq = nullptr;  // [cin][cout]
     float* bias = nullptr;
     float noise_strength = 0.f;

@@ -21,6 +21,9 @@ void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N,
 // per (p, layer): smax = max|s|, s /= smax, eps_row = eps / smax^2
 void launch_style_norm(float* s, int ld, int P, int n_layers, const int* d_off, const int* d_len,
                        float* smax, float* eps_row, float eps, hipStream_t st);
+// per-sample modulated+demodulated weights: wm[b][e] = w[e] * sn[b][e % Cin] * dscale[b][(e / Cin) % Cout]
+void launch_modulate_weights(const half_t* w, long long elems, int Cin, int Cout, const float* sn, int sn_stride,
+                              const float* dscale, int ds_stride, int P, half_t* wm, hipStream_t st);
 void launch_noise(float* out, int n_mb, int hw, uint32_t layer, uint32_t mb0, uint32_t generation,
                   uint64_t seed, hipStream_t st);
 

@@ -102,6 +102,31 @@ void launch_style_norm(float* s, int ld, int P, int n_layers, const int* d_off, 
                        smax, eps_row, eps);
 }
 
+// ---- per-sample weights for the high-resolution layers: the reference's own formulation
+// (modules.py:940-958: w * style, * demod), materialised once per pass where the weight
+// tensor is tiny (<= ~1 MB); removes the modulation VALU work from the conv staging loop.
+__global__ void modulate_weights_kernel(const half_t* w, long long elems, int Cin, int Cout, const float* sn,
+                                        int sn_stride, const float* dscale, int ds_stride, half_t* wm) {
+    const int b = blockIdx.y;
+    const long long e8 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (e8 >= elems) return;
+    const int i = (int)(e8 % Cin);
+    const int o = (int)((e8 / Cin) % Cout);
+    const h8 v = *(const h8*)(w + e8);
+    const float d = dscale ? dscale[(long long)b * ds_stride + o] : 1.f;
+    const float* s = sn + (long long)b * sn_stride + i;
+    h8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (half_t)((float)v[j] * s[j] * d);
+    *(h8*)(wm + (long long)b * elems + e8) = r;
+}
+void launch_modulate_weights(const half_t* w, long long elems, int Cin, int Cout, const float* sn, int sn_stride,
+                              const float* dscale, int ds_stride, int P, half_t* wm, hipStream_t st) {
+    dim3 g((unsigned)((elems / 8 + 255) / 256), P);
+    hipLaunchKernelGGL(modulate_weights_kernel, g, dim3(256), 0, st, w, elems, Cin, Cout, sn, sn_stride, dscale,
+                       ds_stride, wm);
+}
+
 // ---- noise planes: Philox4x32-10 + Box-Muller (numpy mirror: clip_glass_amd/synth.py) --
 __device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 #pragma unroll

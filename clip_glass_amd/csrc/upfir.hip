@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
         a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
     }
     const half_t* xb = p.x + (long long)b * p.x_bstride;
+    const half_t* wb = p.w_up + (long long)b * p.w_bstride;
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
 
     h8 ra[NA], rb[NB];
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             if (u < NVB) {
                 const int tap = u >> 7;           // / (32 * 4)
                 const int n = (u >> 2) & 31;
-                rb[k] = *(const h8*)(p.w_up + ((long long)tap * p.Cout + n0 + n) * p.Cin + c0 + part * 8);
+                rb[k] = *(const h8*)(wb + ((long long)tap * p.Cout + n0 + n) * p.Cin + c0 + part * 8);
             }
         }
     };
