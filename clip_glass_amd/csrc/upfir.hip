@@ -175,23 +175,27 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     __syncthreads();
 
     // ---- FIR (separable [1,3,3,1]/4 per axis, sliding window) + noise + bias + lrelu -----------
+    // Packed-fp16 arithmetic (v_pk_fma_f16): the t tile is fp16 already; 4+4 taps with weights
+    // {1/4,3/4} add ~2 fp16 roundings per output — same class as the fp16 activation store.
     if (t >= 240) return;
     const int cg = t & 3, oxl = t >> 2;              // 8-channel group, local output column 0..59
     const int px = txi * 60 + oxl;
     if (px >= p.Wo) return;
-    const float f[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-    f4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+    const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+    h8 bias8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias8[j] = (half_t)0.f;
     if (p.bias) {
-        b0 = *(const f4*)(p.bias + n0 + cg * 8);
-        b1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
+        const f4 b0 = *(const f4*)(p.bias + n0 + cg * 8), b1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)b0[j]; bias8[j + 4] = (half_t)b1[j]; }
     }
     const float* nz = p.noise ? p.noise + (long long)(b / p.batch_size) * p.Ho * p.Wo : nullptr;
-    float hs[4][8];
+    const half_t k1 = (half_t)(GLASS_SQRT2 * p.out_scale), k2 = (half_t)(0.2f * GLASS_SQRT2 * p.out_scale);
+    h8 hs[4];
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
-        float h[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = 0.f;
+        h8 hv[4];
 #pragma unroll
         for (int jx = 0; jx < 4; ++jx) {
             const int ltx = oxl + 1 + jx;
@@ -199,29 +203,27 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             const h8 v = *(const h8*)(T + ((r * 64 + ltx) * 32 + ((cg ^ (sw >> 1)) * 8)));
             if (sw & 1) {                            // the two quads of the pair sit swapped
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { h[j] += f[jx] * (float)v[j + 4]; h[j + 4] += f[jx] * (float)v[j]; }
+                for (int j = 0; j < 4; ++j) { hv[jx][j] = v[j + 4]; hv[jx][j + 4] = v[j]; }
             } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] += f[jx] * (float)v[j];
+                hv[jx] = v;
             }
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hs[r & 3][j] = h[j];
+        hs[r & 3] = (hv[0] + hv[3]) * fq + (hv[1] + hv[2]) * ft;
         if (r >= 4) {
             const int py = tyi * 12 + (r - 4);
             if (py < p.Ho) {
-                float nv = 0.f;
-                if (nz) nv = p.noise_strength * nz[(long long)py * p.Wo + px];
-                h8 o;
+                h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + (hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft;
+                half_t nv = (half_t)0.f;
+                if (nz) nv = (half_t)(p.noise_strength * nz[(long long)py * p.Wo + px]);
+                v = v + bias8 + nv;
+                if (p.act) {
+                    const h8 a = v * k1, c2 = v * k2;     // lrelu(v)*sqrt2*scale = max(v*k1, v*k2) for k1 > k2 > 0
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float v = f[0] * hs[(r - 3) & 3][j] + f[1] * hs[(r - 2) & 3][j] + f[2] * hs[(r - 1) & 3][j] +
-                              f[3] * hs[r & 3][j];
-                    v += nv + (j < 4 ? b0[j] : b1[j - 4]);
-                    if (p.act) v = lrelu_sqrt2(v);
-                    o[j] = (half_t)(v * p.out_scale);
+                    for (int j = 0; j < 8; ++j) v[j] = a[j] > c2[j] ? a[j] : c2[j];
+                } else {
+                    v = v * (half_t)p.out_scale;
                 }
-                *(h8*)(p.y + (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + n0 + cg * 8) = o;
+                *(h8*)(p.y + (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + n0 + cg * 8) = v;
             }
         }
     }
