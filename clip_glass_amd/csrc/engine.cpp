@@ -173,7 +173,10 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
         return GLASS_ERR_ARG;
     }
     e->chunk = chunk;
+    e->overlap = getenv("GLASS_NO_OVERLAP") == nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream_d, hipStreamNonBlocking);
+    e->cur = e->stream;
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err != hipSuccess) {
@@ -189,12 +192,16 @@ extern "C" void glass_engine_destroy(glass_engine* e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->stream_d) hipStreamSynchronize(e->stream_d);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
+    for (auto ev : e->ev_g) hipEventDestroy(ev);
+    for (auto ev : e->ev_d) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream_d) hipStreamDestroy(e->stream_d);
     delete e;
 }
 
@@ -536,10 +543,10 @@ static int alloc_buffers(glass_engine* e) {
     }
     maxact = std::max(maxact, (size_t)16 * (c.channels[0] + 16));
     e->act_elems = maxact * CH;
-    const int n_act = c.use_discriminator ? 6 : 2;
-    for (int i = 0; i < n_act; ++i)
-        if ((rc = dev_alloc(e, &e->act[i], e->act_elems))) return rc;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 8; ++i)   // [0..5]: D scratch (D stream), [6..7]: G ping-pong (main stream)
+        if (i >= 6 || c.use_discriminator)
+            if ((rc = dev_alloc(e, &e->act[i], e->act_elems))) return rc;
+    for (int i = 0; i < 4; ++i)     // two sets (chunk parity) of skip-image ping-pong
         if ((rc = dev_alloc(e, &e->ybuf[i], (size_t)CH * 3 * e->R * e->R))) return rc;
     // whole-population buffers for the low-resolution phases (res <= low_res)
     {
@@ -632,11 +639,11 @@ struct Prof {
         pe.bytes = bytes;
         pe.e0 = get();
         pe.e1 = get();
-        hipEventRecord(pe.e0, e->stream);
+        hipEventRecord(pe.e0, e->cur);
     }
     ~Prof() {
         if (!on) return;
-        hipEventRecord(pe.e1, e->stream);
+        hipEventRecord(pe.e1, e->cur);
         e->prof_events.push_back(pe);
     }
 };
@@ -668,16 +675,16 @@ static void collect_profile(glass_engine* e) {
 
 static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
     Prof pr(e, tag, flops, bytes);
-    const char* k = p.up ? launch_upconv_fused(p, e->stream) : nullptr;
-    if (!k) k = launch_conv_tiled(p, e->stream);
-    if (!k) k = launch_conv_direct(p, e->stream);
+    const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
+    if (!k) k = launch_conv_tiled(p, e->cur);
+    if (!k) k = launch_conv_direct(p, e->cur);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
     if (e->profiling) e->tag_kernel[tag] = k;
 }
 static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
     Prof pr(e, tag, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
-    const char* k = launch_gemm_tiled(p, e->stream);
-    if (!k) k = launch_gemm_direct(p, e->stream);
+    const char* k = launch_gemm_tiled(p, e->cur);
+    if (!k) k = launch_gemm_direct(p, e->cur);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
     if (e->profiling) e->tag_kernel[tag] = k;
 }
@@ -702,7 +709,7 @@ static int upload_noise(glass_engine* e, int P, int generation, int first_mb, co
             const int hw = e->gconv[l].res_out * e->gconv[l].res_out;
             Prof pr(e, "noise", 0, (double)n_mb * hw * 4);
             launch_noise(e->d_noise[l], n_mb, hw, (uint32_t)l, (uint32_t)first_mb, (uint32_t)generation, c.noise_seed,
-                         e->stream);
+                         e->cur);
         }
     } else if (c.noise_mode == 2) {
         REQUIRE(noise && noise->planes, GLASS_ERR_ARG, "noise_mode 2 requires caller-provided noise planes");
@@ -714,9 +721,9 @@ static int upload_noise(glass_engine* e, int P, int generation, int first_mb, co
                 const float* src = noise->planes[(size_t)m * noise->n_layers + l];
                 REQUIRE(src, GLASS_ERR_ARG, "noise: null plane");
                 GLASS_HIP(hipMemcpyAsync(e->d_noise[l] + (size_t)m * hw, src, hw * sizeof(float), hipMemcpyHostToDevice,
-                                         e->stream));
+                                         e->cur));
             }
-        GLASS_HIP(hipStreamSynchronize(e->stream));  // caller's planes may be freed after return
+        GLASS_HIP(hipStreamSynchronize(e->cur));  // caller's planes may be freed after return
     }
     return GLASS_OK;
 }
@@ -726,34 +733,34 @@ static void run_styles(glass_engine* e, int P) {
     const int L = c.latent_size;
     {
         Prof pr(e, "mapping", 2.0 * P * L * L * c.mapping_layers, 4.0 * L * L * c.mapping_layers);
-        launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->stream);
+        launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->cur);
         float *a = e->d_w0, *b = e->d_w1;
         for (int i = 0; i < c.mapping_layers; ++i) {
-            launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->stream);
+            launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->cur);
             std::swap(a, b);
         }
         if (a != e->d_w0)  // result must end in d_w0
-            hipMemcpyAsync(e->d_w0, a, (size_t)P * L * sizeof(float), hipMemcpyDeviceToDevice, e->stream);
+            hipMemcpyAsync(e->d_w0, a, (size_t)P * L * sizeof(float), hipMemcpyDeviceToDevice, e->cur);
     }
     {
         Prof pr(e, "styles", 2.0 * P * L * e->S_total, 4.0 * L * e->S_total);
         launch_dense(e->d_w0, L, P, L, e->style_wt, e->S_total, e->style_b, e->d_s, e->S_total, 0, 0, nullptr, 0,
-                     e->stream);
+                     e->cur);
         launch_style_norm(e->d_s, e->S_total, P, e->n_style, e->d_style_off, e->d_style_len, e->d_smax, e->d_epsrow,
-                          1e-8f, e->stream);
+                          1e-8f, e->cur);
     }
     {
         Prof pr(e, "demod", 0, 0);
         for (auto& g : e->gconv)
             launch_dense(e->d_s + g.style_off, e->S_total, P, g.cin, g.wsq, g.cout, nullptr, e->d_dscale + g.ds_off,
-                         e->D_total, 1, 2, e->d_epsrow + g.style_idx, e->n_style, e->stream);
+                         e->D_total, 1, 2, e->d_epsrow + g.style_idx, e->n_style, e->cur);
     }
     {
         Prof pr(e, "premod_weights", 0, 0);
         for (auto& g : e->gconv)
             if (g.premod)
                 launch_modulate_weights(g.up ? g.w_up : g.w, g.welems, g.cin, g.cout, e->d_s + g.style_off, e->S_total,
-                                        e->d_dscale + g.ds_off, e->D_total, P, g.wm, e->stream);
+                                        e->d_dscale + g.ds_off, e->D_total, P, g.wm, e->cur);
     }
 }
 
@@ -826,7 +833,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
                     B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));
             launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
                          e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style, yprev, yb[yi],
-                         e->stream);
+                         e->cur);
         }
         yprev = yb[yi];
         yi ^= 1;
@@ -852,12 +859,12 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         {
             snprintf(tag, sizeof tag, "D.blur.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
-            launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->stream);
+            launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->cur);
         }
         {
             snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);
-            launch_blur_down(X, B, r, r, d.cin, XS, e->stream);
+            launch_blur_down(X, B, r, r, d.cin, XS, e->cur);
         }
         ConvParams s = conv_defaults();
         s.x = XS; s.x_bstride = (long long)r2 * r2 * d.cin; s.B = B; s.H = s.W = r2; s.Cin = d.cin;
@@ -881,7 +888,7 @@ static void run_fromrgb(glass_engine* e, int B, const float* y, half_t* X) {
     const int n = c.n_blocks;
     Prof pr(e, "D.fromrgb", 2.0 * B * (double)e->R * e->R * 3 * c.channels[n - 1],
             B * (double)e->R * e->R * (12.0 + 2.0 * c.channels[n - 1]));
-    launch_fromrgb(y, B, e->R, c.channels[n - 1], e->d_frgb_w, e->d_frgb_b, X, e->stream);
+    launch_fromrgb(y, B, e->R, c.channels[n - 1], e->d_frgb_w, e->d_frgb_b, X, e->cur);
 }
 
 // mbstd + final conv + dense head for the whole population: X is [P][4][4][C0]
@@ -890,7 +897,7 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     const int CL = c.channels[0];
     {
         Prof pr(e, "D.mbstd", 0, 4.0 * P * 16 * CL);
-        launch_mbstd(X, P, 16, CL, e->d_final_cpad, c.batch_size, c.mbstd_group, 1e-8f, scratch, e->stream);
+        launch_mbstd(X, P, 16, CL, e->d_final_cpad, c.batch_size, c.mbstd_group, 1e-8f, scratch, e->cur);
     }
     ConvParams p = conv_defaults();
     p.x = scratch; p.x_bstride = 16LL * e->d_final_cpad; p.B = P; p.H = p.W = 4; p.Cin = e->d_final_cpad; p.Hc = p.Wc = 4;
@@ -904,7 +911,7 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     run_gemm(e, g, "D.dense0");
     {
         Prof pr(e, "D.dense1", 2.0 * P * CL, 0);
-        launch_dense(e->d_dh, CL, P, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis, 1, 0, 0, nullptr, 0, e->stream);
+        launch_dense(e->d_dh, CL, P, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis, 1, 0, 0, nullptr, 0, e->cur);
     }
 }
 
@@ -917,26 +924,26 @@ static void run_clip(glass_engine* e, int P) {
     run_gemm(e, g, "clip.patch_embed");
     {
         Prof pr(e, "clip.embed_lnpre", 0, 8.0 * M * W);
-        launch_embed_lnpre(e->d_pe, e->c_cls, e->c_pos, e->c_lnpre_g, e->c_lnpre_b, P, T, W, e->d_x, e->stream);
+        launch_embed_lnpre(e->d_pe, e->c_cls, e->c_pos, e->c_lnpre_g, e->c_lnpre_b, P, T, W, e->d_x, e->cur);
     }
     for (auto& b : e->cblk) {
         {
             Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
-            launch_layernorm(e->d_x, W, M, W, b.ln1_g, b.ln1_b, e->d_ln16, nullptr, e->stream);
+            launch_layernorm(e->d_x, W, M, W, b.ln1_g, b.ln1_b, e->d_ln16, nullptr, e->cur);
         }
         memset(&g, 0, sizeof g);
         g.a = e->d_ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = e->d_qkv; g.ldo = 3 * W;
         run_gemm(e, g, "clip.qkv");
         {
             Prof pr(e, "clip.attention", 4.0 * P * c.clip_heads * (double)T * T * 64, 8.0 * M * W);
-            launch_attention(e->d_qkv, P, T, c.clip_heads, 64, 0, e->d_attn, e->stream);
+            launch_attention(e->d_qkv, P, T, c.clip_heads, 64, 0, e->d_attn, e->cur);
         }
         memset(&g, 0, sizeof g);
         g.a = e->d_attn; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = e->d_x; g.ldo = W;
         run_gemm(e, g, "clip.attn_out");
         {
             Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
-            launch_layernorm(e->d_x, W, M, W, b.ln2_g, b.ln2_b, e->d_ln16, nullptr, e->stream);
+            launch_layernorm(e->d_x, W, M, W, b.ln2_g, b.ln2_b, e->d_ln16, nullptr, e->cur);
         }
         memset(&g, 0, sizeof g);
         g.a = e->d_ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = e->d_hid; g.ldo = 4 * W;
@@ -947,10 +954,10 @@ static void run_clip(glass_engine* e, int P) {
     }
     {
         Prof pr(e, "clip.head", 2.0 * P * W * c.clip_embed, 4.0 * W * c.clip_embed);
-        launch_layernorm(e->d_x, (long long)T * W, P, W, e->c_lnpost_g, e->c_lnpost_b, nullptr, e->d_cls, e->stream);
+        launch_layernorm(e->d_x, (long long)T * W, P, W, e->c_lnpost_g, e->c_lnpost_b, nullptr, e->d_cls, e->cur);
         launch_dense(e->d_cls, W, P, W, e->c_proj, c.clip_embed, nullptr, e->d_feat, c.clip_embed, 0, 0, nullptr, 0,
-                     e->stream);
-        launch_cosine(e->d_feat, e->d_target, P, c.clip_embed, e->d_sim, e->stream);
+                     e->cur);
+        launch_cosine(e->d_feat, e->d_target, P, c.clip_embed, e->d_sim, e->cur);
     }
 }
 
@@ -966,8 +973,8 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     GLASS_HIP(hipSetDevice(c.device));
     const int L = c.latent_size;
     memcpy(e->h_pinned, latents, (size_t)P * L * sizeof(float));
-    GLASS_HIP(hipEventRecord(e->ev0, e->stream));
-    GLASS_HIP(hipMemcpyAsync(e->d_z, e->h_pinned, (size_t)P * L * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    GLASS_HIP(hipEventRecord(e->ev0, e->cur));
+    GLASS_HIP(hipMemcpyAsync(e->d_z, e->h_pinned, (size_t)P * L * sizeof(float), hipMemcpyHostToDevice, e->cur));
     run_styles(e, P);
     int rc = upload_noise(e, P, generation, first_mb, noise);
     if (rc) return rc;
@@ -992,26 +999,46 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     half_t* dmid = e->low[5];
     const int res_mid = d_hi < nd ? e->dblk[d_hi].res : 4;
     const long long dmid_bs = (long long)res_mid * res_mid * (d_hi < nd ? e->dblk[d_hi].cin : c.channels[0]);
-    // ---- phase B: high-resolution synthesis (+ high-resolution D) per chunk -----------------
-    for (int c0 = 0; c0 < P; c0 += e->chunk) {
+    // ---- phase B: high-resolution synthesis per chunk on the main stream; resize + high-resolution
+    // D of chunk k run on the second stream, overlapping the synthesis of chunk k+1 (memory-bound
+    // and matrix-bound phases of the two networks interleave on the CUs).
+    const int n_chunks = (P + e->chunk - 1) / e->chunk;
+    while ((int)e->ev_g.size() < n_chunks) {
+        hipEvent_t a, b2;
+        GLASS_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        GLASS_HIP(hipEventCreateWithFlags(&b2, hipEventDisableTiming));
+        e->ev_g.push_back(a);
+        e->ev_d.push_back(b2);
+    }
+    const bool overlap = e->overlap && out_F;
+    hipStream_t sd = overlap ? e->stream_d : e->stream;
+    for (int c0 = 0, k = 0; c0 < P; c0 += e->chunk, ++k) {
         const int B = std::min(e->chunk, P - c0);
+        const int set = k & 1;
+        e->cur = e->stream;
+        if (overlap && k >= 2) GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_d[k - 2], 0));  // y set re-use
         const float* y = ylow + (size_t)c0 * 3 * res_low * res_low;
         if (nlow < n) {
-            half_t* const pp[2] = {e->act[0], e->act[1]};
-            float* const yb[2] = {e->ybuf[0], e->ybuf[1]};
+            half_t* const pp[2] = {e->act[6], e->act[7]};
+            float* const yb[2] = {e->ybuf[2 * set], e->ybuf[2 * set + 1]};
             const half_t* xo;
             run_g_blocks(e, c0, B, nlow, n, xlow + (size_t)c0 * xlow_bs, xlow_bs, pp, y, yb, &xo, &y);
         }
         if (images) {
-            launch_finalize_image(y, e->d_img, (long long)B * img_elems, e->stream);
+            launch_finalize_image(y, e->d_img, (long long)B * img_elems, e->cur);
             GLASS_HIP(hipMemcpyAsync(images + (size_t)c0 * img_elems, e->d_img, (size_t)B * img_elems * sizeof(float),
-                                     hipMemcpyDeviceToHost, e->stream));
+                                     hipMemcpyDeviceToHost, e->cur));
         }
         if (out_F) {
+            if (overlap) {
+                GLASS_HIP(hipEventRecord(e->ev_g[k], e->stream));
+                GLASS_HIP(hipStreamWaitEvent(sd, e->ev_g[k], 0));
+            }
+            e->cur = sd;
             {
                 Prof pr(e, "clip.resize", 0, B * (16.0 * c.clip_res * c.clip_res * 3 + 2.0 * 3 * c.clip_res * c.clip_res));
                 launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
-                                      e->stream);
+                                      e->cur);
             }
             if (want_d) {
                 if (d_hi > 0) {
@@ -1019,27 +1046,38 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
                     half_t* const bufs[5] = {e->act[1], e->act[2], e->act[3], e->act[4], e->act[5]};
                     half_t* Xo = run_d_blocks(e, B, 0, d_hi, e->act[0], bufs);
                     GLASS_HIP(hipMemcpyAsync(dmid + (size_t)c0 * dmid_bs, Xo, (size_t)B * dmid_bs * sizeof(half_t),
-                                             hipMemcpyDeviceToDevice, e->stream));
+                                             hipMemcpyDeviceToDevice, e->cur));
                 } else {
                     run_fromrgb(e, B, y, dmid + (size_t)c0 * dmid_bs);
                 }
             }
+            if (overlap) GLASS_HIP(hipEventRecord(e->ev_d[k], sd));
         }
     }
-    // ---- phase C: low-resolution discriminator + head, whole population ----------------------
+    // ---- phase C: low-resolution discriminator + head (second stream) || CLIP (main stream) ------
     if (want_d) {
+        e->cur = sd;
         half_t* const bufs[5] = {e->low[0], e->low[1], e->low[2], e->low[3], e->low[4]};
         half_t* Xo = run_d_blocks(e, P, d_hi, nd, dmid, bufs);
         run_d_head(e, P, Xo, Xo == e->low[0] ? e->low[1] : e->low[0]);
     }
     if (out_F) {
+        if (overlap) {   // patches (written on the second stream) -> CLIP on the main stream
+            GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_d[n_chunks - 1], 0));
+        }
+        e->cur = e->stream;
         run_clip(e, P);
-        launch_assemble_F(e->d_sim, e->d_dis, P, c.n_obj, e->d_F, e->stream);
+        if (overlap) {   // join: D head finished
+            GLASS_HIP(hipEventRecord(e->ev_g[0], sd));
+            GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_g[0], 0));
+        }
+        launch_assemble_F(e->d_sim, e->d_dis, P, c.n_obj, e->d_F, e->cur);
         GLASS_HIP(hipMemcpyAsync(e->h_pinned, e->d_F, (size_t)P * c.n_obj * sizeof(float), hipMemcpyDeviceToHost,
-                                 e->stream));
+                                 e->cur));
     }
-    GLASS_HIP(hipEventRecord(e->ev1, e->stream));
-    GLASS_HIP(hipStreamSynchronize(e->stream));
+    e->cur = e->stream;
+    GLASS_HIP(hipEventRecord(e->ev1, e->cur));
+    GLASS_HIP(hipStreamSynchronize(e->cur));
     GLASS_HIP(hipGetLastError());
     GLASS_HIP(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
     if (out_F) memcpy(out_F, e->h_pinned, (size_t)P * c.n_obj * sizeof(float));

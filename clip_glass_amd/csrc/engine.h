@@ -66,7 +66,9 @@ struct glass_engine {
     int S_total = 0, D_total = 0;
     int chunk = 0;
     bool finalized = false, has_target = false;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_d = nullptr, cur = nullptr;  // main, second (D/resize), current target
+    bool overlap = true;
+    std::vector<hipEvent_t> ev_g, ev_d;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;
     int last_P = 0;
@@ -101,12 +103,12 @@ struct glass_engine {
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;
     std::vector<float*> d_noise;  // per noise layer: [n_mb_max][res*res]
-    half_t* act[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per-chunk, high resolution
+    half_t* act[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // per-chunk, high resolution
     half_t* low[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // whole population, res <= low_res
     float* ylow[2] = {nullptr, nullptr};
     int low_res = 32, n_low = 0;
     size_t act_elems = 0;
-    float* ybuf[2] = {nullptr, nullptr};
+    float* ybuf[4] = {nullptr, nullptr, nullptr, nullptr};
     float* d_img = nullptr;
     half_t *d_patches = nullptr, *d_ln16 = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_hid = nullptr;
     float *d_pe = nullptr, *d_x = nullptr, *d_cls = nullptr, *d_feat = nullptr, *d_sim = nullptr, *d_dis = nullptr,
