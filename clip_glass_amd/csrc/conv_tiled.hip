@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
 
     h8 ra[NA], rb[NB];
-    f4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = {1.f, 1.f, 1.f, 1.f};
+    h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] = (half_t)1.f;
 
     auto load_a = [&](int c0) {
 #pragma unroll
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
         }
         if (snb) {
-            s0 = *(const f4*)(snb + c0);
-            s1 = *(const f4*)(snb + c0 + 4);
+            const f4 s0 = *(const f4*)(snb + c0), s1 = *(const f4*)(snb + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
         }
     };
     auto load_b = [&](int c0, int ty) {
@@ -100,13 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const int v = t + 256 * k;
             if (NVA % 256 == 0 || v < NVA) {
                 h8 a = ra[k];
-                if (snb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[j] = (half_t)((float)a[j] * s0[j]);
-                        a[j + 4] = (half_t)((float)a[j + 4] * s1[j]);
-                    }
-                }
+                if (snb) a = a * sh;   // 4 x v_pk_mul_f16
                 *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
             }
         }

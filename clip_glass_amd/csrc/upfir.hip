@@ -61,7 +61,9 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
 
     h8 ra[NA], rb[NB];
-    f4 s0 = {1.f, 1.f, 1.f, 1.f}, s1 = {1.f, 1.f, 1.f, 1.f};
+    h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] = (half_t)1.f;
     auto load_a = [&](int c0) {
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
@@ -70,8 +72,9 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
         }
         if (snb) {
-            s0 = *(const f4*)(snb + c0);
-            s1 = *(const f4*)(snb + c0 + 4);
+            const f4 s0 = *(const f4*)(snb + c0), s1 = *(const f4*)(snb + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
         }
     };
     auto load_b = [&](int c0) {
@@ -91,13 +94,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             const int v = t + 256 * k;
             if (v < NVA) {
                 h8 a = ra[k];
-                if (snb) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        a[j] = (half_t)((float)a[j] * s0[j]);
-                        a[j + 4] = (half_t)((float)a[j + 4] * s1[j]);
-                    }
-                }
+                if (snb) a = a * sh;   // 4 x v_pk_mul_f16
                 *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
             }
         }
@@ -130,21 +127,30 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             load_a((s + 1) * 32);
             load_b((s + 1) * 32);
         }
-        // tap (ky,kx): parity (ky&1, kx&1); reads x[m - (k>>1)]
+        // tap (ky,kx) feeds parity class (ky&1, kx&1) and reads x[m - (ky>>1), n - (kx>>1)]: the 9 taps
+        // use only 4 distinct input shifts, so each x fragment is loaded once per shift and re-used
+        // by every tap of that shift (17 LDS fragment reads per 18 MFMAs instead of 27).
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ry = ky & 1, ay = ky >> 1;
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int rx = kx & 1, ax = kx >> 1;
+            for (int ay = 0; ay < 2; ++ay) {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const h8 wf = *(const h8*)(Bs + ((ky * 3 + kx) * 32 + lr) * ROWB + kk * 32 + kh * 16);
+                for (int ax = 0; ax < 2; ++ax) {
+                    h8 wf[2][2];   // taps of this shift: ky in {2ay, 2ay+1 (if ay == 0)}, kx likewise
+#pragma unroll
+                    for (int ky = ay * 2; ky < (ay ? 3 : 2); ++ky)
+#pragma unroll
+                        for (int kx = ax * 2; kx < (ax ? 3 : 2); ++kx)
+                            wf[ky & 1][kx & 1] = *(const h8*)(Bs + ((ky * 3 + kx) * 32 + lr) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const int prow = wave * 2 + i + 1 - ay;          // patch row of x[my - ay]
+                        const int prow = wave * 2 + i + 1 - ay;
                         const h8 xf = *(const h8*)(As + (prow * PW + lr + 1 - ax) * ROWB + kk * 32 + kh * 16);
-                        acc[i][ry * 2 + rx] = mfma32(wf, xf, acc[i][ry * 2 + rx]);
+#pragma unroll
+                        for (int ky = ay * 2; ky < (ay ? 3 : 2); ++ky)
+#pragma unroll
+                            for (int kx = ax * 2; kx < (ax ? 3 : 2); ++kx)
+                                acc[i][(ky & 1) * 2 + (kx & 1)] = mfma32(wf[ky & 1][kx & 1], xf, acc[i][(ky & 1) * 2 + (kx & 1)]);
                     }
                 }
             }
