@@ -446,33 +446,11 @@ static int finalize_discriminator(glass_engine* e) {
     return upload(e, &e->d_dense1_b, B1->data);
 }
 
-static int finalize_clip(glass_engine* e) {
-    const glass_config& c = e->cfg;
-    const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, E = c.clip_embed;
-    const std::string v = "clip.visual.";
-    GET(conv1, v + "conv1.weight");
-    GET(cls, v + "class_embedding");
-    GET(pos, v + "positional_embedding");
-    GET(lg, v + "ln_pre.weight");
-    GET(lb, v + "ln_pre.bias");
-    GET(pg, v + "ln_post.weight");
-    GET(pb, v + "ln_post.bias");
-    GET(proj, v + "proj");
-    REQUIRE(numel(conv1) == (size_t)W * 3 * ps * ps && numel(cls) == (size_t)W && numel(pos) == (size_t)T * W &&
-                numel(proj) == (size_t)W * E,
-            GLASS_ERR_ARG, "bad CLIP visual shapes");
-    int rc = upload(e, &e->c_patch_w, to_half(conv1->data.data(), numel(conv1)));
-    if (rc) return rc;
-    if ((rc = upload(e, &e->c_cls, cls->data))) return rc;
-    if ((rc = upload(e, &e->c_pos, pos->data))) return rc;
-    if ((rc = upload(e, &e->c_lnpre_g, lg->data))) return rc;
-    if ((rc = upload(e, &e->c_lnpre_b, lb->data))) return rc;
-    if ((rc = upload(e, &e->c_lnpost_g, pg->data))) return rc;
-    if ((rc = upload(e, &e->c_lnpost_b, pb->data))) return rc;
-    if ((rc = upload(e, &e->c_proj, proj->data))) return rc;  // already [K=W][N=E]
+static int load_clip_blocks(glass_engine* e, const char* prefix, int layers, int W, std::vector<ClipBlock>& out) {
     char nm[256];
-    for (int i = 0; i < c.clip_layers; ++i) {
-        snprintf(nm, sizeof nm, "clip.visual.transformer.resblocks.%d.", i);
+    int rc;
+    for (int i = 0; i < layers; ++i) {
+        snprintf(nm, sizeof nm, "%s%d.", prefix, i);
         const std::string p = nm;
         ClipBlock b;
         GET(l1g, p + "ln_1.weight");
@@ -502,7 +480,62 @@ static int finalize_clip(glass_engine* e) {
         if ((rc = upload(e, &b.b_out, bo->data))) return rc;
         if ((rc = upload(e, &b.b_fc, bf->data))) return rc;
         if ((rc = upload(e, &b.b_proj, bp->data))) return rc;
-        e->cblk.push_back(b);
+        out.push_back(b);
+    }
+    return GLASS_OK;
+}
+
+static int finalize_clip(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, E = c.clip_embed;
+    const std::string v = "clip.visual.";
+    GET(conv1, v + "conv1.weight");
+    GET(cls, v + "class_embedding");
+    GET(pos, v + "positional_embedding");
+    GET(lg, v + "ln_pre.weight");
+    GET(lb, v + "ln_pre.bias");
+    GET(pg, v + "ln_post.weight");
+    GET(pb, v + "ln_post.bias");
+    GET(proj, v + "proj");
+    REQUIRE(numel(conv1) == (size_t)W * 3 * ps * ps && numel(cls) == (size_t)W && numel(pos) == (size_t)T * W &&
+                numel(proj) == (size_t)W * E,
+            GLASS_ERR_ARG, "bad CLIP visual shapes");
+    int rc = upload(e, &e->c_patch_w, to_half(conv1->data.data(), numel(conv1)));
+    if (rc) return rc;
+    if ((rc = upload(e, &e->c_cls, cls->data))) return rc;
+    if ((rc = upload(e, &e->c_pos, pos->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpre_g, lg->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpre_b, lb->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpost_g, pg->data))) return rc;
+    if ((rc = upload(e, &e->c_lnpost_b, pb->data))) return rc;
+    if ((rc = upload(e, &e->c_proj, proj->data))) return rc;  // already [K=W][N=E]
+    int rc2 = load_clip_blocks(e, "clip.visual.transformer.resblocks.", c.clip_layers, W, e->cblk);
+    if (rc2) return rc2;
+    // ---- optional text tower (clip/model.py:277-290) ----
+    if (find(e, "clip.token_embedding.weight") != nullptr) {
+        GET(tok, "clip.token_embedding.weight");
+        GET(tpos, "clip.positional_embedding");
+        GET(fg, "clip.ln_final.weight");
+        GET(fb, "clip.ln_final.bias");
+        GET(tp, "clip.text_projection");
+        REQUIRE(tok->dims.size() == 2 && tpos->dims.size() == 2 && tpos->dims[1] == tok->dims[1], GLASS_ERR_ARG,
+                "bad CLIP text embedding shapes");
+        e->t_vocab = (int)tok->dims[0];
+        e->t_width = (int)tok->dims[1];
+        e->t_ctx = (int)tpos->dims[0];
+        REQUIRE(e->t_width % 64 == 0 && numel(tp) == (size_t)e->t_width * E, GLASS_ERR_ARG, "bad CLIP text projection shape");
+        int nl = 0;
+        char nm2[256];
+        for (;; ++nl) {
+            snprintf(nm2, sizeof nm2, "clip.transformer.resblocks.%d.ln_1.weight", nl);
+            if (!find(e, nm2)) break;
+        }
+        if ((rc = upload(e, &e->t_tok, tok->data))) return rc;
+        if ((rc = upload(e, &e->t_pos, tpos->data))) return rc;
+        if ((rc = upload(e, &e->t_lnf_g, fg->data))) return rc;
+        if ((rc = upload(e, &e->t_lnf_b, fb->data))) return rc;
+        if ((rc = upload(e, &e->t_proj, tp->data))) return rc;
+        if ((rc = load_clip_blocks(e, "clip.transformer.resblocks.", nl, e->t_width, e->tblk))) return rc;
     }
     return GLASS_OK;
 }
@@ -1083,6 +1116,78 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     if (out_F) memcpy(out_F, e->h_pinned, (size_t)P * c.n_obj * sizeof(float));
     e->last_P = P;
     if (e->profiling) collect_profile(e);
+    return GLASS_OK;
+}
+
+// CLIP text tower: token+pos embedding -> causal transformer -> ln_final -> EOT row @ text_projection
+extern "C" int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, int32_t n_texts, int32_t ctx, float* out_feat) {
+    REQUIRE(e && tokens && out_feat && n_texts > 0, GLASS_ERR_ARG, "null argument");
+    REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first");
+    REQUIRE(e->t_tok != nullptr, GLASS_ERR_STATE, "CLIP text tower weights were not loaded (clip.token_embedding.weight ...)");
+    REQUIRE(ctx == e->t_ctx && ctx <= 128, GLASS_ERR_ARG, "context length does not match positional_embedding");
+    GLASS_HIP(hipSetDevice(e->cfg.device));
+    const int W = e->t_width, heads = W / 64, M = n_texts * ctx, E = e->cfg.clip_embed;
+    std::vector<int> eot(n_texts);
+    for (int n = 0; n < n_texts; ++n) {       // text.argmax(dim=-1): EOT has the highest id (clip/model.py:318)
+        int best = 0;
+        for (int t = 0; t < ctx; ++t) {
+            const int v = tokens[(size_t)n * ctx + t];
+            REQUIRE(v >= 0 && v < e->t_vocab, GLASS_ERR_ARG, "token id out of range");
+            if (v > tokens[(size_t)n * ctx + best]) best = t;
+        }
+        eot[n] = best;
+    }
+    int* d_tok = nullptr;
+    float *x = nullptr, *cls = nullptr, *feat = nullptr;
+    half_t *ln16 = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    auto cleanup = [&]() {
+        hipFree(d_tok); hipFree(x); hipFree(cls); hipFree(feat); hipFree(ln16); hipFree(qkv); hipFree(att); hipFree(hid);
+    };
+    hipError_t err = hipMalloc(&d_tok, (size_t)M * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&x, (size_t)M * W * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&cls, (size_t)n_texts * W * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&feat, (size_t)n_texts * E * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&ln16, (size_t)M * W * sizeof(half_t));
+    if (err == hipSuccess) err = hipMalloc(&qkv, (size_t)M * 3 * W * sizeof(half_t));
+    if (err == hipSuccess) err = hipMalloc(&att, (size_t)M * W * sizeof(half_t));
+    if (err == hipSuccess) err = hipMalloc(&hid, (size_t)M * 4 * W * sizeof(half_t));
+    if (err != hipSuccess) {
+        cleanup();
+        glass_set_error(std::string("encode_text: hipMalloc failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_NOMEM;
+    }
+    hipStream_t st = e->stream;
+    hipMemcpyAsync(d_tok, tokens, (size_t)M * sizeof(int), hipMemcpyHostToDevice, st);
+    launch_embed_text(d_tok, e->t_tok, e->t_pos, M, ctx, W, x, st);
+    GemmParams g;
+    for (auto& b : e->tblk) {
+        launch_layernorm(x, W, M, W, b.ln1_g, b.ln1_b, ln16, nullptr, st);
+        memset(&g, 0, sizeof g);
+        g.a = ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = qkv; g.ldo = 3 * W;
+        if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+        launch_attention(qkv, n_texts, ctx, heads, 64, 1, att, st);
+        memset(&g, 0, sizeof g);
+        g.a = att; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = x; g.ldo = W;
+        if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+        launch_layernorm(x, W, M, W, b.ln2_g, b.ln2_b, ln16, nullptr, st);
+        memset(&g, 0, sizeof g);
+        g.a = ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = hid; g.ldo = 4 * W;
+        if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+        memset(&g, 0, sizeof g);
+        g.a = hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = x; g.ldo = W;
+        if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+    }
+    for (int n = 0; n < n_texts; ++n)   // ln_final on the EOT row of each text only (row-wise op)
+        launch_layernorm(x + ((size_t)n * ctx + eot[n]) * W, W, 1, W, e->t_lnf_g, e->t_lnf_b, nullptr, cls + (size_t)n * W, st);
+    launch_dense(cls, W, n_texts, W, e->t_proj, E, nullptr, feat, E, 0, 0, nullptr, 0, st);
+    err = hipMemcpyAsync(out_feat, feat, (size_t)n_texts * E * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipGetLastError();
+    cleanup();
+    if (err != hipSuccess) {
+        glass_set_error(std::string("encode_text failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_HIP;
+    }
     return GLASS_OK;
 }
 

@@ -97,6 +97,10 @@ struct glass_engine {
     float *c_cls = nullptr, *c_pos = nullptr, *c_lnpre_g = nullptr, *c_lnpre_b = nullptr;
     float *c_lnpost_g = nullptr, *c_lnpost_b = nullptr, *c_proj = nullptr;
     std::vector<ClipBlock> cblk;
+    // text tower (optional)
+    std::vector<ClipBlock> tblk;
+    float *t_tok = nullptr, *t_pos = nullptr, *t_lnf_g = nullptr, *t_lnf_b = nullptr, *t_proj = nullptr;
+    int t_width = 0, t_ctx = 0, t_vocab = 0;
     float* d_target = nullptr;
 
     // ---- activations / scratch ----

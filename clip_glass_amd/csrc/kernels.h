@@ -50,6 +50,9 @@ void launch_mbstd(const half_t* x, int B, int hw, int C, int Cpad, int batch_siz
 // --- CLIP --------------------------------------------------------------------------
 void launch_embed_lnpre(const float* patch_emb, const float* cls, const float* pos, const float* g,
                         const float* b, int P, int T, int D, float* x, hipStream_t st);
+// x[n*ctx + t][:] = tok_emb[tokens[n*ctx+t]][:] + pos[t][:]
+void launch_embed_text(const int* tokens, const float* tok_emb, const float* pos, int n_rows, int ctx, int D, float* x,
+                       hipStream_t st);
 void launch_layernorm(const float* x, long long row_stride, int M, int D, const float* g, const float* b,
                       half_t* out16, float* out32, hipStream_t st);
 void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,

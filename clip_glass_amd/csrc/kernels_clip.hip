@@ -46,6 +46,18 @@ void launch_embed_lnpre(const float* patch_emb, const float* cls, const float* p
                        T, D, x);
 }
 
+// token + positional embedding of the text tower (clip/model.py:308-310)
+__global__ void embed_text_kernel(const int* tokens, const float* tok_emb, const float* pos, int ctx, int D, float* x) {
+    const int row = blockIdx.x;
+    const float* te = tok_emb + (long long)tokens[row] * D;
+    const float* pe = pos + (long long)(row % ctx) * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) x[(long long)row * D + i] = te[i] + pe[i];
+}
+void launch_embed_text(const int* tokens, const float* tok_emb, const float* pos, int n_rows, int ctx, int D, float* x,
+                       hipStream_t st) {
+    hipLaunchKernelGGL(embed_text_kernel, dim3(n_rows), dim3(128), 0, st, tokens, tok_emb, pos, ctx, D, x);
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long long row_stride, int M, int D,
                                                         const float* g, const float* b, half_t* o16, float* o32) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);

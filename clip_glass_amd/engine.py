@@ -57,6 +57,7 @@ def load_library(path=None):
     lib.glass_engine_load_tensor.argtypes = [C.c_void_p, C.c_char_p, fp, C.c_int32, C.POINTER(C.c_int64)]
     lib.glass_engine_finalize.argtypes = [C.c_void_p]
     lib.glass_engine_set_target.argtypes = [C.c_void_p, fp, C.c_int32]
+    lib.glass_engine_encode_text.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, fp]
     lib.glass_engine_evaluate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_generate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
@@ -142,6 +143,14 @@ class Engine:
     def set_target(self, feat):
         f = _f32(feat).reshape(-1)
         _check(self.lib, self.lib.glass_engine_set_target(self._h, _fp(f), f.size))
+
+    def encode_text(self, tokens):
+        """CLIP.encode_text (clip/model.py:307-320): tokens int [n, ctx] -> float32 [n, clip_embed]."""
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.empty((t.shape[0], self.cfg.clip_embed), dtype=np.float32)
+        _check(self.lib, self.lib.glass_engine_encode_text(self._h, t.ctypes.data_as(C.POINTER(C.c_int32)), t.shape[0],
+                                                            t.shape[1], _fp(out)))
+        return out
 
     # --- the pass ------------------------------------------------------------
     def _noise_arg(self, noise):

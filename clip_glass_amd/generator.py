@@ -14,18 +14,24 @@ from .utils import save_grid, save_image
 CLIP_VIT_B32 = (768, 12, 12, 32, 224, 512)
 
 
-def _load_clip_state(config):
+def _load_clip_state(config, with_text):
     w = str(getattr(config, "clip_weights", "synthetic:0"))
     if w.startswith("synthetic"):
         seed = int(w.split(":")[1]) if ":" in w else 0
         geom = tuple(getattr(config, "clip_geometry", CLIP_VIT_B32))
-        return synth.make_state(synth.clip_visual_spec(geom[0], geom[1], geom[3], geom[4], geom[5]), seed), geom
+        state = synth.make_state(synth.clip_visual_spec(geom[0], geom[1], geom[3], geom[4], geom[5]), seed)
+        if with_text:
+            tg = getattr(config, "clip_text_geometry", dict(width=512, layers=12))
+            state.update(synth.make_state(synth.clip_text_spec(width=tg["width"], layers=tg["layers"], out_dim=geom[5]), seed))
+        return state, geom
     import torch   # reference: clip.load -> torch.jit.load(archive).state_dict() (clip/clip.py:64-78)
     try:
         sd = torch.jit.load(w, map_location="cpu").state_dict()
     except RuntimeError:
         sd = torch.load(w, map_location="cpu")
-    state = {"clip." + k: v.float().numpy() for k, v in sd.items() if k.startswith("visual.")}
+    state = {"clip." + k: v.float().numpy() for k, v in sd.items()
+             if k.startswith("visual.") or (with_text and not k.startswith("visual.") and v.dim() > 0
+                                            and k not in ("input_resolution", "context_length", "vocab_size"))}
     width = state["clip.visual.conv1.weight"].shape[0]
     patch = state["clip.visual.conv1.weight"].shape[-1]
     grid = round((state["clip.visual.positional_embedding"].shape[0] - 1) ** 0.5)
@@ -40,7 +46,8 @@ class Generator:
         if config.task != "txt2img":
             raise NotImplementedError("img2txt (GPT2) is a later row of SURVEY §8")
         self.model = config.model(config)                                   # generator.py:19
-        clip_state, geom = _load_clip_state(config)
+        need_text = getattr(config, "target_features", None) is None
+        clip_state, geom = _load_clip_state(config, need_text)
         pop = int(getattr(config, "max_pop", max(config.pop_size, config.batch_size)))
         pop = (pop + config.batch_size - 1) // config.batch_size * config.batch_size
         device = getattr(config, "device", 0)
@@ -57,10 +64,11 @@ class Generator:
         self.generation = 0
         if getattr(config, "target_features", None) is not None:            # pre-computed text feature
             self.text_features = np.asarray(config.target_features, np.float32).reshape(1, -1)
-        else:
-            raise NotImplementedError(
-                "text target strings need the CLIP text tower + BPE tokenizer (SURVEY §8(f) rank 4, not built "
-                "yet): pass config.target_features = CLIP.encode_text(tokenize([target]))[0] (generator.py:23-24)")
+        else:                                                               # generator.py:23-24
+            from .tokenizer import DEFAULT_BPE, ClipTokenizer
+            tok = ClipTokenizer(getattr(config, "bpe_path", DEFAULT_BPE))
+            self.tokens = tok.tokenize([self.config.target])
+            self.text_features = self.engine.encode_text(self.tokens)
         self.engine.set_target(self.text_features[0])
 
     # --- the hot path: generate + clip_similarity + discriminate in ONE device pass -------------

@@ -82,6 +82,13 @@ int glass_engine_finalize(glass_engine* e);
 /* Target text feature, host float32 [clip_embed] (generator.py:23-24: encode_text once). */
 int glass_engine_set_target(glass_engine* e, const float* feat, int32_t n);
 
+/* CLIP text tower (clip/model.py:307-320), run once at init by the reference (generator.py:23-24).
+ * Available when the text-tower tensors ("clip.token_embedding.weight", "clip.positional_embedding",
+ * "clip.transformer.resblocks.*", "clip.ln_final.*", "clip.text_projection") were loaded before
+ * finalize().  tokens: host int32 [n_texts, ctx] as produced by clip.tokenize (clip/clip.py:125-138);
+ * out_feat: host float32 [n_texts, clip_embed]. */
+int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, int32_t n_texts, int32_t ctx, float* out_feat);
+
 /* THE HOT PATH — replaces GenerationProblem._evaluate (problem.py:14-29).
  * latents: host float32 [P, latent_size] row-major (latent.py:37-38);
  * generation: index folded into the device noise stream (noise_mode 1);

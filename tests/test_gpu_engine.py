@@ -143,3 +143,43 @@ def test_generation_problem_drop_in():
     prob.generator.save(img, p)
     assert os.path.getsize(p) > 0
     prob.generator.engine.close()
+
+
+def test_text_tower_matches_oracle_and_golden_tokens():
+    """glass_engine_encode_text vs the oracle's CLIP.encode_text restatement (clip/model.py:307-320) on the
+    token ids the reference tokenizer produced for the default target (tests/golden/mini_problem.npz)."""
+    import os
+    from oracle import clip_ref
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mini_problem.npz")))
+    tokens = np.stack([g["tokens"], np.r_[g["tokens"][:5], 49407, np.zeros(71, np.int64)]]).astype(np.int64)
+    sd = M.make_state("mini", 0)
+    sd.update(synth.make_state(synth.clip_text_spec(width=64, layers=2, out_dim=M.CONFIGS["mini"]["clip"][5]), 0))
+    e = M.make_engine("mini", sd, max_pop=8, noise_mode=0)
+    got = e.encode_text(tokens)
+    e.close()
+    ref = clip_ref.encode_text(_t(sd), torch.tensor(tokens)).numpy()
+    check("text tower (mini)", got, ref, 3e-3)
+    # the golden's text_features came from the REFERENCE's encode_text on the same weights / tokens
+    check("text tower vs reference golden", got[0], g["text_features"], 3e-3)
+
+
+def test_run_cli_end_to_end(tmp_path):
+    """`python -m clip_glass_amd.run` mirror of run.py: a few NSGA-II generations on the mini architecture with a
+    TEXT target (tokenizer + device text tower), periodic image dumps, result pickle, final output."""
+    import os, pickle
+    bpe = "/root/reference/assets/bpe_simple_vocab_16e6.txt.gz"
+    from clip_glass_amd import run
+    c = M.CONFIGS["mini"]
+    extra = dict(channels=c["channels"], dim_z=c["latent"], mapping_layers=c["mapping"], clip_geometry=c["clip"],
+                 clip_text_geometry=dict(width=64, layers=2), problem_args=dict(n_var=c["latent"], n_obj=2, n_constr=c["latent"], xl=-10, xu=10))
+    if not os.path.exists(bpe):   # no vocab on the GPU box: use the text feature the reference produced (golden)
+        g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "mini_problem.npz")))
+        extra["target_features"] = g["text_features"]
+    argv = ["--config", "StyleGAN2_ffhq_d", "--generations", "3", "--save-each", "2", "--tmp-folder", str(tmp_path),
+            "--weights", "synthetic:0", "--clip-weights", "synthetic:0", "--pop-size", "8", "--bpe-path", bpe]
+    res = run.main(argv, extra_config=extra)
+    assert np.atleast_2d(res.F).shape[1] == 2
+    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result.npz", "output.jpg"):
+        assert os.path.getsize(os.path.join(str(tmp_path), f)) > 0, f
+    d = pickle.load(open(os.path.join(str(tmp_path), "genetic_result"), "rb"))
+    assert set(d) == {"X", "F", "G", "CV"}

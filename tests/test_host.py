@@ -205,3 +205,28 @@ def test_population_sharding_two_process_gloo():
         x5 = synth.latents(1, 20, 8).astype(np.float32)
         np.testing.assert_allclose(Fr[:, 1], x5[:, 1], rtol=1e-6)
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_clip_tokenizer_matches_reference_known_answers():
+    """Own BPE implementation vs the reference tokenizer (needs the reference's merges asset)."""
+    bpe = "/root/reference/assets/bpe_simple_vocab_16e6.txt.gz"
+    if not os.path.exists(bpe):
+        pytest.skip("reference BPE asset not present")
+    from clip_glass_amd.tokenizer import ClipTokenizer
+    tok = ClipTokenizer(bpe)
+    ids = tok.tokenize(["a wolf at night with the moon in the background"])
+    assert ids.shape == (1, 77) and ids.dtype == np.int64
+    assert ids[0, :12].tolist() == [49406, 320, 5916, 536, 930, 593, 518, 3293, 530, 518, 5994, 49407]   # SURVEY §4
+    assert not ids[0, 12:].any()
+    try:
+        import ref_harness as rh
+        ref_tok = rh.load_reference()["clip_clip"].tokenize
+    except Exception:
+        ref_tok = None
+    texts = ["A photo of  a CAT!!", "it's 42 degrees & sunny -- don't you think?", "naïve café façade", "x" * 10,
+             "the quick brown fox jumps over the lazy dog, twice.", "&amp; html &lt;escapes&gt;"]
+    mine = tok.tokenize(texts)
+    if ref_tok is not None:
+        np.testing.assert_array_equal(mine, ref_tok(texts).numpy())
+    with pytest.raises(RuntimeError, match="too long"):
+        tok.tokenize(["word " * 100])
