@@ -15,13 +15,16 @@
 // Block = one 32 x (32*NW) output tile; the K loop (taps x 16-channel steps) is split
 // round-robin over the 4 waves (split-K, summed through LDS) and software-pipelined one
 // step ahead, so the small-M layers are no longer a single wave chasing load latency.
-template <int NW>
+// SPLITK = true : block = one 32-row tile, K split over the 4 waves (small M: more parallelism)
+// SPLITK = false: block = 128 rows, wave w owns rows 32w..32w+31 over the full K (large M: the
+//                 4 waves read the same weight fragments -> L1 hits instead of 4x the L2 traffic)
+template <int NW, bool SPLITK>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
-    __shared__ float red[3][NW][16][64];
+    __shared__ float red[SPLITK ? 3 : 1][SPLITK ? NW : 1][16][SPLITK ? 64 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const long long M = (long long)p.B * p.Hc * p.Wc;
-    const long long mw = (long long)blockIdx.x * 32;  // first GEMM row of this block
+    const long long mw = SPLITK ? (long long)blockIdx.x * 32 : (long long)blockIdx.x * 128 + wave * 32;  // first GEMM row of this wave
     const int n0 = blockIdx.y * (32 * NW);
     const long long m = mw + r;
     const bool mvalid = m < M;
@@ -81,17 +84,19 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
         for (int nw = 0; nw < NW; ++nw) acc[nw] = mfma32(a, f.bf[nw], acc[nw]);
     };
     Frag f0, f1;
-    int s = wave;
+    constexpr int KS_ = SPLITK ? 4 : 1;   // K-step stride between this wave's steps
+    int s = SPLITK ? wave : 0;
     if (s < total) load(s, f0);
-    for (; s < total; s += 8) {          // two steps per iteration: static register double buffer
-        if (s + 4 < total) load(s + 4, f1);
+    for (; s < total; s += 2 * KS_) {     // two steps per iteration: static register double buffer
+        if (s + KS_ < total) load(s + KS_, f1);
         compute(f0);
-        if (s + 4 < total) {
-            if (s + 8 < total) load(s + 8, f0);
+        if (s + KS_ < total) {
+            if (s + 2 * KS_ < total) load(s + 2 * KS_, f0);
             compute(f1);
         }
     }
     // ---- split-K reduction: waves 1..3 -> LDS -> wave 0 --------------------------------------
+    if (SPLITK) {
     if (wave > 0) {
 #pragma unroll
         for (int nw = 0; nw < NW; ++nw)
@@ -105,6 +110,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
             acc[nw][reg] += red[0][nw][reg][lane] + red[1][nw][reg][lane] + red[2][nw][reg][lane];
+    }
 
     // ---- epilogue: demod, noise, bias, activation, residual, store -------------
     const int col = lane & 31;
@@ -141,17 +147,22 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
     if (p.w_bstride != 0) abort();  // per-sample weights are a tiled/upfir-only path (engine guarantees it)
     const long long M = (long long)p.B * p.Hc * p.Wc;
+    if (p.Neff > 64 && ((M + 127) / 128) * ((p.Neff + 127) / 128) >= 256) {   // enough 128 x 128 blocks to fill the chip: row-parallel
+        hipLaunchKernelGGL((conv_direct_kernel<4, false>), dim3((unsigned)((M + 127) / 128), (p.Neff + 127) / 128), dim3(256), 0,
+                           st, p);
+        return "conv_direct_kernel<4,rows>";
+    }
     const unsigned gx = (unsigned)((M + 31) / 32);
     // wide n tiles re-use the activation fragment; narrow ones give small problems more blocks
     if (p.Neff > 64 && (long long)gx * ((p.Neff + 127) / 128) >= 512) {
-        hipLaunchKernelGGL(conv_direct_kernel<4>, dim3(gx, (p.Neff + 127) / 128), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_direct_kernel<4, true>), dim3(gx, (p.Neff + 127) / 128), dim3(256), 0, st, p);
         return "conv_direct_kernel<4>";
     }
     if (p.Neff > 32) {
-        hipLaunchKernelGGL(conv_direct_kernel<2>, dim3(gx, (p.Neff + 63) / 64), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((conv_direct_kernel<2, true>), dim3(gx, (p.Neff + 63) / 64), dim3(256), 0, st, p);
         return "conv_direct_kernel<2>";
     }
-    hipLaunchKernelGGL(conv_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_direct_kernel<1, true>), dim3(gx, 1), dim3(256), 0, st, p);
     return "conv_direct_kernel<1>";
 }
 
