@@ -616,6 +616,19 @@ static int alloc_buffers(glass_engine* e) {
         if ((rc = dev_alloc(e, &e->d_dfin, (size_t)P * 16 * c.channels[0]))) return rc;
         if ((rc = dev_alloc(e, &e->d_dh, (size_t)P * c.channels[0]))) return rc;
     }
+    {   // descriptor table of the demodulation problems (one launch for all layers)
+        std::vector<DenseDesc> dd;
+        for (auto& g : e->gconv) {
+            DenseDesc q;
+            q.x = e->d_s + g.style_off; q.ldx = e->S_total; q.K = g.cin; q.wt = g.wsq; q.N = g.cout; q.bias = nullptr;
+            q.out = e->d_dscale + g.ds_off; q.ldo = e->D_total; q.eps_row = e->d_epsrow + g.style_idx; q.eps_stride = e->n_style;
+            dd.push_back(q);
+            e->demod_max_n = std::max(e->demod_max_n, g.cout);
+        }
+        DenseDesc* dptr = nullptr;
+        if ((rc = upload(e, &dptr, dd))) return rc;
+        e->d_demod_desc = dptr;
+    }
     GLASS_HIP(hipMemset(e->d_dis, 0, (size_t)P * sizeof(float)));
     e->h_pinned_bytes = std::max((size_t)P * L, (size_t)P * (c.clip_embed + 8)) * sizeof(float);
     GLASS_HIP(hipHostMalloc((void**)&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
@@ -784,9 +797,7 @@ static void run_styles(glass_engine* e, int P) {
     }
     {
         Prof pr(e, "demod", 0, 0);
-        for (auto& g : e->gconv)
-            launch_dense(e->d_s + g.style_off, e->S_total, P, g.cin, g.wsq, g.cout, nullptr, e->d_dscale + g.ds_off,
-                         e->D_total, 1, 2, e->d_epsrow + g.style_idx, e->n_style, e->cur);
+        launch_dense_multi((const DenseDesc*)e->d_demod_desc, (int)e->gconv.size(), e->demod_max_n, P, 1, 2, e->cur);
     }
     {
         Prof pr(e, "premod_weights", 0, 0);

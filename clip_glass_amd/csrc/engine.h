@@ -82,6 +82,8 @@ struct glass_engine {
     int *d_style_off = nullptr, *d_style_len = nullptr;
     std::vector<int> style_off, style_len;
     half_t* g_const = nullptr;  // [4][4][C0]
+    void* d_demod_desc = nullptr;  // DenseDesc[gconv.size()] for the single-launch demodulation
+    int demod_max_n = 0;
     std::vector<GConv> gconv;
     std::vector<GRgb> grgb;
     // ---- D ----

@@ -18,6 +18,11 @@ void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipSt
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
                   hipStream_t st);
+struct DenseDesc {
+    const float* x; int ldx; int K; const float* wt; int N; const float* bias; float* out; int ldo;
+    const float* eps_row; int eps_stride;
+};
+void launch_dense_multi(const DenseDesc* d_desc, int n_desc, int max_N, int P, int in_sq, int mode, hipStream_t st);
 // per (p, layer): smax = max|s|, s /= smax, eps_row = eps / smax^2
 void launch_style_norm(float* s, int ld, int P, int n_layers, const int* d_off, const int* d_len,
                        float* smax, float* eps_row, float eps, hipStream_t st);

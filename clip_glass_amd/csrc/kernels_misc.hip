@@ -33,14 +33,14 @@ void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipSt
 // the 26 style affines (one launch), demodulation coefficients, CLIP proj, D dense1.
 #define DENSE_PB 16
 #define DENSE_KT 128
-__global__ __launch_bounds__(256) void dense_kernel(const float* x, int ldx, int P, int K, const float* wt,
-                                                    int N, const float* bias, float* out, int ldo, int in_sq,
-                                                    int mode, const float* eps_row, int eps_stride) {
+__device__ __forceinline__ void dense_body(const float* x, int ldx, int P, int K, const float* wt, int N,
+                                           const float* bias, float* out, int ldo, int in_sq, int mode,
+                                           const float* eps_row, int eps_stride, int bx, int by) {
     __shared__ float xs[DENSE_PB][DENSE_KT];
     const int t = threadIdx.x;
-    const int n = blockIdx.x * 64 + (t & 63);
+    const int n = bx * 64 + (t & 63);
     const int pg = t >> 6;
-    const int p0 = blockIdx.y * DENSE_PB;
+    const int p0 = by * DENSE_PB;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < K; k0 += DENSE_KT) {
         for (int e = t; e < DENSE_PB * DENSE_KT; e += 256) {
@@ -70,6 +70,22 @@ __global__ __launch_bounds__(256) void dense_kernel(const float* x, int ldx, int
         else if (mode == 2) v = rsqrtf(v + eps_row[(long long)p * eps_stride]);
         out[(long long)p * ldo + n] = v;
     }
+}
+__global__ __launch_bounds__(256) void dense_kernel(const float* x, int ldx, int P, int K, const float* wt,
+                                                    int N, const float* bias, float* out, int ldo, int in_sq,
+                                                    int mode, const float* eps_row, int eps_stride) {
+    dense_body(x, ldx, P, K, wt, N, bias, out, ldo, in_sq, mode, eps_row, eps_stride, blockIdx.x, blockIdx.y);
+}
+// many independent small problems in ONE launch (blockIdx.z = problem): the 17 demodulation tables
+__global__ __launch_bounds__(256) void dense_multi_kernel(const DenseDesc* d, int P, int in_sq, int mode) {
+    const DenseDesc q = d[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= q.N) return;
+    dense_body(q.x, q.ldx, P, q.K, q.wt, q.N, q.bias, q.out, q.ldo, in_sq, mode, q.eps_row, q.eps_stride, blockIdx.x,
+               blockIdx.y);
+}
+void launch_dense_multi(const DenseDesc* d_desc, int n_desc, int max_N, int P, int in_sq, int mode, hipStream_t st) {
+    dim3 g((max_N + 63) / 64, (P + DENSE_PB - 1) / DENSE_PB, n_desc);
+    hipLaunchKernelGGL(dense_multi_kernel, g, dim3(256), 0, st, d_desc, P, in_sq, mode);
 }
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
