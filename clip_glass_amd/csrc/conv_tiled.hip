@@ -22,7 +22,10 @@
 
 #define ROWB 80  // bytes per LDS row (32 halfs + 8 pad)
 
-template <int KS, int S, int TH, int NT>
+// PERSIST: the block walks several work items and prefetches the first stage of the next tile during
+// the last MFMA block + store epilogue of the current one (memory-bound small-K layers); otherwise
+// one work item per block (MFMA-bound layers: fewer live registers).
+template <int KS, int S, int TH, int NT, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = TH / 4;                 // tile rows per wave
     constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
@@ -38,35 +41,51 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     char* As = smem;
     char* Bs = smem + A_BYTES;
 
-    // ---- block -> (pixel tile, n tile); blocks sharing a pixel tile share an XCD (id % 8) ----
-    const int id = blockIdx.x;
-    const int lo = id & 7, rest = id >> 3;
-    const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
-    if (pt >= PT) return;
-    const int tpi = tiles_x * tiles_y;
-    const int b = pt / tpi;
-    const int trem = pt - b * tpi;
-    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
-    const int n0 = nt * NT;
-
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, kh = lane >> 5;
     const int part = t & 3;
+    const int tpi = tiles_x * tiles_y;
+    const int PT8 = (PT + 7) & ~7;
+    const int n_work = PT8 * NTn;              // work items = (pixel tile, n tile)
 
-    // ---- per-thread staging descriptors (independent of the channel chunk) -------------------
+    // ---- persistent block: work items id, id + gridDim.x, ...  An item decodes to (pixel tile, n tile)
+    // such that the n-tiles of one pixel tile sit on one XCD (id % 8) and share its L2. -------------
+    struct Tile { int b, ty0, tx0, n0; bool valid; };
+    auto decode = [&](int id) {
+        Tile w;
+        const int lo = id & 7, rest = id >> 3;
+        const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
+        w.valid = id < n_work && pt < PT;
+        const int ptc = w.valid ? pt : 0;
+        w.b = ptc / tpi;
+        const int trem = ptc - w.b * tpi;
+        w.ty0 = (trem / tiles_x) * TH;
+        w.tx0 = (trem % tiles_x) * 32;
+        w.n0 = nt * NT;
+        return w;
+    };
+
+    // staging state of the tile being LOADED (may be one tile ahead of the tile being computed)
     int a_goff[NA];   // element offset into the image (without chunk offset), -1 = zero fill
+    const half_t* xb = p.x;
+    const half_t* wb = p.w;
+    const float* snb = nullptr;
+    int ld_n0 = 0;
+    auto aim = [&](const Tile& w) {
 #pragma unroll
-    for (int k = 0; k < NA; ++k) {
-        const int v = t + 256 * k;
-        const int pix = v >> 2;
-        const int pr = pix / PW, pc = pix - pr * PW;
-        const int iy = ty0 * S - p.pad + pr, ix = tx0 * S - p.pad + pc;
-        const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
-    }
-    const half_t* xb = p.x + (long long)b * p.x_bstride;
-    const half_t* wb = p.w + (long long)b * p.w_bstride;
-    const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
+        for (int k = 0; k < NA; ++k) {
+            const int v = t + 256 * k;
+            const int pix = v >> 2;
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int iy = w.ty0 * S - p.pad + pr, ix = w.tx0 * S - p.pad + pc;
+            const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
+        }
+        xb = p.x + (long long)w.b * p.x_bstride;
+        wb = p.w + (long long)w.b * p.w_bstride;
+        snb = p.sn ? p.sn + (long long)w.b * p.sn_stride + part * 8 : nullptr;
+        ld_n0 = w.n0;
+    };
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
@@ -93,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             if (NVB % 256 == 0 || u < NVB) {
                 const int tx = u / (NT * 4);
                 const int n = (u >> 2) % NT;
-                rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + n0 + n) * p.Cin + c0 + part * 8);
+                rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
             }
         }
     };
@@ -103,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const int v = t + 256 * k;
             if (NVA % 256 == 0 || v < NVA) {
                 h8 a = ra[k];
-                if (snb) a = a * sh;   // 4 x v_pk_mul_f16
+                if (p.sn) a = a * sh;   // 4 x v_pk_mul_f16
                 *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
             }
         }
@@ -116,107 +135,130 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         }
     };
 
-    f16x acc[RW][NJ];
-#pragma unroll
-    for (int i = 0; i < RW; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-
     const int n_chunks = p.Cin >> 5;
     const int n_stages = n_chunks * KS;
+
+    int id = blockIdx.x;
+    Tile cur = decode(id);
+    while (id < n_work && !cur.valid) { id += gridDim.x; cur = decode(id); }   // skip padding items
+    if (id >= n_work) return;
+    aim(cur);
     load_a(0);
     load_b(0, 0);
-    int c = 0, ty = 0;
-    for (int s = 0; s < n_stages; ++s) {
-        if (s > 0) __syncthreads();  // previous stage's fragment reads are done
-        if (ty == 0) store_a();
-        store_b();
-        __syncthreads();
-        int nc = c, nty = ty + 1;
-        if (nty == KS) { nty = 0; nc = c + 1; }
-        if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
-            if (nty == 0) load_a(nc * 32);
-            load_b(nc * 32, nty);
-        }
-        // ---- MFMA block: KS taps x 2 k16 steps x RW x NJ --------------------------------
-#pragma unroll
-        for (int tx = 0; tx < KS; ++tx) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                h8 wf[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    wf[j] = *(const h8*)(Bs + (tx * NT + j * 32 + lr) * ROWB + kk * 32 + kh * 16);
-#pragma unroll
-                for (int i = 0; i < RW; ++i) {
-                    const int prow = (wave * RW + i) * S + ty;
-                    const h8 xf = *(const h8*)(As + (prow * PW + lr * S + tx) * ROWB + kk * 32 + kh * 16);
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
-                }
-            }
-        }
-        c = nc;
-        ty = nty;
-    }
 
-    // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ----
+    for (;;) {
+        // next valid work item of this block (uniform across the block)
+        int nid = id + gridDim.x;
+        Tile nxt = decode(nid);
+        while (nid < n_work && !nxt.valid) { nid += gridDim.x; nxt = decode(nid); }
+        const bool has_next = PERSIST && nid < n_work;
+
+        f16x acc[RW][NJ];
 #pragma unroll
-    for (int i = 0; i < RW; ++i) {
-        const int oy = ty0 + wave * RW + i, ox = tx0 + lr;
+        for (int i = 0; i < RW; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + j * 32 + 8 * g + 4 * kh;  // first of 4 consecutive n
-                int o = nb, py = oy, px = ox;
-                if (p.up) {
-                    const int ph = nb / p.Cout;
-                    o = nb - ph * p.Cout;
-                    py = 2 * oy + (ph >> 1);
-                    px = 2 * ox + (ph & 1);
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+        int c = 0, ty = 0;
+        for (int s = 0; s < n_stages; ++s) {
+            __syncthreads();  // previous stage's (or previous tile's) fragment reads are done
+            if (ty == 0) store_a();
+            store_b();
+            __syncthreads();
+            int nc = c, nty = ty + 1;
+            if (nty == KS) { nty = 0; nc = c + 1; }
+            if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
+                if (nty == 0) load_a(nc * 32);
+                load_b(nc * 32, nty);
+            } else if (has_next) {   // last stage: prefetch stage 0 of the NEXT tile; it stays in flight
+                aim(nxt);            // through this tile's MFMA block and store epilogue
+                load_a(0);
+                load_b(0, 0);
+            }
+            // ---- MFMA block: KS taps x 2 k16 steps x RW x NJ --------------------------------
+#pragma unroll
+            for (int tx = 0; tx < KS; ++tx) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    h8 wf[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        wf[j] = *(const h8*)(Bs + (tx * NT + j * 32 + lr) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        const int prow = (wave * RW + i) * S + ty;
+                        const h8 xf = *(const h8*)(As + (prow * PW + lr * S + tx) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                    }
                 }
-                float v[4];
+            }
+            c = nc;
+            ty = nty;
+        }
+
+        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ----
+        const int b = cur.b;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
-                if (p.dscale) {
-                    const f4 d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + o);
+        for (int i = 0; i < RW; ++i) {
+            const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] *= d[q];
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = cur.n0 + j * 32 + 8 * g + 4 * kh;  // first of 4 consecutive n
+                    int o = nb, py = oy, px = ox;
+                    if (p.up) {
+                        const int ph = nb / p.Cout;
+                        o = nb - ph * p.Cout;
+                        py = 2 * oy + (ph >> 1);
+                        px = 2 * ox + (ph & 1);
+                    }
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                    if (p.dscale) {
+                        const f4 d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + o);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] *= d[q];
+                    }
+                    if (p.noise) {
+                        const float nz = p.noise_strength *
+                                         p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += nz;
+                    }
+                    if (p.bias) {
+                        const f4 bb = *(const f4*)(p.bias + o);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += bb[q];
+                    }
+                    if (p.act) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                    }
+                    const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
+                    if (p.res) {
+                        const h4 r = *(const h4*)(p.res + oidx);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
+                    }
+                    h4 out;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                    *(h4*)(p.y + oidx) = out;
                 }
-                if (p.noise) {
-                    const float nz = p.noise_strength *
-                                     p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += nz;
-                }
-                if (p.bias) {
-                    const f4 bb = *(const f4*)(p.bias + o);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += bb[q];
-                }
-                if (p.act) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
-                }
-                const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
-                if (p.res) {
-                    const h4 r = *(const h4*)(p.res + oidx);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
-                }
-                h4 out;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
-                *(h4*)(p.y + oidx) = out;
             }
         }
+        if (!has_next) break;
+        id = nid;
+        cur = nxt;
     }
 }
 
-template <int KS, int S, int TH, int NT>
+template <int KS, int S, int TH, int NT, bool PERSIST = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
@@ -224,7 +266,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT>,
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
@@ -232,8 +274,24 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT>), dim3(PT8 * NTn), dim3(256), LDS, st, p, NTn, tiles_x,
-                       tiles_y, PT);
+    // persistent grid: as many workgroups as are resident at once (256 CUs x blocks/CU), a multiple of 8
+    // so a block keeps its XCD; each block walks its work items with cross-tile prefetch
+    static int resident = 0;
+    if (!resident) {
+        int per_cu = 1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST>, 256, LDS);
+        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        resident = prop.multiProcessorCount * per_cu;
+        resident -= resident % 8;
+        if (!PERSIST) resident = 1 << 30;
+    }
+    const int n_work = PT8 * NTn;
+    const int grid = n_work < resident ? n_work : resident;
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -247,9 +305,12 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
         static const int th4 = getenv("GLASS_TH4") ? atoi(getenv("GLASS_TH4")) : 0;   // experiment knob
         if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
         if ((th4 & 2) && p.Neff % 64 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 64>(p, st, "conv_tiled_kernel<3,1,4,64>");
+        static const bool persist = getenv("GLASS_PERSIST") != nullptr;   // measured slower (more live registers -> lower occupancy): off
+        if (persist && p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64, true>(p, st, "conv_tiled_kernel<3,1,8,64,persist>");
         if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64>(p, st, "conv_tiled_kernel<3,1,8,64>");
         // memory-bound, tiny K: small tiles = more workgroups per CU = more bytes in flight
         if ((th4 & 1) && p.Neff % 32 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 32>(p, st, "conv_tiled_kernel<3,1,4,32>");
+        if (persist && p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32, true>(p, st, "conv_tiled_kernel<3,1,8,32,persist>");
         if (p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32>(p, st, "conv_tiled_kernel<3,1,8,32>");
         return nullptr;
     }
