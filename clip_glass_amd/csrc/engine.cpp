@@ -173,7 +173,9 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
         return GLASS_ERR_ARG;
     }
     e->chunk = chunk;
-    e->overlap = getenv("GLASS_NO_OVERLAP") == nullptr;
+    // two-stream overlap is worth +3 % throughput but stretches every co-running kernel ~2x, which makes
+    // per-kernel profiles (rocprof, roofline) meaningless: opt-in (GLASS_OVERLAP=1 / glass_engine_set_overlap)
+    e->overlap = getenv("GLASS_OVERLAP") != nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream_d, hipStreamNonBlocking);
     e->cur = e->stream;
@@ -1234,6 +1236,12 @@ extern "C" int glass_engine_last_gpu_ms(glass_engine* e, float* ms) {
 extern "C" int glass_engine_set_profiling(glass_engine* e, int32_t on) {
     REQUIRE(e, GLASS_ERR_ARG, "null engine");
     e->profiling = on != 0;
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_set_overlap(glass_engine* e, int32_t on) {
+    REQUIRE(e, GLASS_ERR_ARG, "null engine");
+    e->overlap = on != 0;
     return GLASS_OK;
 }
 

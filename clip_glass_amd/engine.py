@@ -63,6 +63,7 @@ def load_library(path=None):
     lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
     lib.glass_engine_last_gpu_ms.argtypes = [C.c_void_p, fp]
     lib.glass_engine_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.glass_engine_set_overlap.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
     lib.glass_engine_get_profile.argtypes = [C.c_void_p, C.POINTER(ProfRow), C.c_int32, C.POINTER(C.c_int32)]
     lib.glass_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
@@ -198,6 +199,9 @@ class Engine:
 
     def set_profiling(self, on):
         _check(self.lib, self.lib.glass_engine_set_profiling(self._h, int(on)))
+
+    def set_overlap(self, on):
+        _check(self.lib, self.lib.glass_engine_set_overlap(self._h, int(on)))
 
     def set_profile_filter(self, kernel_substr):
         _check(self.lib, self.lib.glass_engine_set_profile_filter(self._h, (kernel_substr or "").encode()))

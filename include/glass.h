@@ -128,6 +128,11 @@ int glass_engine_set_profiling(glass_engine* e, int32_t on);
 int glass_engine_set_profile_filter(glass_engine* e, const char* kernel_substr);
 int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_rows, int32_t* n_rows);
 
+/* Two-stream overlap (synthesis of chunk k+1 || resize + D of chunk k) on/off; default off
+ * (GLASS_OVERLAP=1 turns it on at creation).  Results are identical either way; it buys ~3 %
+ * throughput and stretches co-running kernels, so per-kernel profiles are only clean with it off. */
+int glass_engine_set_overlap(glass_engine* e, int32_t on);
+
 /* Device info for bench.py (CU count, name, HBM bytes). */
 int glass_device_info(int32_t device, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes);
 
