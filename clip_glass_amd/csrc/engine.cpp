@@ -141,7 +141,7 @@ static std::vector<float> transposed(const float* W, int N, int K, float coef) {
 // ------------------------------------------------------------------------------------
 extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) {
     REQUIRE(cfg && out, GLASS_ERR_ARG, "null argument");
-    REQUIRE(cfg->n_blocks >= 1 && cfg->n_blocks <= GLASS_MAX_BLOCKS, GLASS_ERR_ARG, "n_blocks out of range");
+    REQUIRE(cfg->n_blocks >= 0 && cfg->n_blocks <= GLASS_MAX_BLOCKS, GLASS_ERR_ARG, "n_blocks out of range");
     for (int i = 0; i < cfg->n_blocks; ++i)
         REQUIRE(cfg->channels[i] > 0 && cfg->channels[i] % 16 == 0, GLASS_ERR_ARG,
                 "channels must be positive multiples of 16");
@@ -164,7 +164,7 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     GLASS_HIP(hipSetDevice(cfg->device));
     glass_engine* e = new glass_engine();
     e->cfg = *cfg;
-    e->R = 4 << (cfg->n_blocks - 1);
+    e->R = cfg->n_blocks > 0 ? 4 << (cfg->n_blocks - 1) : 0;
     int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (16 / cfg->batch_size) * cfg->batch_size);
     chunk = std::min(chunk, cfg->max_pop);
     if (chunk % cfg->batch_size != 0) {
@@ -576,15 +576,15 @@ static int alloc_buffers(glass_engine* e) {
         if (b > 0) ch = std::max<size_t>(ch, c.channels[b - 1]);
         maxact = std::max(maxact, (res + 1) * (res + 1) * ch);
     }
-    maxact = std::max(maxact, (size_t)16 * (c.channels[0] + 16));
+    if (c.n_blocks > 0) maxact = std::max(maxact, (size_t)16 * (c.channels[0] + 16));
     e->act_elems = maxact * CH;
-    for (int i = 0; i < 8; ++i)   // [0..5]: D scratch (D stream), [6..7]: G ping-pong (main stream)
+    for (int i = 0; i < 8 && c.n_blocks > 0; ++i)   // [0..5]: D scratch (D stream), [6..7]: G ping-pong (main stream)
         if (i >= 6 || c.use_discriminator)
             if ((rc = dev_alloc(e, &e->act[i], e->act_elems))) return rc;
     for (int i = 0; i < 4; ++i)     // two sets (chunk parity) of skip-image ping-pong
         if ((rc = dev_alloc(e, &e->ybuf[i], (size_t)CH * 3 * e->R * e->R))) return rc;
     // whole-population buffers for the low-resolution phases (res <= low_res)
-    {
+    if (c.n_blocks > 0) {
         e->n_low = 0;
         while (e->n_low < c.n_blocks && (4 << e->n_low) <= e->low_res) ++e->n_low;
         if (e->n_low < 1) e->n_low = 1;
@@ -614,7 +614,7 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_dis, (size_t)P))) return rc;
     if ((rc = dev_alloc(e, &e->d_F, (size_t)P * 2))) return rc;
     if ((rc = dev_alloc(e, &e->d_target, (size_t)c.clip_embed))) return rc;
-    if (c.use_discriminator) {
+    if (c.use_discriminator && c.n_blocks > 0) {
         if ((rc = dev_alloc(e, &e->d_dfin, (size_t)P * 16 * c.channels[0]))) return rc;
         if ((rc = dev_alloc(e, &e->d_dh, (size_t)P * c.channels[0]))) return rc;
     }
@@ -637,13 +637,72 @@ static int alloc_buffers(glass_engine* e) {
     return GLASS_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// GPT-2 (optional): Conv1D weights are [nx][nf] (gpt2/model.py:30-43) -> transposed to [nf][nx]
+// ------------------------------------------------------------------------------------
+static int finalize_gpt2(glass_engine* e) {
+    if (!find(e, "gpt2.transformer.wte.weight")) return GLASS_OK;
+    GET(wte, "gpt2.transformer.wte.weight");
+    GET(wpe, "gpt2.transformer.wpe.weight");
+    GET(lg, "gpt2.transformer.ln_f.weight");
+    GET(lb, "gpt2.transformer.ln_f.bias");
+    REQUIRE(wte->dims.size() == 2 && wpe->dims.size() == 2 && wpe->dims[1] == wte->dims[1], GLASS_ERR_ARG, "bad GPT-2 embedding shapes");
+    e->g_vocab = (int)wte->dims[0];
+    e->g_dim = (int)wte->dims[1];
+    e->g_npos = (int)wpe->dims[0];
+    const int D = e->g_dim;
+    REQUIRE(D % 64 == 0, GLASS_ERR_ARG, "GPT-2 width must be a multiple of the 64-wide head");
+    int rc;
+    if ((rc = upload(e, &e->g_wte, wte->data))) return rc;
+    if ((rc = upload(e, &e->g_wpe, wpe->data))) return rc;
+    if ((rc = upload(e, &e->g_lnf_g, lg->data))) return rc;
+    if ((rc = upload(e, &e->g_lnf_b, lb->data))) return rc;
+    char nm[256];
+    auto tr = [](const HostTensor* w, int nx, int nf) {   // [nx][nf] -> [nf][nx]
+        std::vector<float> v((size_t)nx * nf);
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nf; ++j) v[(size_t)j * nx + i] = w->data[(size_t)i * nf + j];
+        return v;
+    };
+    for (int i = 0;; ++i) {
+        snprintf(nm, sizeof nm, "gpt2.transformer.h.%d.", i);
+        const std::string p = nm;
+        if (!find(e, p + "ln_1.weight")) break;
+        glass_engine::Gpt2Block b;
+        GET(l1g, p + "ln_1.weight"); GET(l1b, p + "ln_1.bias"); GET(l2g, p + "ln_2.weight"); GET(l2b, p + "ln_2.bias");
+        GET(wa, p + "attn.c_attn.weight"); GET(ba, p + "attn.c_attn.bias");
+        GET(wo, p + "attn.c_proj.weight"); GET(bo, p + "attn.c_proj.bias");
+        GET(wf, p + "mlp.c_fc.weight"); GET(bf, p + "mlp.c_fc.bias");
+        GET(wp, p + "mlp.c_proj.weight"); GET(bp, p + "mlp.c_proj.bias");
+        REQUIRE(numel(wa) == (size_t)3 * D * D && numel(wo) == (size_t)D * D && numel(wf) == (size_t)4 * D * D &&
+                    numel(wp) == (size_t)4 * D * D, GLASS_ERR_ARG, "bad GPT-2 block shapes: " + p);
+        if ((rc = upload(e, &b.ln1_g, l1g->data))) return rc;
+        if ((rc = upload(e, &b.ln1_b, l1b->data))) return rc;
+        if ((rc = upload(e, &b.ln2_g, l2g->data))) return rc;
+        if ((rc = upload(e, &b.ln2_b, l2b->data))) return rc;
+        if ((rc = upload(e, &b.w_qkv, tr(wa, D, 3 * D)))) return rc;
+        if ((rc = upload(e, &b.b_qkv, ba->data))) return rc;
+        if ((rc = upload(e, &b.w_o, tr(wo, D, D)))) return rc;
+        if ((rc = upload(e, &b.b_o, bo->data))) return rc;
+        if ((rc = upload(e, &b.w_fc, tr(wf, D, 4 * D)))) return rc;
+        if ((rc = upload(e, &b.b_fc, bf->data))) return rc;
+        if ((rc = upload(e, &b.w_pr, tr(wp, 4 * D, D)))) return rc;
+        if ((rc = upload(e, &b.b_pr, bp->data))) return rc;
+        e->gblk.push_back(b);
+    }
+    return GLASS_OK;
+}
+
 extern "C" int glass_engine_finalize(glass_engine* e) {
     REQUIRE(e, GLASS_ERR_ARG, "null engine");
     REQUIRE(!e->finalized, GLASS_ERR_STATE, "engine already finalized");
     GLASS_HIP(hipSetDevice(e->cfg.device));
-    int rc = finalize_generator(e);
-    if (rc) return rc;
-    if (e->cfg.use_discriminator && (rc = finalize_discriminator(e))) return rc;
+    int rc = GLASS_OK;
+    if (e->cfg.n_blocks > 0) {
+        if ((rc = finalize_generator(e))) return rc;
+        if (e->cfg.use_discriminator && (rc = finalize_discriminator(e))) return rc;
+    }
+    if ((rc = finalize_gpt2(e))) return rc;
     if ((rc = finalize_clip(e))) return rc;
     if ((rc = alloc_buffers(e))) return rc;
     e->host.clear();  // host copies no longer needed
@@ -1015,6 +1074,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     REQUIRE(P > 0 && P <= c.max_pop, GLASS_ERR_ARG, "population size out of range (max_pop)");
     REQUIRE(P % c.batch_size == 0, GLASS_ERR_ARG,
             "population size must be a multiple of batch_size (reference asserts: models.py:112)");
+    REQUIRE(e->cfg.n_blocks > 0, GLASS_ERR_STATE, "this engine was created without a GAN (n_blocks = 0)");
     if (out_F) REQUIRE(e->has_target, GLASS_ERR_STATE, "set_target() first");
     GLASS_HIP(hipSetDevice(c.device));
     const int L = c.latent_size;
@@ -1200,6 +1260,109 @@ extern "C" int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, 
     if (err != hipSuccess) {
         glass_set_error(std::string("encode_text failed: ") + hipGetErrorString(err));
         return GLASS_ERR_HIP;
+    }
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_encode_image(glass_engine* e, const float* images, int32_t n, float* out_feat) {
+    REQUIRE(e && images && out_feat && n > 0, GLASS_ERR_ARG, "null argument");
+    REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first");
+    REQUIRE(n <= e->cfg.max_pop, GLASS_ERR_ARG, "more images than max_pop");
+    const glass_config& c = e->cfg;
+    GLASS_HIP(hipSetDevice(c.device));
+    const size_t elems = (size_t)n * 3 * c.clip_res * c.clip_res;
+    float* d_img = nullptr;
+    GLASS_HIP(hipMalloc(&d_img, elems * sizeof(float)));
+    hipError_t err = hipMemcpyAsync(d_img, images, elems * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    e->cur = e->stream;
+    launch_image_patches(d_img, n, c.clip_res, c.clip_patch, e->d_patches, e->stream);
+    run_clip(e, n);
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(out_feat, e->d_feat, (size_t)n * c.clip_embed * sizeof(float), hipMemcpyDeviceToHost, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err == hipSuccess) err = hipGetLastError();
+    hipFree(d_img);
+    e->prof_events.clear();
+    e->event_next = 0;
+    if (err != hipSuccess) {
+        glass_set_error(std::string("encode_image failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_HIP;
+    }
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context, int32_t P, int32_t nctx, int32_t length,
+                                        int32_t* out_tokens) {
+    REQUIRE(e && context && out_tokens && P > 0 && nctx > 0 && length > 0, GLASS_ERR_ARG, "bad argument");
+    REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first");
+    REQUIRE(e->g_wte != nullptr, GLASS_ERR_STATE, "GPT-2 weights were not loaded (gpt2.transformer.*)");
+    const int D = e->g_dim, V = e->g_vocab, heads = D / 64, Tmax = nctx + length;
+    REQUIRE(Tmax <= e->g_npos && Tmax <= 256, GLASS_ERR_ARG, "sequence longer than the position table / 256");
+    for (long long i = 0; i < (long long)P * nctx; ++i)
+        REQUIRE(context[i] >= 0 && context[i] < V, GLASS_ERR_ARG, "token id out of range");
+    GLASS_HIP(hipSetDevice(e->cfg.device));
+    const int nl = (int)e->gblk.size();
+    const size_t rows = (size_t)P * nctx;
+    int *d_tok = nullptr, *d_next = nullptr;
+    float *x = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *last = nullptr, *logits = nullptr, *kc = nullptr,
+          *vc = nullptr;
+    auto cleanup = [&]() {
+        hipFree(d_tok); hipFree(d_next); hipFree(x); hipFree(ln); hipFree(qkv); hipFree(att); hipFree(hid); hipFree(last);
+        hipFree(logits); hipFree(kc); hipFree(vc);
+    };
+    hipError_t err = hipMalloc(&d_tok, rows * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&d_next, (size_t)P * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&x, rows * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&ln, rows * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&qkv, rows * 3 * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&att, rows * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&hid, rows * 4 * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&last, (size_t)P * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&logits, (size_t)P * V * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&kc, (size_t)nl * P * Tmax * D * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc(&vc, (size_t)nl * P * Tmax * D * sizeof(float));
+    if (err != hipSuccess) {
+        cleanup();
+        glass_set_error(std::string("gpt2_decode: hipMalloc failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_NOMEM;
+    }
+    hipStream_t st = e->stream;
+    std::vector<int32_t> gen((size_t)P * length);
+    hipMemcpyAsync(d_tok, context, rows * sizeof(int), hipMemcpyHostToDevice, st);
+    int nd = nctx, past = 0;
+    for (int step = 0; step < length; ++step) {
+        const int M = P * nd;
+        launch_gpt2_embed(step == 0 ? d_tok : d_next, e->g_wte, e->g_wpe, M, nd, past, D, x, st);
+        for (int l = 0; l < nl; ++l) {
+            const auto& b = e->gblk[l];
+            float* kcl = kc + (size_t)l * P * Tmax * D;
+            float* vcl = vc + (size_t)l * P * Tmax * D;
+            launch_layernorm(x, D, M, D, b.ln1_g, b.ln1_b, nullptr, ln, st);
+            launch_gemm_f32(ln, b.w_qkv, b.b_qkv, qkv, M, 3 * D, D, D, 3 * D, 0, st);
+            launch_gpt2_attention(qkv, kcl, vcl, P, nd, past, Tmax, heads, att, st);
+            launch_gemm_f32(att, b.w_o, b.b_o, x, M, D, D, D, D, 2, st);
+            launch_layernorm(x, D, M, D, b.ln2_g, b.ln2_b, nullptr, ln, st);
+            launch_gemm_f32(ln, b.w_fc, b.b_fc, hid, M, 4 * D, D, D, 4 * D, 1, st);
+            launch_gemm_f32(hid, b.w_pr, b.b_pr, x, M, D, 4 * D, 4 * D, D, 2, st);
+        }
+        // ln_f on the last position of each sequence, tied lm_head, greedy pick
+        launch_layernorm(x + (size_t)(nd - 1) * D, (long long)nd * D, P, D, e->g_lnf_g, e->g_lnf_b, nullptr, last, st);
+        launch_gemm_f32(last, e->g_wte, nullptr, logits, P, V, D, D, V, 0, st);
+        launch_argmax(logits, P, V, d_next, st);
+        hipMemcpyAsync(gen.data() + (size_t)step * P, d_next, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, st);
+        past += nd;
+        nd = 1;
+    }
+    err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipGetLastError();
+    cleanup();
+    if (err != hipSuccess) {
+        glass_set_error(std::string("gpt2_decode failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_HIP;
+    }
+    for (int p = 0; p < P; ++p) {
+        for (int t = 0; t < nctx; ++t) out_tokens[(size_t)p * Tmax + t] = context[(size_t)p * nctx + t];
+        for (int s = 0; s < length; ++s) out_tokens[(size_t)p * Tmax + nctx + s] = gen[(size_t)s * P + p];
     }
     return GLASS_OK;
 }

@@ -99,6 +99,11 @@ struct glass_engine {
     float *c_cls = nullptr, *c_pos = nullptr, *c_lnpre_g = nullptr, *c_lnpre_b = nullptr;
     float *c_lnpost_g = nullptr, *c_lnpost_b = nullptr, *c_proj = nullptr;
     std::vector<ClipBlock> cblk;
+    // GPT-2 (optional, fp32; config C5)
+    struct Gpt2Block { float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *w_qkv, *b_qkv, *w_o, *b_o, *w_fc, *b_fc, *w_pr, *b_pr; };
+    std::vector<Gpt2Block> gblk;
+    float *g_wte = nullptr, *g_wpe = nullptr, *g_lnf_g = nullptr, *g_lnf_b = nullptr;
+    int g_vocab = 0, g_dim = 0, g_npos = 0;
     // text tower (optional)
     std::vector<ClipBlock> tblk;
     float *t_tok = nullptr, *t_pos = nullptr, *t_lnf_g = nullptr, *t_lnf_b = nullptr, *t_proj = nullptr;

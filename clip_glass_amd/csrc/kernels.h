@@ -64,3 +64,14 @@ void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, in
                       hipStream_t st);
 void launch_cosine(const float* feat, const float* target, int P, int D, float* sim, hipStream_t st);
 void launch_assemble_F(const float* sim, const float* dis, int P, int n_obj, float* F, hipStream_t st);
+
+// --- GPT-2 (fp32, gpt2.hip) ----------------------------------------------------------
+void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
+                       hipStream_t st);
+void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
+                     int mode, hipStream_t st);
+void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd, int past, int Tmax, int heads,
+                           float* out, hipStream_t st);
+void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st);
+// NCHW fp32 image [n][3][S][S] -> CLIP patch matrix [n*G*G][3*ps*ps] fp16
+void launch_image_patches(const float* img, int n, int S, int ps, half_t* patches, hipStream_t st);

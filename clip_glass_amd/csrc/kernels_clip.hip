@@ -163,3 +163,19 @@ __global__ void assemble_F_kernel(const float* sim, const float* dis, int P, int
 void launch_assemble_F(const float* sim, const float* dis, int P, int n_obj, float* F, hipStream_t st) {
     hipLaunchKernelGGL(assemble_F_kernel, dim3((P + 63) / 64), dim3(64), 0, st, sim, dis, P, n_obj, F);
 }
+
+// images already resized / normalised by the caller (clip.py:68-74 preprocess) -> patch-embedding operand
+__global__ void image_patches_kernel(const float* img, int n, int S, int ps, half_t* patches) {
+    const int G = S / ps;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * 3 * S * S) return;
+    const int X = (int)(idx % S), Y = (int)((idx / S) % S);
+    const int c = (int)((idx / ((long long)S * S)) % 3), b = (int)(idx / ((long long)S * S * 3));
+    const int gy = Y / ps, iy = Y - gy * ps, gx = X / ps, ix = X - gx * ps;
+    const long long row = ((long long)b * G + gy) * G + gx;
+    patches[row * (3LL * ps * ps) + ((long long)c * ps + iy) * ps + ix] = (half_t)img[idx];
+}
+void launch_image_patches(const float* img, int n, int S, int ps, half_t* patches, hipStream_t st) {
+    const long long total = (long long)n * 3 * S * S;
+    hipLaunchKernelGGL(image_patches_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, n, S, ps, patches);
+}

@@ -58,6 +58,8 @@ def load_library(path=None):
     lib.glass_engine_finalize.argtypes = [C.c_void_p]
     lib.glass_engine_set_target.argtypes = [C.c_void_p, fp, C.c_int32]
     lib.glass_engine_encode_text.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, fp]
+    lib.glass_engine_encode_image.argtypes = [C.c_void_p, fp, C.c_int32, fp]
+    lib.glass_engine_gpt2_decode.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     lib.glass_engine_evaluate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_generate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
@@ -112,8 +114,8 @@ class Engine:
         cfg.noise_mode, cfg.noise_seed = noise_mode, noise_seed
         self.cfg = cfg
         self.channels = list(channels)
-        self.res = 4 << (len(channels) - 1)
-        self.n_noise = 1 + 2 * (len(channels) - 1)
+        self.res = 4 << (len(channels) - 1) if channels else 0
+        self.n_noise = 1 + 2 * (len(channels) - 1) if channels else 0
         self._h = C.c_void_p()
         _check(self.lib, self.lib.glass_engine_create(C.byref(cfg), C.byref(self._h)))
 
@@ -151,6 +153,22 @@ class Engine:
         out = np.empty((t.shape[0], self.cfg.clip_embed), dtype=np.float32)
         _check(self.lib, self.lib.glass_engine_encode_text(self._h, t.ctypes.data_as(C.POINTER(C.c_int32)), t.shape[0],
                                                             t.shape[1], _fp(out)))
+        return out
+
+    def encode_image(self, images):
+        """CLIP.encode_image on preprocessed images [n,3,R,R] float32 -> [n, clip_embed] (generator.py:26-27)."""
+        a = _f32(images)
+        out = np.empty((a.shape[0], self.cfg.clip_embed), dtype=np.float32)
+        _check(self.lib, self.lib.glass_engine_encode_image(self._h, _fp(a), a.shape[0], _fp(out)))
+        return out
+
+    def gpt2_decode(self, context, length):
+        """gpt2/sample.py:21-36 with sample=False: int tokens [P, n] -> [P, n + length] (greedy, fp32)."""
+        c = np.ascontiguousarray(context, dtype=np.int32)
+        out = np.empty((c.shape[0], c.shape[1] + length), dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        _check(self.lib, self.lib.glass_engine_gpt2_decode(self._h, c.ctypes.data_as(ip), c.shape[0], c.shape[1], length,
+                                                            out.ctypes.data_as(ip)))
         return out
 
     # --- the pass ------------------------------------------------------------

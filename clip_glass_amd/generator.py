@@ -22,7 +22,8 @@ def _load_clip_state(config, with_text):
         state = synth.make_state(synth.clip_visual_spec(geom[0], geom[1], geom[3], geom[4], geom[5]), seed)
         if with_text:
             tg = getattr(config, "clip_text_geometry", dict(width=512, layers=12))
-            state.update(synth.make_state(synth.clip_text_spec(width=tg["width"], layers=tg["layers"], out_dim=geom[5]), seed))
+            state.update(synth.make_state(synth.clip_text_spec(width=tg["width"], layers=tg["layers"],
+                                                               vocab=tg.get("vocab", 49408), out_dim=geom[5]), seed))
         return state, geom
     import torch   # reference: clip.load -> torch.jit.load(archive).state_dict() (clip/clip.py:64-78)
     try:
@@ -39,19 +40,52 @@ def _load_clip_state(config, with_text):
     return state, (width, layers, width // 64, patch, patch * grid, state["clip.visual.proj"].shape[1])
 
 
+def clip_preprocess(path_or_image, n_px=224):
+    """clip/clip.py:68-74: Resize(n_px, BICUBIC) -> CenterCrop -> RGB -> ToTensor -> Normalize.
+    torchvision is absent here; restated with PIL (third-party, unpinned)."""
+    from PIL import Image
+    img = Image.open(path_or_image) if isinstance(path_or_image, str) else path_or_image
+    w, h = img.size
+    if w <= h:
+        nw, nh = n_px, int(n_px * h / w)
+    else:
+        nw, nh = int(n_px * w / h), n_px
+    img = img.resize((nw, nh), Image.BICUBIC)
+    left, top = int(round((nw - n_px) / 2.0)), int(round((nh - n_px) / 2.0))
+    img = img.crop((left, top, left + n_px, top + n_px)).convert("RGB")
+    a = np.asarray(img, dtype=np.float32).transpose(2, 0, 1) / 255.0
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], np.float32)[:, None, None]
+    std = np.array([0.26862954, 0.26130258, 0.27577711], np.float32)[:, None, None]
+    return (a - mean) / std
+
+
 class Generator:
     def __init__(self, config, dist=None):
         self.config = config
         self.augmentation = None
-        if config.task != "txt2img":
-            raise NotImplementedError("img2txt (GPT2) is a later row of SURVEY §8")
         self.model = config.model(config)                                   # generator.py:19
-        need_text = getattr(config, "target_features", None) is None
-        clip_state, geom = _load_clip_state(config, need_text)
-        pop = int(getattr(config, "max_pop", max(config.pop_size, config.batch_size)))
-        pop = (pop + config.batch_size - 1) // config.batch_size * config.batch_size
         device = getattr(config, "device", 0)
         device = int(str(device).split(":")[1]) if ":" in str(device) else (device if isinstance(device, int) else 0)
+        pop = int(getattr(config, "max_pop", max(config.pop_size, config.batch_size)))
+        self.generation = 0
+        if config.task == "img2txt":                                        # generator.py:25-27, 52-59
+            clip_state, geom = _load_clip_state(config, True)
+            self.engine = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1,
+                                 max_pop=pop, clip=geom, noise_mode=0, device=device)
+            self.engine.load_state(self.model.state)
+            self.engine.load_state(clip_state)
+            self.engine.finalize()
+            self.model.engine = self.engine
+            if getattr(config, "target_features", None) is not None:
+                self.image_features = np.asarray(config.target_features, np.float32).reshape(1, -1)
+            else:
+                self.image_features = self.engine.encode_image(clip_preprocess(config.target, geom[4])[None])
+            from .tokenizer import DEFAULT_BPE, ClipTokenizer
+            self.tokenizer = ClipTokenizer(getattr(config, "bpe_path", DEFAULT_BPE))
+            return
+        need_text = getattr(config, "target_features", None) is None
+        clip_state, geom = _load_clip_state(config, need_text)
+        pop = (pop + config.batch_size - 1) // config.batch_size * config.batch_size
         self.engine = Engine(self.model.channels[::-1], latent_size=config.dim_z,
                              mapping_layers=getattr(config, "mapping_layers", 8), batch_size=config.batch_size,
                              use_discriminator=bool(config.use_discriminator and config.problem_args["n_obj"] == 2),
@@ -61,7 +95,6 @@ class Generator:
         self.engine.load_state(self.model.state)
         self.engine.load_state(clip_state)
         self.engine.finalize()
-        self.generation = 0
         if getattr(config, "target_features", None) is not None:            # pre-computed text feature
             self.text_features = np.asarray(config.target_features, np.float32).reshape(1, -1)
         else:                                                               # generator.py:23-24
@@ -71,15 +104,33 @@ class Generator:
             self.text_features = self.engine.encode_text(self.tokens)
         self.engine.set_target(self.text_features[0])
 
+    def clip_similarity_texts(self, texts):
+        """generator.py:52-59 (img2txt branch): tokenize -> encode_text -> cosine vs the target image feature;
+        a tokenisation failure zeroes the WHOLE population, as the reference's bare except does."""
+        try:
+            tokens = self.tokenizer.tokenize(texts)
+        except Exception:
+            return np.zeros(len(texts), np.float32)
+        tf = self.engine.encode_text(tokens).astype(np.float64)
+        im = self.image_features.astype(np.float64)
+        den = np.maximum(np.linalg.norm(tf, axis=1) * np.linalg.norm(im, axis=1), 1e-8)
+        return ((tf @ im.T)[:, 0] / den).astype(np.float32)
+
     # --- the hot path: generate + clip_similarity + discriminate in ONE device pass -------------
     def evaluate(self, ls, noise=None, first_minibatch=0):
+        if self.config.task == "img2txt":           # problem.py:19-20,27 with the GPT2 config
+            texts = self.model.generate(*ls())
+            self.last_texts = texts
+            return -self.clip_similarity_texts(texts)[:, None]
         (z,) = ls()
         F = self.engine.evaluate(z, generation=self.generation, first_minibatch=first_minibatch, noise=noise)
         self.generation += 1
         return F
 
     def generate(self, ls, minibatch=None, noise=None):
-        """generator.py:29-34 — images [P,3,R,R] float32 after config.norm (biggan_norm)."""
+        """generator.py:29-34 — images [P,3,R,R] float32 after config.norm (biggan_norm); texts for img2txt."""
+        if self.config.task == "img2txt":
+            return self.model.generate(*ls())
         (z,) = ls()
         bs = self.config.batch_size
         P = z.shape[0]
@@ -98,6 +149,10 @@ class Generator:
 
     def save(self, input, path):
         """generator.py:63-72"""
+        if self.config.task == "img2txt":
+            with open(path, "w") as f:
+                f.write("\n".join(input))
+            return
         if input.shape[0] > 1:
             save_grid(input, path)
         else:

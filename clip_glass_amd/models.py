@@ -70,5 +70,67 @@ class DeepMindBigGAN:
 
 
 class GPT2:
+    """models.py:13-62 — GPT-2 small as a token-latent text generator (img2txt).  Host part: weights
+    (HF `gpt2-pytorch_model.bin` remapped as gpt2/utils.py:10-51 does, or synthetic), BPE, parse_out; the
+    decode itself runs on the device (glass_engine_gpt2_decode, fp32)."""
+
     def __init__(self, config):
-        raise NotImplementedError("GPT-2 img2txt (BASELINE config C5) is a later row of SURVEY §8")
+        self.config = config
+        w = str(config.weights)
+        if w.startswith("synthetic"):
+            seed = int(w.split(":")[1]) if ":" in w else 0
+            geo = getattr(config, "gpt2_geometry", dict(n_embd=768, n_layer=12))
+            self.state = synth.make_state(synth.gpt2_spec(geo["n_embd"], geo["n_layer"], config.encoder_size), seed)
+        else:
+            if not os.path.exists(w):
+                print("Weights not found!\nRun: ./download-weights.sh GPT2")                 # models.py:18-20
+                sys.exit(1)
+            import torch
+            sd = torch.load(w, map_location="cpu")
+            self.state = {}
+            for k, v in sd.items():                                                          # gpt2/utils.py:13-26
+                for old, new in ((".g", ".weight"), (".b", ".bias"), (".w", ".weight")):
+                    if k.endswith(old):
+                        k = k[:-len(old)] + new
+                        break
+                if not k.startswith("transformer."):                                         # utils.py:46-48
+                    k = "transformer." + k
+                if k.endswith("attn.bias"):       # the causal-mask buffer, not a weight
+                    continue
+                self.state["gpt2." + k] = v.float().numpy()
+        self.enc = None
+        enc_path, vocab_path = getattr(config, "encoder", None), getattr(config, "vocab", None)
+        if enc_path and vocab_path and os.path.exists(enc_path) and os.path.exists(vocab_path):
+            from .gpt2_bpe import Gpt2Bpe
+            self.enc = Gpt2Bpe(enc_path, vocab_path)
+            self.init_tokens = np.asarray(self.enc.encode(config.init_text), dtype=np.int64)   # models.py:30
+        else:
+            self.init_tokens = np.asarray(getattr(config, "init_tokens", [1169, 4286, 286]), dtype=np.int64)  # "the picture of"
+        self.engine = None    # set by Generator
+
+    def has_discriminator(self):
+        return False
+
+    def decode_tokens(self, z):
+        """models.py:45-60: context = z ++ init_tokens, 30 greedy steps."""
+        z = np.asarray(z, dtype=np.int64)
+        ctx = np.concatenate([z, np.tile(self.init_tokens, (z.shape[0], 1))], axis=1)
+        return self.engine.gpt2_decode(ctx, self.config.max_tokens_len)
+
+    def parse_out(self, out):
+        """models.py:32-42"""
+        eot = self.enc.eot if self.enc is not None else self.config.encoder_size - 1
+        texts = []
+        for seq in out:
+            seq = [int(t) for t in seq]
+            if eot in seq:
+                text = seq[self.config.dim_z:seq.index(eot)]      # empty when <|endoftext|> sits in the latent part
+            else:
+                text = seq[self.config.dim_z:]
+            texts.append(self.enc.decode(text)[:self.config.max_text_len])
+        return texts
+
+    def generate(self, z, minibatch=None):
+        if self.enc is None:
+            raise RuntimeError("GPT-2 BPE assets not found (config.encoder / config.vocab)")
+        return self.parse_out(self.decode_tokens(z))

@@ -38,7 +38,8 @@ class GenerationProblem(Problem):
         ls = self.config.latent(self.config)
         ls.set_from_population(x)
         P = np.asarray(x).shape[0]
-        assert P % self.config.batch_size == 0          # models.py:112 (reference asserts inside generate)
+        if self.config.task == "txt2img":
+            assert P % self.config.batch_size == 0      # models.py:112 (reference asserts inside generate)
         F = self.generator.evaluate(ls)
         if self.config.problem_args["n_obj"] == 2 and self.config.use_discriminator:
             out["F"] = F                                # column_stack((-sim, hinge)) (problem.py:25)

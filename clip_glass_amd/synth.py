@@ -158,6 +158,23 @@ def clip_text_spec(width=512, layers=12, ctx=77, vocab=49408, out_dim=512):
     return spec
 
 
+def gpt2_spec(n_embd=768, n_layer=12, vocab=50257, n_positions=1024):
+    """(name, shape, kind) of GPT2LMHeadModel (gpt2/model.py:126-211) under the keys the reference holds after
+    gpt2/utils.py load_weight; Conv1D weights are [nx, nf]; init std 0.02 (model.py:34, config.py:17)."""
+    p = "gpt2.transformer."
+    spec = [(p + "wte.weight", (vocab, n_embd), ("n", 0.02)), (p + "wpe.weight", (n_positions, n_embd), ("n", 0.01))]
+    for i in range(n_layer):
+        q = p + "h.%d." % i
+        spec += [(q + "ln_1.weight", (n_embd,), ("ln_w", 0.1)), (q + "ln_1.bias", (n_embd,), ("n", 0.1)),
+                 (q + "attn.c_attn.weight", (n_embd, 3 * n_embd), ("n", 0.05)), (q + "attn.c_attn.bias", (3 * n_embd,), ("n", 0.02)),
+                 (q + "attn.c_proj.weight", (n_embd, n_embd), ("n", 0.02)), (q + "attn.c_proj.bias", (n_embd,), ("n", 0.02)),
+                 (q + "ln_2.weight", (n_embd,), ("ln_w", 0.1)), (q + "ln_2.bias", (n_embd,), ("n", 0.1)),
+                 (q + "mlp.c_fc.weight", (n_embd, 4 * n_embd), ("n", 0.05)), (q + "mlp.c_fc.bias", (4 * n_embd,), ("n", 0.02)),
+                 (q + "mlp.c_proj.weight", (4 * n_embd, n_embd), ("n", 0.02)), (q + "mlp.c_proj.bias", (n_embd,), ("n", 0.02))]
+    spec += [(p + "ln_f.weight", (n_embd,), ("ln_w", 0.1)), (p + "ln_f.bias", (n_embd,), ("n", 0.1))]
+    return spec
+
+
 def make_tensor(seed, name, shape, kind, map_lr_mul=0.01):
     if isinstance(kind, tuple):
         k, std = kind

@@ -47,7 +47,7 @@ class ClipTokenizer:
         self.context_length = context_length
         self.byte_to_char, order = _byte_alphabet()
         lines = gzip.open(bpe_path).read().decode("utf-8").split("\n")
-        merges = [tuple(l.split()) for l in lines[1:49152 - 256 - 2 + 1]]
+        merges = [tuple(l.split()) for l in lines[1:49152 - 256 - 2 + 1] if l.strip()]
         base = [self.byte_to_char[b] for b in order]
         vocab = base + [c + "</w>" for c in base] + ["".join(m) for m in merges] + ["<|startoftext|>", "<|endoftext|>"]
         self.token_id = {tok: i for i, tok in enumerate(vocab)}

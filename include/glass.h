@@ -38,7 +38,8 @@ typedef struct glass_engine glass_engine;
  * argparse/config Namespace (config.py:80-95; stylegan2/models.py kwargs). */
 typedef struct glass_config {
     int32_t device;               /* HIP device ordinal (reference: --device, run.py:17) */
-    int32_t n_blocks;             /* number of resolutions, 4*2^(n_blocks-1) px output (9 -> 1024) */
+    int32_t n_blocks;             /* number of resolutions, 4*2^(n_blocks-1) px output (9 -> 1024);
+                                     0 = no GAN (text-only engine for the GPT2 / img2txt config) */
     int32_t channels[GLASS_MAX_BLOCKS]; /* channels per resolution, LOW -> HIGH res
                                      (reference G order reversed: stylegan2/models.py:748-750) */
     int32_t latent_size;          /* 512 */
@@ -88,6 +89,17 @@ int glass_engine_set_target(glass_engine* e, const float* feat, int32_t n);
  * finalize().  tokens: host int32 [n_texts, ctx] as produced by clip.tokenize (clip/clip.py:125-138);
  * out_feat: host float32 [n_texts, clip_embed]. */
 int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, int32_t n_texts, int32_t ctx, float* out_feat);
+
+/* CLIP image tower on caller-supplied images (generator.py:26-27: the img2txt target), host float32
+ * [n,3,clip_res,clip_res] already preprocessed as clip.py:68-74 does; out_feat float32 [n, clip_embed]. */
+int glass_engine_encode_image(glass_engine* e, const float* images, int32_t n, float* out_feat);
+
+/* GPT-2 greedy decode (config GPT2 / img2txt: models.py:45-62, gpt2/sample.py:21-36 with sample=False).
+ * Needs the "gpt2.transformer.*" tensors (reference GPT2LMHeadModel keys after gpt2/utils.py load_weight).
+ * context: host int32 [P, n_ctx_tok] (latent tokens ++ init_text tokens); out: host int32
+ * [P, n_ctx_tok + length] = context ++ `length` greedily decoded tokens.  All arithmetic is fp32. */
+int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context, int32_t P, int32_t n_ctx_tok, int32_t length,
+                             int32_t* out_tokens);
 
 /* THE HOT PATH — replaces GenerationProblem._evaluate (problem.py:14-29).
  * latents: host float32 [P, latent_size] row-major (latent.py:37-38);

@@ -164,3 +164,27 @@ def build_ref_clip(sd, fp32=True):
     st["vocab_size"] = torch.tensor(st["token_embedding.weight"].shape[0])
     model = R["clip_model"].build_model(st)
     return model.float() if fp32 else model
+
+
+def build_ref_gpt2(sd, n_embd, n_layer, vocab):
+    """The reference's own GPT2LMHeadModel (gpt2/model.py) loaded with a synthetic state."""
+    import torch
+    load_reference()
+    import importlib
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        gm = importlib.import_module("gpt2.model")
+        gc = importlib.import_module("gpt2.config")
+        gs = importlib.import_module("gpt2.sample")
+    finally:
+        os.chdir(cwd)
+    n_pos = int(sd["gpt2.transformer.wpe.weight"].shape[0])
+    cfg = gc.GPT2Config(vocab_size_or_config_json_file=vocab, n_positions=n_pos, n_ctx=n_pos, n_embd=n_embd, n_layer=n_layer,
+                        n_head=n_embd // 64)
+    model = gm.GPT2LMHeadModel(cfg)
+    st = {k[len("gpt2."):]: torch.as_tensor(v) for k, v in sd.items() if k.startswith("gpt2.")}
+    missing = model.load_state_dict(st, strict=False)
+    assert not [k for k in missing.missing_keys if not k.endswith("attn.bias") and "lm_head" not in k], missing
+    model.set_tied()
+    return model.eval(), gs.sample_sequence
