@@ -303,7 +303,8 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
     const int KS = p.KS, S = p.stride;
     if (KS == 3 && S == 1 && p.pad == 1) {
         static const int th4 = getenv("GLASS_TH4") ? atoi(getenv("GLASS_TH4")) : 0;   // experiment knob
-        if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
+        static const bool nt64 = getenv("GLASS_NT64") != nullptr;   // experiment knob
+        if (!nt64 && p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
         if ((th4 & 2) && p.Neff % 64 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 64>(p, st, "conv_tiled_kernel<3,1,4,64>");
         static const bool persist = getenv("GLASS_PERSIST") != nullptr;   // measured slower (more live registers -> lower occupancy): off
         if (persist && p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64, true>(p, st, "conv_tiled_kernel<3,1,8,64,persist>");

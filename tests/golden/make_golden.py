@@ -104,6 +104,20 @@ def problem_case(seed=0, noise_seed=5):
                 tokens=R["clip_clip"].tokenize([cfg.target]).numpy()[0])
 
 
+def gpt2_case(seed=2, P=8):
+    """Reference GPT2LMHeadModel + sample_sequence (gpt2/sample.py) on a small synthetic GPT-2: greedy tokens."""
+    geo = dict(n_embd=128, n_layer=2, vocab=2048)
+    sd = synth.make_state(synth.gpt2_spec(**geo, n_positions=64), seed)
+    model, sample_sequence = rh.build_ref_gpt2(sd, geo["n_embd"], geo["n_layer"], geo["vocab"])
+    ctx = np.random.RandomState(1).randint(0, geo["vocab"], size=(P, 23)).astype(np.int64)
+    out = sample_sequence(model=model, length=30, context=torch.tensor(ctx), start_token=None, batch_size=P,
+                          temperature=0.7, top_k=40, device="cpu", sample=False)
+    with torch.no_grad():
+        logits, _ = model(torch.tensor(ctx))
+    return dict(seed=seed, n_embd=geo["n_embd"], n_layer=geo["n_layer"], vocab=geo["vocab"], context=ctx,
+                tokens=np.asarray(out, dtype=np.int64), last_logits=logits[:, -1, :64].numpy())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ffhq", action="store_true")
@@ -111,6 +125,8 @@ def main():
     assert rh.available(), "needs /root/reference"
     np.savez_compressed(os.path.join(HERE, "mini_problem.npz"), **problem_case())
     print("mini_problem.npz")
+    np.savez_compressed(os.path.join(HERE, "gpt2_mini.npz"), **gpt2_case())
+    print("gpt2_mini.npz")
     np.savez_compressed(os.path.join(HERE, "mid_modules.npz"), **modules_case("mid", 8, 4, 0, 11, 2))
     print("mid_modules.npz")
     np.savez_compressed(os.path.join(HERE, "mini_modules.npz"), **modules_case("mini", 8, 4, 0, 11, 2))

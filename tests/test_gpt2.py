@@ -223,3 +223,36 @@ def test_encode_image_matches_oracle():
     ref = clip_ref.encode_image(_t(sd), torch.tensor(img)).numpy()
     from util import check
     check("encode_image", got, ref, 5e-3)
+
+
+def _gold():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpt2_mini.npz")))
+
+
+def test_oracle_reproduces_reference_gpt2_golden():
+    g = _gold()
+    sd = synth.make_state(synth.gpt2_spec(int(g["n_embd"]), int(g["n_layer"]), int(g["vocab"]), n_positions=64), int(g["seed"]))
+    out = gpt2_ref.sample_sequence(_t(sd), torch.tensor(g["context"]), 30).numpy()
+    assert np.array_equal(out, g["tokens"])
+    with torch.no_grad():
+        logits, _ = gpt2_ref.forward(_t(sd), torch.tensor(g["context"]))
+    np.testing.assert_allclose(logits[:, -1, :64].numpy(), g["last_logits"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_reference_gpt2_golden():
+    import glass_models as M
+    from clip_glass_amd.engine import Engine
+    g = _gold()
+    sd = synth.make_state(synth.gpt2_spec(int(g["n_embd"]), int(g["n_layer"]), int(g["vocab"]), n_positions=64), int(g["seed"]))
+    clip = M.CONFIGS["mini"]["clip"]
+    sd.update(synth.make_state(synth.clip_visual_spec(clip[0], clip[1], clip[3], clip[4], clip[5]), 0))
+    e = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1, max_pop=8, clip=clip, noise_mode=0)
+    e.load_state(sd)
+    e.finalize()
+    got = e.gpt2_decode(g["context"], 30)
+    e.close()
+    ok = int((got == g["tokens"]).all(axis=1).sum())
+    diag("[gpt2] golden (reference sampler) %d/%d sequences token-identical" % (ok, got.shape[0]))
+    assert ok >= got.shape[0] - 1
