@@ -1,0 +1,400 @@
+// biggan.cpp — BigGAN-deep generator behind the same engine / C ABI (config C3: DeepMindBigGAN256/512,
+// reference call sites models.py:64-86, latent.py:4-24, config.py:31-74).
+//
+// The network itself lives in pytorch-pretrained-biggan==0.1.1 (absent from /root/reference): the layer
+// algebra here follows that package's published BigGAN-deep generator under its state-dict keys
+// ("biggan." + key), restated in oracle/biggan_ref.py.  MI355X formulation:
+//   * spectral norm folded at load:  W <- weight_orig / (u . W_mat v)       (inference uses the stored u, v)
+//   * every BigGANBatchNorm folded to one per-(candidate, channel) affine  y = x*A + S, the tables for ALL
+//     56 norms of the network produced by ONE dense launch (cond[P,256] x [256, 2*Ctot]) + one table kernel;
+//     the conv biases feeding a norm are folded into its shift
+//   * bn1..bn3 + ReLU ride in the epilogue of the conv that produces their input (scale, shift, relu),
+//     so each GenBlock is 4 MFMA convs + 1 affine-relu (bn0) + the skip gather
+//   * self-attention = one 1x1 conv for theta|phi|g, a split/max-pool kernel, two batched MFMA GEMMs
+//     around an fp32 row softmax, and the output 1x1 conv with gamma folded in and the residual fused
+//   * activations NHWC fp16 (fp32 accumulate), images leave as planar fp32 like the StyleGAN2 path.
+#include <math.h>
+#include <string.h>
+
+#include "engine.h"
+#include "kernels.h"
+
+namespace {
+
+// weight_orig / sigma as a flat float vector [rows][cols]
+int sn_fold(glass_engine* e, const std::string& prefix, int rows, size_t cols, std::vector<float>& out) {
+    const HostTensor* w = find(e, prefix + ".weight_orig");
+    const HostTensor* u = find(e, prefix + ".weight_u");
+    const HostTensor* v = find(e, prefix + ".weight_v");
+    if (!w) {   // already-normalised weight
+        const HostTensor* w2 = find(e, prefix + ".weight");
+        REQUIRE(w2 != nullptr, GLASS_ERR_STATE, "missing tensor: " + prefix + ".weight_orig");
+        REQUIRE(numel(w2) == (size_t)rows * cols, GLASS_ERR_ARG, "bad shape: " + prefix + ".weight");
+        out = w2->data;
+        return GLASS_OK;
+    }
+    REQUIRE(u && v, GLASS_ERR_STATE, "missing tensor: " + prefix + ".weight_u / weight_v");
+    REQUIRE(numel(w) == (size_t)rows * cols && numel(u) == (size_t)rows && numel(v) == cols, GLASS_ERR_ARG,
+            "bad shape: " + prefix + " (spectral-norm weight / u / v)");
+    double sigma = 0.0;
+    for (int i = 0; i < rows; ++i) {
+        double acc = 0.0;
+        const float* wr = w->data.data() + (size_t)i * cols;
+        for (size_t j = 0; j < cols; ++j) acc += (double)wr[j] * v->data[j];
+        sigma += acc * u->data[i];
+    }
+    REQUIRE(sigma != 0.0, GLASS_ERR_ARG, "zero spectral norm: " + prefix);
+    out.resize((size_t)rows * cols);
+    const float inv = (float)(1.0 / sigma);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = w->data[i] * inv;
+    return GLASS_OK;
+}
+
+// conv weight [cout][cin][ks][ks] -> [ks*ks][cout_pad][cin] fp16 (rows >= cout are zero)
+std::vector<_Float16> pack(const std::vector<float>& W, int cout, int cin, int ks, int cout_pad, float scale = 1.f) {
+    std::vector<_Float16> out((size_t)ks * ks * cout_pad * cin, (_Float16)0.f);
+    for (int o = 0; o < cout; ++o)
+        for (int i = 0; i < cin; ++i)
+            for (int t = 0; t < ks * ks; ++t)
+                out[((size_t)t * cout_pad + o) * cin + i] = (_Float16)(W[((size_t)o * cin + i) * ks * ks + t] * scale);
+    return out;
+}
+
+// BigGANBatchNorm: statistics row for this truncation (blend as the package does)
+int stat_row(glass_engine* e, const std::string& name, int n_stats, int C, double truncation, std::vector<float>& out) {
+    GET(t, name);
+    REQUIRE(numel(t) == (size_t)n_stats * C, GLASS_ERR_ARG, "bad shape: " + name);
+    const double step = 1.0 / (n_stats - 1);
+    double ip = 0.0;
+    const double coef = modf(truncation / step, &ip);
+    const int start = (int)ip;
+    REQUIRE(start >= 0 && start < n_stats && (coef == 0.0 || start + 1 < n_stats), GLASS_ERR_ARG,
+            "truncation outside the stored batch-norm statistics");
+    out.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const float a = t->data[(size_t)start * C + c];
+        out[c] = coef != 0.0 ? (float)(a * coef + t->data[(size_t)(start + 1) * C + c] * (1 - coef)) : a;
+    }
+    return GLASS_OK;
+}
+
+}  // namespace
+
+int glass_biggan_finalize(glass_engine* e) {
+    const glass_config& c = e->cfg;
+    BgState& g = e->bg;
+    const int ch = c.bg_ch, zd = c.bg_z_dim, nc = c.bg_num_classes, cd = 2 * zd, ns = c.bg_n_stats;
+    const std::string G = "biggan.generator.";
+    int rc;
+    g.zd = zd;
+    g.nc = nc;
+    g.c0 = 16 * ch;
+    {
+        GET(E, "biggan.embeddings.weight");
+        REQUIRE(numel(E) == (size_t)zd * nc, GLASS_ERR_ARG, "bad shape: biggan.embeddings.weight");
+        if ((rc = upload(e, &g.et, transposed(E->data.data(), zd, nc, 1.f)))) return rc;
+        std::vector<float> W;
+        if ((rc = sn_fold(e, G + "gen_z", 16 * g.c0, cd, W))) return rc;
+        if ((rc = upload(e, &g.genz_wt, transposed(W.data(), 16 * g.c0, cd, 1.f)))) return rc;
+        GET(b, G + "gen_z.bias");
+        REQUIRE(numel(b) == (size_t)16 * g.c0, GLASS_ERR_ARG, "bad shape: gen_z.bias");
+        if ((rc = upload(e, &g.genz_b, b->data))) return rc;
+    }
+    // ---- walk the layer list: block geometry + batch-norm column offsets -----------------------------
+    struct BnRef { std::string prefix; int C, off; bool conditional; std::string prebias; };
+    std::vector<BnRef> bns;
+    int res = 4, m = 0, off = 0;
+    g.blocks.clear();
+    std::vector<std::string> block_prefix;
+    for (int i = 0; i < c.bg_n_layers; ++i) {
+        if (i == c.bg_attention_pos) {
+            g.attn_before = i;
+            g.attn_C = ch * c.bg_layers[i][1];
+            g.attn_res = res;
+            const std::string p = G + "layers." + std::to_string(m);
+            const int C = g.attn_C, c8 = C / 8, c2 = C / 2;
+            REQUIRE(C % 64 == 0 && res % 2 == 0, GLASS_ERR_ARG, "unsupported self-attention geometry");
+            std::vector<float> Wt, Wp, Wg, Wo;
+            if ((rc = sn_fold(e, p + ".snconv1x1_theta", c8, C, Wt))) return rc;
+            if ((rc = sn_fold(e, p + ".snconv1x1_phi", c8, C, Wp))) return rc;
+            if ((rc = sn_fold(e, p + ".snconv1x1_g", c2, C, Wg))) return rc;
+            if ((rc = sn_fold(e, p + ".snconv1x1_o_conv", C, c2, Wo))) return rc;
+            std::vector<float> cat;
+            cat.insert(cat.end(), Wt.begin(), Wt.end());
+            cat.insert(cat.end(), Wp.begin(), Wp.end());
+            cat.insert(cat.end(), Wg.begin(), Wg.end());
+            if ((rc = upload(e, &g.attn_w_tpg, pack(cat, 2 * c8 + c2, C, 1, 2 * c8 + c2)))) return rc;
+            GET(gm, p + ".gamma");
+            if ((rc = upload(e, &g.attn_w_o, pack(Wo, C, c2, 1, C, gm->data[0])))) return rc;
+            ++m;
+        }
+        BgBlock b;
+        b.up = c.bg_layers[i][0];
+        b.cin = ch * c.bg_layers[i][1];
+        b.cout = ch * c.bg_layers[i][2];
+        b.mid = b.cin / 4;
+        b.res_in = res;
+        REQUIRE(b.cin % 128 == 0 && b.mid % 32 == 0 && b.cout % 32 == 0, GLASS_ERR_ARG,
+                "BigGAN channel widths must keep in/4 and out multiples of 32");
+        REQUIRE(b.cin == b.cout || b.cin == 2 * b.cout, GLASS_ERR_ARG,
+                "GenBlock: out channels must equal in or in/2 (channel-drop skip)");
+        const std::string p = G + "layers." + std::to_string(m);
+        const int cins[4] = {b.cin, b.mid, b.mid, b.mid}, couts[4] = {b.mid, b.mid, b.mid, b.cout}, kss[4] = {1, 3, 3, 1};
+        for (int k = 0; k < 4; ++k) {
+            b.bn_off[k] = off;
+            bns.push_back({p + ".bn_" + std::to_string(k), cins[k], off, true,
+                           k > 0 ? p + ".conv_" + std::to_string(k - 1) + ".bias" : std::string()});
+            off += cins[k];
+            std::vector<float> W;
+            if ((rc = sn_fold(e, p + ".conv_" + std::to_string(k), couts[k], (size_t)cins[k] * kss[k] * kss[k], W))) return rc;
+            if ((rc = upload(e, &b.w[k], pack(W, couts[k], cins[k], kss[k], couts[k])))) return rc;
+        }
+        GET(b3, p + ".conv_3.bias");
+        REQUIRE(numel(b3) == (size_t)b.cout, GLASS_ERR_ARG, "bad shape: conv_3.bias");
+        if ((rc = upload(e, &b.b3, b3->data))) return rc;
+        g.blocks.push_back(b);
+        if (b.up) res *= 2;
+        ++m;
+    }
+    REQUIRE(!g.blocks.empty() && g.blocks[0].cin == g.c0, GLASS_ERR_ARG, "first GenBlock must take 16*ch channels");
+    REQUIRE(g.blocks.back().cout == ch, GLASS_ERR_ARG, "last GenBlock must produce `ch` channels");
+    g.R = res;
+    g.final_bn_off = off;
+    bns.push_back({G + "bn", ch, off, false, std::string()});
+    off += ch;
+    g.Ctot = off;
+    // ---- batch-norm tables: dense weights [cd][2*Ctot] ( gain columns | offset columns ) ---------------
+    {
+        const size_t CT = (size_t)g.Ctot;
+        std::vector<float> wt((size_t)cd * 2 * CT, 0.f), bias(2 * CT, 0.f), inv_std(CT), mean(CT), prebias(CT, 0.f);
+        for (auto& r : bns) {
+            std::vector<float> mu, var;
+            if ((rc = stat_row(e, r.prefix + ".running_means", ns, r.C, c.bg_truncation, mu))) return rc;
+            if ((rc = stat_row(e, r.prefix + ".running_vars", ns, r.C, c.bg_truncation, var))) return rc;
+            for (int k = 0; k < r.C; ++k) {
+                mean[r.off + k] = mu[k];
+                inv_std[r.off + k] = 1.f / sqrtf(var[k] + c.bg_eps);
+            }
+            if (r.conditional) {
+                std::vector<float> Ws, Wo;
+                if ((rc = sn_fold(e, r.prefix + ".scale", r.C, cd, Ws))) return rc;
+                if ((rc = sn_fold(e, r.prefix + ".offset", r.C, cd, Wo))) return rc;
+                for (int k = 0; k < r.C; ++k) {
+                    bias[r.off + k] = 1.f;   // weight = 1 + scale(cond)
+                    for (int j = 0; j < cd; ++j) {
+                        wt[(size_t)j * 2 * CT + r.off + k] = Ws[(size_t)k * cd + j];
+                        wt[(size_t)j * 2 * CT + CT + r.off + k] = Wo[(size_t)k * cd + j];
+                    }
+                }
+            } else {
+                GET(w, r.prefix + ".weight");
+                GET(b, r.prefix + ".bias");
+                REQUIRE(numel(w) == (size_t)r.C && numel(b) == (size_t)r.C, GLASS_ERR_ARG, "bad shape: " + r.prefix);
+                for (int k = 0; k < r.C; ++k) {
+                    bias[r.off + k] = w->data[k];
+                    bias[CT + r.off + k] = b->data[k];
+                }
+            }
+            if (!r.prebias.empty()) {
+                GET(pb, r.prebias);
+                REQUIRE(numel(pb) == (size_t)r.C, GLASS_ERR_ARG, "bad shape: " + r.prebias);
+                for (int k = 0; k < r.C; ++k) prebias[r.off + k] = pb->data[k];
+            }
+        }
+        if ((rc = upload(e, &g.bn_wt, wt))) return rc;
+        if ((rc = upload(e, &g.bn_bias, bias))) return rc;
+        if ((rc = upload(e, &g.bn_inv_std, inv_std))) return rc;
+        if ((rc = upload(e, &g.bn_mean, mean))) return rc;
+        if ((rc = upload(e, &g.bn_prebias, prebias))) return rc;
+    }
+    {   // conv_to_rgb: only the first 3 of `ch` output channels are used (z[:, :3]); padded to rgb_cpad MFMA columns
+        std::vector<float> W;
+        if ((rc = sn_fold(e, G + "conv_to_rgb", ch, (size_t)ch * 9, W))) return rc;
+        W.resize((size_t)3 * ch * 9);
+        if ((rc = upload(e, &g.rgb_w, pack(W, 3, ch, 3, g.rgb_cpad)))) return rc;
+        GET(b, G + "conv_to_rgb.bias");
+        std::vector<float> bb(g.rgb_cpad, 0.f);
+        for (int k = 0; k < 3; ++k) bb[k] = b->data[k];
+        if ((rc = upload(e, &g.rgb_b, bb))) return rc;
+    }
+    // ---- activation buffers (per chunk of candidates) ---------------------------------------------------
+    const size_t P = c.max_pop, CH = e->chunk;
+    size_t mx = 0, mt0 = 0, mt1 = 0, mtu = 0, mr = 0;
+    for (auto& b : g.blocks) {
+        const size_t hi = (size_t)b.res_in * b.res_in, ro = (size_t)(b.res_in << b.up), ho = ro * ro;
+        mx = std::max(mx, std::max(hi * b.cin, ho * b.cout));
+        mt0 = std::max(mt0, hi * b.cin);
+        mt1 = std::max(mt1, hi * b.mid);
+        mtu = std::max(mtu, ho * b.mid);
+        mr = std::max(mr, ho * b.cout);
+    }
+    const size_t RR = (size_t)g.R * g.R;
+    mt0 = std::max(mt0, RR * ch);
+    mtu = std::max(mtu, RR * g.rgb_cpad);
+    if ((rc = dev_alloc(e, &g.cond, P * cd))) return rc;
+    if ((rc = dev_alloc(e, &g.tab, P * 2 * g.Ctot))) return rc;
+    if ((rc = dev_alloc(e, &g.h32, CH * 16 * g.c0))) return rc;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = dev_alloc(e, &g.x[i], CH * mx))) return rc;
+    if ((rc = dev_alloc(e, &g.t0, CH * mt0))) return rc;
+    if ((rc = dev_alloc(e, &g.t1, CH * mt1))) return rc;
+    if ((rc = dev_alloc(e, &g.t1u, CH * mtu))) return rc;
+    if ((rc = dev_alloc(e, &g.t2, CH * mtu))) return rc;
+    if ((rc = dev_alloc(e, &g.t3, CH * mtu))) return rc;
+    if ((rc = dev_alloc(e, &g.r, CH * mr))) return rc;
+    if (g.attn_before >= 0) {
+        const size_t hw = (size_t)g.attn_res * g.attn_res, hq = hw / 4, C = g.attn_C, c8 = C / 8, c2 = C / 2;
+        if ((rc = dev_alloc(e, &g.a_T, CH * hw * (2 * c8 + c2)))) return rc;
+        if ((rc = dev_alloc(e, &g.a_theta, CH * hw * c8))) return rc;
+        if ((rc = dev_alloc(e, &g.a_phi, CH * hq * c8))) return rc;
+        if ((rc = dev_alloc(e, &g.a_gT, CH * c2 * hq))) return rc;
+        if ((rc = dev_alloc(e, &g.a_S, CH * hw * hq))) return rc;
+        if ((rc = dev_alloc(e, &g.a_P, CH * hw * hq))) return rc;
+        if ((rc = dev_alloc(e, &g.a_O, CH * hw * c2))) return rc;
+    }
+    return GLASS_OK;
+}
+
+int glass_biggan_prepare(glass_engine* e, int P) {
+    BgState& g = e->bg;
+    const int cd = 2 * g.zd;
+    {
+        Prof pr(e, "bg.cond", 2.0 * P * g.nc * g.zd, 4.0 * ((double)P * e->cfg.latent_size + (double)g.nc * g.zd));
+        launch_bg_cond(e->d_z, P, e->cfg.latent_size, g.zd, g.nc, g.et, g.cond, e->cur);
+    }
+    {
+        Prof pr(e, "bg.bn_tables", 2.0 * P * cd * 2.0 * g.Ctot, 4.0 * ((double)cd * 2 * g.Ctot + 2.0 * P * 2 * g.Ctot));
+        launch_dense(g.cond, cd, P, cd, g.bn_wt, 2 * g.Ctot, g.bn_bias, g.tab, 2 * g.Ctot, 0, 0, nullptr, 0, e->cur);
+        launch_bg_bn_tables(g.tab, P, g.Ctot, g.bn_inv_std, g.bn_mean, g.bn_prebias, e->cur);
+    }
+    return GLASS_OK;
+}
+
+namespace {
+
+// one conv of the BigGAN path: x [B][res][res][cin] -> y [B][res][res][cout]; bn >= 0: fused scale/shift + relu
+void bg_conv(glass_engine* e, const char* tag, int c0, int B, int res, int cin, int cout, int ks, const half_t* w,
+             const half_t* x, half_t* y, int bn_off, const float* bias, const half_t* resid) {
+    BgState& g = e->bg;
+    ConvParams p = conv_defaults();
+    p.x = x;
+    p.x_bstride = (long long)res * res * cin;
+    p.B = B; p.H = res; p.W = res; p.Cin = cin;
+    p.Hc = res; p.Wc = res; p.Ho = res; p.Wo = res;
+    p.KS = ks; p.stride = 1; p.pad = ks / 2;
+    p.w = w;
+    p.Neff = cout; p.Cout = cout;
+    if (bn_off >= 0) {
+        p.dscale = g.tab + (size_t)c0 * 2 * g.Ctot + bn_off;
+        p.shift = p.dscale + g.Ctot;
+        p.ds_stride = 2 * g.Ctot;
+        p.act = 2;
+    }
+    p.bias = bias;
+    p.res = resid;
+    p.y = y;
+    const double M = (double)B * res * res;
+    run_conv(e, p, tag, 2.0 * M * cout * cin * ks * ks, 2.0 * (M * cin + M * cout + (double)cout * cin * ks * ks));
+}
+
+void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
+    BgState& g = e->bg;
+    const int res = g.attn_res, C = g.attn_C, c8 = C / 8, c2 = C / 2, CT = 2 * c8 + c2;
+    const int hw = res * res, hq = hw / 4;
+    bg_conv(e, "bg.attn.theta_phi_g", 0, B, res, C, CT, 1, g.attn_w_tpg, x, g.a_T, -1, nullptr, nullptr);
+    {
+        Prof pr(e, "bg.attn.split_pool", 0, 2.0 * B * ((double)hw * CT + (double)hw * c8 + (double)hq * (c8 + c2)));
+        launch_bg_attn_split(g.a_T, B, res, res, c8, c2, g.a_theta, g.a_phi, g.a_gT, e->cur);
+    }
+    GemmParams q;
+    memset(&q, 0, sizeof q);   // logits = theta . phi^T  (fp32 out)
+    q.a = g.a_theta; q.w = g.a_phi; q.M = hw; q.N = hq; q.K = c8; q.mode = 3; q.out32 = g.a_S; q.ldo = hq;
+    q.batch = B; q.a_bs = (long long)hw * c8; q.w_bs = (long long)hq * c8; q.o_bs = (long long)hw * hq;
+    {
+        Prof pr(e, "bg.attn.logits", 2.0 * B * hw * (double)hq * c8, B * (2.0 * hw * c8 + 2.0 * hq * c8 + 4.0 * hw * hq));
+        const char* k = launch_gemm_tiled(q, e->cur);
+        if (!k) k = launch_gemm_direct(q, e->cur);
+        if (pr.on) pr.pe.name = std::string("bg.attn.logits@") + k;
+    }
+    {
+        Prof pr(e, "bg.attn.softmax", 0, 6.0 * B * hw * (double)hq);
+        launch_bg_softmax(g.a_S, (long long)B * hw, hq, g.a_P, e->cur);
+    }
+    memset(&q, 0, sizeof q);   // attn_g = P . g^T
+    q.a = g.a_P; q.w = g.a_gT; q.M = hw; q.N = c2; q.K = hq; q.mode = 0; q.out16 = g.a_O; q.ldo = c2;
+    q.batch = B; q.a_bs = (long long)hw * hq; q.w_bs = (long long)c2 * hq; q.o_bs = (long long)hw * c2;
+    {
+        Prof pr(e, "bg.attn.values", 2.0 * B * hw * (double)hq * c2, B * (2.0 * hw * hq + 2.0 * hq * c2 + 2.0 * hw * c2));
+        const char* k = launch_gemm_tiled(q, e->cur);
+        if (!k) k = launch_gemm_direct(q, e->cur);
+        if (pr.on) pr.pe.name = std::string("bg.attn.values@") + k;
+    }
+    // out = x + gamma * o_conv(attn_g): gamma folded into the weights, x as the fused residual
+    bg_conv(e, "bg.attn.o_conv", 0, B, res, c2, C, 1, g.attn_w_o, g.a_O, y, -1, nullptr, x);
+}
+
+}  // namespace
+
+int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
+    BgState& g = e->bg;
+    const int cd = 2 * g.zd, TS = 2 * g.Ctot;
+    const float* tabA = g.tab + (size_t)c0 * TS;
+    {   // gen_z: cond -> [B][4][4][16ch] (the package views the linear output as NHWC before permuting)
+        Prof pr(e, "bg.gen_z", 2.0 * B * cd * 16.0 * g.c0, 4.0 * (double)cd * 16 * g.c0);
+        launch_dense(g.cond + (size_t)c0 * cd, cd, B, cd, g.genz_wt, 16 * g.c0, g.genz_b, g.h32, 16 * g.c0, 0, 0, nullptr, 0,
+                     e->cur);
+        launch_bg_to_half(g.h32, g.x[0], (long long)B * 16 * g.c0, e->cur);
+    }
+    int cur = 0;
+    char tag[64];
+    for (size_t i = 0; i < g.blocks.size(); ++i) {
+        if ((int)i == g.attn_before) {
+            bg_attention(e, B, g.x[cur], g.x[cur ^ 1]);
+            cur ^= 1;
+        }
+        const BgBlock& b = g.blocks[i];
+        const int ri = b.res_in, ro = b.res_in << b.up;
+        const half_t* x = g.x[cur];
+        {
+            snprintf(tag, sizeof tag, "bg.b%zu.bn0_relu", i);
+            Prof pr(e, tag, 0, 4.0 * B * ri * ri * (double)b.cin);
+            launch_bg_affine_relu(x, B, (long long)ri * ri, b.cin, tabA + b.bn_off[0], tabA + g.Ctot + b.bn_off[0], TS, g.t0,
+                                  e->cur);
+        }
+        snprintf(tag, sizeof tag, "bg.b%zu.conv0.r%d.%dx%d", i, ri, b.cin, b.mid);
+        bg_conv(e, tag, c0, B, ri, b.cin, b.mid, 1, b.w[0], g.t0, g.t1, b.bn_off[1], nullptr, nullptr);
+        const half_t* t1 = g.t1;
+        if (b.up) {
+            snprintf(tag, sizeof tag, "bg.b%zu.upsample", i);
+            Prof pr(e, tag, 0, 2.0 * B * (double)(ri * ri + ro * ro) * b.mid);
+            launch_bg_gather(g.t1, B, ri, ri, b.mid, b.mid, 1, g.t1u, e->cur);
+            t1 = g.t1u;
+        }
+        snprintf(tag, sizeof tag, "bg.b%zu.conv1.r%d.%dx%d", i, ro, b.mid, b.mid);
+        bg_conv(e, tag, c0, B, ro, b.mid, b.mid, 3, b.w[1], t1, g.t2, b.bn_off[2], nullptr, nullptr);
+        snprintf(tag, sizeof tag, "bg.b%zu.conv2.r%d.%dx%d", i, ro, b.mid, b.mid);
+        bg_conv(e, tag, c0, B, ro, b.mid, b.mid, 3, b.w[2], g.t2, g.t3, b.bn_off[3], nullptr, nullptr);
+        const half_t* skip = x;
+        if (b.up || b.cin != b.cout) {   // x0[:, :in/2] and / or nearest x2
+            snprintf(tag, sizeof tag, "bg.b%zu.skip", i);
+            Prof pr(e, tag, 0, 2.0 * B * (double)(ri * ri + ro * ro) * b.cout);
+            launch_bg_gather(x, B, ri, ri, b.cin, b.cout, b.up, g.r, e->cur);
+            skip = g.r;
+        }
+        snprintf(tag, sizeof tag, "bg.b%zu.conv3.r%d.%dx%d", i, ro, b.mid, b.cout);
+        bg_conv(e, tag, c0, B, ro, b.mid, b.cout, 1, b.w[3], g.t3, g.x[cur ^ 1], -1, b.b3, skip);
+        cur ^= 1;
+    }
+    {   // bn - relu - conv_to_rgb[:3] - tanh
+        const int R = g.R, ch = e->cfg.bg_ch;
+        {
+            Prof pr(e, "bg.final.bn_relu", 0, 4.0 * B * R * R * (double)ch);
+            launch_bg_affine_relu(g.x[cur], B, (long long)R * R, ch, tabA + g.final_bn_off, tabA + g.Ctot + g.final_bn_off, TS,
+                                  g.t0, e->cur);
+        }
+        bg_conv(e, "bg.final.conv_to_rgb", c0, B, R, ch, g.rgb_cpad, 3, g.rgb_w, g.t0, g.t1u, -1, g.rgb_b, nullptr);
+        Prof pr(e, "bg.final.tanh", 0, B * (double)R * R * (2.0 * g.rgb_cpad + 12.0));
+        launch_bg_rgb_tanh(g.t1u, B, (long long)R * R, g.rgb_cpad, y, e->cur);
+    }
+    return GLASS_OK;
+}

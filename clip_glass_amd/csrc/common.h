@@ -44,7 +44,8 @@ struct ConvParams {
     float noise_strength;
     int batch_size;         // candidates per noise plane
     const float* bias;      // [Cout] (nullable)
-    int act;                // 1: leaky-relu(0.2) * sqrt(2)
+    const float* shift;     // [B][ds_stride] per-sample per-channel shift added after bias (nullable; BigGAN conditional BN)
+    int act;                // 1: leaky-relu(0.2) * sqrt(2); 2: relu
     const half_t* res;      // residual [B][Ho][Wo][Cout] added after activation (nullable)
     float out_scale;
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
@@ -60,4 +61,6 @@ struct GemmParams {
     half_t* out16;
     float* out32;
     int ldo;
+    int batch;              // 0/1: single problem; >1: blockIdx.z walks problems a_bs / w_bs / o_bs elements apart
+    long long a_bs, w_bs, o_bs;
 };

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
             if (p.dscale) val *= p.dscale[(long long)rb * p.ds_stride + o];
             if (p.noise) val += p.noise_strength * p.noise[((long long)(rb / p.batch_size) * p.Ho + py) * p.Wo + px];
             if (p.bias) val += p.bias[o];
-            if (p.act) val = lrelu_sqrt2(val);
+            if (p.shift) val += p.shift[(long long)rb * p.ds_stride + o];
+            if (p.act == 1) val = lrelu_sqrt2(val);
+            else if (p.act == 2) val = fmaxf(val, 0.f);
             const long long oidx = (((long long)rb * p.Ho + py) * p.Wo + px) * p.Cout + o;
             if (p.res) val += (float)p.res[oidx];
             val *= p.out_scale;
@@ -172,6 +174,12 @@ const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
 // ---------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
+    if (p.batch > 1) {   // batched problems (BigGAN self-attention): one z-slice per problem
+        p.a += (long long)blockIdx.z * p.a_bs;
+        p.w += (long long)blockIdx.z * p.w_bs;
+        if (p.out16) p.out16 += (long long)blockIdx.z * p.o_bs;
+        if (p.out32) p.out32 += (long long)blockIdx.z * p.o_bs;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const int mw = blockIdx.x * 128 + wave * 32;
@@ -223,14 +231,14 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
 }
 
 const char* launch_gemm_direct(const GemmParams& p, hipStream_t st) {
-    const unsigned gx = (unsigned)((p.M + 127) / 128);
+    const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
     if (p.N > 64) {
-        hipLaunchKernelGGL(gemm_direct_kernel<4>, dim3(gx, (p.N + 127) / 128), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_direct_kernel<4>, dim3(gx, (p.N + 127) / 128, gz), dim3(256), 0, st, p);
         return "gemm_direct_kernel<4>";
     } else if (p.N > 32) {
-        hipLaunchKernelGGL(gemm_direct_kernel<2>, dim3(gx, 1), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_direct_kernel<2>, dim3(gx, 1, gz), dim3(256), 0, st, p);
         return "gemm_direct_kernel<2>";
     }
-    hipLaunchKernelGGL(gemm_direct_kernel<1>, dim3(gx, 1), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(gemm_direct_kernel<1>, dim3(gx, 1, gz), dim3(256), 0, st, p);
     return "gemm_direct_kernel<1>";
 }

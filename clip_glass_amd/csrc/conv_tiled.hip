@@ -235,9 +235,17 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] += bb[q];
                     }
-                    if (p.act) {
+                    if (p.shift) {
+                        const f4 sh4 = *(const f4*)(p.shift + (long long)b * p.ds_stride + o);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += sh4[q];
+                    }
+                    if (p.act == 1) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                     }
                     const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
                     if (p.res) {

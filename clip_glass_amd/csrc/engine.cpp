@@ -18,51 +18,6 @@ void glass_set_error(const std::string& s) { g_err = s; }
 extern "C" const char* glass_last_error(void) { return g_err.c_str(); }
 extern "C" const char* glass_version(void) { return "clip-glass-amd 0.1 (gfx950)"; }
 
-#define REQUIRE(cond, code, msg)          \
-    do {                                  \
-        if (!(cond)) {                    \
-            glass_set_error(msg);         \
-            return code;                  \
-        }                                 \
-    } while (0)
-
-// ------------------------------------------------------------------------------------
-// allocation / upload helpers
-// ------------------------------------------------------------------------------------
-template <typename T>
-static int dev_alloc(glass_engine* e, T** p, size_t n) {
-    void* q = nullptr;
-    hipError_t err = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-    if (err != hipSuccess) {
-        glass_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(err));
-        return GLASS_ERR_NOMEM;
-    }
-    e->allocs.push_back(q);
-    *p = (T*)q;
-    return GLASS_OK;
-}
-template <typename T>
-static int upload(glass_engine* e, T** p, const std::vector<T>& v) {
-    int rc = dev_alloc(e, p, v.size());
-    if (rc) return rc;
-    GLASS_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    return GLASS_OK;
-}
-
-static const HostTensor* find(glass_engine* e, const std::string& name) {
-    auto it = e->host.find(name);
-    return it == e->host.end() ? nullptr : &it->second;
-}
-#define GET(var, name)                                                            \
-    const HostTensor* var = find(e, name);                                        \
-    REQUIRE(var != nullptr, GLASS_ERR_STATE, std::string("missing tensor: ") + (name))
-
-static size_t numel(const HostTensor* t) {
-    size_t n = 1;
-    for (auto d : t->dims) n *= (size_t)d;
-    return n;
-}
-
 // ------------------------------------------------------------------------------------
 // weight repacking (reference layouts -> kernel layouts)
 // ------------------------------------------------------------------------------------
@@ -118,18 +73,18 @@ int glass_fold_upconv(const float* W, int cout, int cin, std::vector<_Float16>& 
     return 0;
 }
 
-static std::vector<_Float16> to_half(const float* p, size_t n, float scale = 1.f) {
+std::vector<_Float16> to_half(const float* p, size_t n, float scale) {
     std::vector<_Float16> v(n);
     for (size_t i = 0; i < n; ++i) v[i] = (_Float16)(p[i] * scale);
     return v;
 }
-static std::vector<float> scaled(const float* p, size_t n, float scale) {
+std::vector<float> scaled(const float* p, size_t n, float scale) {
     std::vector<float> v(n);
     for (size_t i = 0; i < n; ++i) v[i] = p[i] * scale;
     return v;
 }
 // W[N][K] * coef -> Wt[K][N]
-static std::vector<float> transposed(const float* W, int N, int K, float coef) {
+std::vector<float> transposed(const float* W, int N, int K, float coef) {
     std::vector<float> v((size_t)N * K);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) v[(size_t)k * N + n] = W[(size_t)n * K + k] * coef;
@@ -158,13 +113,38 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
                 cfg->clip_res % cfg->clip_patch == 0 && (3 * cfg->clip_patch * cfg->clip_patch) % 16 == 0,
             GLASS_ERR_ARG, "unsupported CLIP geometry (head dim must be 64)");
     REQUIRE(cfg->noise_mode >= 0 && cfg->noise_mode <= 2, GLASS_ERR_ARG, "noise_mode must be 0,1,2");
+    int bg_res = 0;
+    if (cfg->generator == GLASS_GEN_BIGGAN_DEEP) {
+        REQUIRE(cfg->n_blocks == 0 && !cfg->use_discriminator && cfg->n_obj == 1, GLASS_ERR_ARG,
+                "BigGAN-deep: n_blocks must be 0, no discriminator, n_obj 1 (config.py:31-74)");
+        REQUIRE(cfg->bg_n_layers > 0 && cfg->bg_n_layers <= GLASS_MAX_BG_LAYERS, GLASS_ERR_ARG, "bg_n_layers out of range");
+        REQUIRE(cfg->bg_ch > 0 && cfg->bg_ch % 32 == 0 && cfg->bg_z_dim > 0 && cfg->bg_z_dim % 4 == 0 && cfg->bg_num_classes > 0,
+                GLASS_ERR_ARG, "BigGAN-deep: bad channel_width / z_dim / num_classes");
+        REQUIRE(cfg->latent_size == cfg->bg_z_dim + cfg->bg_num_classes, GLASS_ERR_ARG,
+                "BigGAN-deep: latent_size must be z_dim + num_classes (latent.py:16-18)");
+        REQUIRE(cfg->bg_n_stats >= 2 && cfg->bg_eps > 0.f && cfg->bg_truncation > 0.f && cfg->bg_truncation <= 1.f,
+                GLASS_ERR_ARG, "BigGAN-deep: bad n_stats / eps / truncation");
+        bg_res = 4;
+        for (int i = 0; i < cfg->bg_n_layers; ++i) {
+            const int cin = cfg->bg_ch * cfg->bg_layers[i][1], cout = cfg->bg_ch * cfg->bg_layers[i][2];
+            REQUIRE(cin > 0 && cout > 0 && (cin == cout || cin == 2 * cout), GLASS_ERR_ARG,
+                    "BigGAN-deep GenBlock: out channels must equal in or in/2 (channel-drop skip)");
+            REQUIRE(cin % 128 == 0 && cout % 32 == 0, GLASS_ERR_ARG,
+                    "BigGAN-deep GenBlock: in/4 and out channels must be multiples of 32");
+            bg_res <<= (cfg->bg_layers[i][0] ? 1 : 0);
+        }
+        REQUIRE(cfg->bg_layers[0][1] == 16 && cfg->bg_layers[cfg->bg_n_layers - 1][2] == 1, GLASS_ERR_ARG,
+                "BigGAN-deep: first GenBlock takes 16*ch channels, last produces ch");
+    } else {
+        REQUIRE(cfg->generator == GLASS_GEN_STYLEGAN2, GLASS_ERR_ARG, "unknown generator kind");
+    }
     int ndev = 0;
     GLASS_HIP(hipGetDeviceCount(&ndev));
     REQUIRE(cfg->device >= 0 && cfg->device < ndev, GLASS_ERR_ARG, "no such HIP device");
     GLASS_HIP(hipSetDevice(cfg->device));
     glass_engine* e = new glass_engine();
     e->cfg = *cfg;
-    e->R = cfg->n_blocks > 0 ? 4 << (cfg->n_blocks - 1) : 0;
+    e->R = cfg->n_blocks > 0 ? 4 << (cfg->n_blocks - 1) : bg_res;
     int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (16 / cfg->batch_size) * cfg->batch_size);
     chunk = std::min(chunk, cfg->max_pop);
     if (chunk % cfg->batch_size != 0) {
@@ -702,6 +682,7 @@ extern "C" int glass_engine_finalize(glass_engine* e) {
         if ((rc = finalize_generator(e))) return rc;
         if (e->cfg.use_discriminator && (rc = finalize_discriminator(e))) return rc;
     }
+    if (e->cfg.generator == GLASS_GEN_BIGGAN_DEEP && (rc = glass_biggan_finalize(e))) return rc;
     if ((rc = finalize_gpt2(e))) return rc;
     if ((rc = finalize_clip(e))) return rc;
     if ((rc = alloc_buffers(e))) return rc;
@@ -723,39 +704,7 @@ extern "C" int glass_engine_set_target(glass_engine* e, const float* feat, int32
 // ------------------------------------------------------------------------------------
 // profiling scopes (hipEvent pair per launch when enabled)
 // ------------------------------------------------------------------------------------
-struct Prof {
-    glass_engine* e;
-    bool on;
-    ProfEvent pe;
-    Prof(glass_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
-        if (on && !e->prof_filter.empty()) {   // only launches whose kernel symbol (as of the previous pass) matches
-            auto it = e->tag_kernel.find(name);
-            on = it != e->tag_kernel.end() && it->second.find(e->prof_filter) != std::string::npos;
-        }
-        if (!on) return;
-        auto get = [&]() {
-            if (e->event_next == e->event_pool.size()) {
-                hipEvent_t ev;
-                hipEventCreate(&ev);
-                e->event_pool.push_back(ev);
-            }
-            return e->event_pool[e->event_next++];
-        };
-        pe.name = name;
-        pe.flops = flops;
-        pe.bytes = bytes;
-        pe.e0 = get();
-        pe.e1 = get();
-        hipEventRecord(pe.e0, e->cur);
-    }
-    ~Prof() {
-        if (!on) return;
-        hipEventRecord(pe.e1, e->cur);
-        e->prof_events.push_back(pe);
-    }
-};
-
-static void collect_profile(glass_engine* e) {
+void collect_profile(glass_engine* e) {
     std::map<std::string, glass_prof_row> rows;
     std::vector<std::string> order;
     for (auto& pe : e->prof_events) {
@@ -780,7 +729,7 @@ static void collect_profile(glass_engine* e) {
     e->event_next = 0;
 }
 
-static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
+void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
     Prof pr(e, tag, flops, bytes);
     const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
     if (!k) k = launch_conv_tiled(p, e->cur);
@@ -788,7 +737,7 @@ static void run_conv(glass_engine* e, const ConvParams& p, const char* tag, doub
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
     if (e->profiling) e->tag_kernel[tag] = k;
 }
-static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
+void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
     Prof pr(e, tag, 2.0 * p.M * p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N));
     const char* k = launch_gemm_tiled(p, e->cur);
     if (!k) k = launch_gemm_direct(p, e->cur);
@@ -796,7 +745,7 @@ static void run_gemm(glass_engine* e, const GemmParams& p, const char* tag) {
     if (e->profiling) e->tag_kernel[tag] = k;
 }
 
-static ConvParams conv_defaults() {
+ConvParams conv_defaults() {
     ConvParams p;
     memset(&p, 0, sizeof p);
     p.out_scale = 1.f;
@@ -1020,7 +969,7 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     }
 }
 
-static void run_clip(glass_engine* e, int P) {
+void run_clip(glass_engine* e, int P) {
     const glass_config& c = e->cfg;
     const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, M = P * T;
     GemmParams g;
@@ -1074,18 +1023,52 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     REQUIRE(P > 0 && P <= c.max_pop, GLASS_ERR_ARG, "population size out of range (max_pop)");
     REQUIRE(P % c.batch_size == 0, GLASS_ERR_ARG,
             "population size must be a multiple of batch_size (reference asserts: models.py:112)");
-    REQUIRE(e->cfg.n_blocks > 0, GLASS_ERR_STATE, "this engine was created without a GAN (n_blocks = 0)");
+    const bool biggan = c.generator == GLASS_GEN_BIGGAN_DEEP;
+    REQUIRE(e->cfg.n_blocks > 0 || biggan, GLASS_ERR_STATE, "this engine was created without a GAN (n_blocks = 0)");
     if (out_F) REQUIRE(e->has_target, GLASS_ERR_STATE, "set_target() first");
     GLASS_HIP(hipSetDevice(c.device));
     const int L = c.latent_size;
     memcpy(e->h_pinned, latents, (size_t)P * L * sizeof(float));
     GLASS_HIP(hipEventRecord(e->ev0, e->cur));
     GLASS_HIP(hipMemcpyAsync(e->d_z, e->h_pinned, (size_t)P * L * sizeof(float), hipMemcpyHostToDevice, e->cur));
+    const int ps = c.clip_patch, G = c.clip_res / ps;
+    const size_t img_elems = (size_t)3 * e->R * e->R;
+    if (biggan) {
+        // BigGAN-deep (models.py:75-86): no noise inputs, no discriminator; candidates are independent, so the
+        // reference's minibatch loop has no semantic effect and the population is walked in engine chunks.
+        int rc = glass_biggan_prepare(e, P);
+        if (rc) return rc;
+        for (int c0 = 0; c0 < P; c0 += e->chunk) {
+            const int B = std::min(e->chunk, P - c0);
+            float* y = e->ybuf[0];
+            if ((rc = glass_biggan_chunk(e, c0, B, y))) return rc;
+            if (images) {
+                launch_finalize_image(y, e->d_img, (long long)B * img_elems, e->cur);
+                GLASS_HIP(hipMemcpyAsync(images + (size_t)c0 * img_elems, e->d_img, (size_t)B * img_elems * sizeof(float),
+                                         hipMemcpyDeviceToHost, e->cur));
+            }
+            if (out_F) {
+                Prof pr(e, "clip.resize", 0, B * (16.0 * c.clip_res * c.clip_res * 3 + 2.0 * 3 * c.clip_res * c.clip_res));
+                launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps, e->cur);
+            }
+        }
+        if (out_F) {
+            run_clip(e, P);
+            launch_assemble_F(e->d_sim, e->d_dis, P, c.n_obj, e->d_F, e->cur);
+            GLASS_HIP(hipMemcpyAsync(e->h_pinned, e->d_F, (size_t)P * c.n_obj * sizeof(float), hipMemcpyDeviceToHost, e->cur));
+        }
+        GLASS_HIP(hipEventRecord(e->ev1, e->cur));
+        GLASS_HIP(hipStreamSynchronize(e->cur));
+        GLASS_HIP(hipGetLastError());
+        GLASS_HIP(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+        if (out_F) memcpy(out_F, e->h_pinned, (size_t)P * c.n_obj * sizeof(float));
+        e->last_P = P;
+        if (e->profiling) collect_profile(e);
+        return GLASS_OK;
+    }
     run_styles(e, P);
     int rc = upload_noise(e, P, generation, first_mb, noise);
     if (rc) return rc;
-    const int ps = c.clip_patch, G = c.clip_res / ps;
-    const size_t img_elems = (size_t)3 * e->R * e->R;
     const bool want_d = out_F && c.use_discriminator && c.n_obj == 2;
     const int n = c.n_blocks;
     const int nlow = std::min(n, e->n_low);           // G blocks 0..nlow-1 run for the whole population

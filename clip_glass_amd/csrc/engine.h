@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -53,6 +54,33 @@ struct ClipBlock {
     float *b_qkv, *b_out, *b_fc, *b_proj;
 };
 
+// BigGAN-deep generator (biggan.cpp)
+struct BgBlock {   // GenBlock: bn0-relu-conv1x1 / bn1-relu-[up]-conv3x3 / bn2-relu-conv3x3 / bn3-relu-conv1x1 + skip
+    int cin, cout, mid, up, res_in;
+    int bn_off[4];           // column offsets of the four batch norms in the affine tables
+    half_t* w[4] = {nullptr, nullptr, nullptr, nullptr};   // [ks*ks][cout][cin] fp16, spectral norm folded
+    float* b3 = nullptr;     // conv_3 bias (the other biases are folded into the next BN's shift)
+};
+struct BgState {
+    int R = 0, Ctot = 0, zd = 0, nc = 0, c0 = 0;
+    float *et = nullptr, *genz_wt = nullptr, *genz_b = nullptr;
+    float *bn_wt = nullptr, *bn_bias = nullptr, *bn_inv_std = nullptr, *bn_mean = nullptr, *bn_prebias = nullptr;
+    std::vector<BgBlock> blocks;
+    int attn_before = -1, attn_C = 0, attn_res = 0;
+    half_t *attn_w_tpg = nullptr, *attn_w_o = nullptr;
+    int final_bn_off = 0, rgb_cpad = 32;
+    half_t* rgb_w = nullptr;
+    float* rgb_b = nullptr;
+    // activations
+    float *cond = nullptr, *tab = nullptr, *h32 = nullptr, *a_S = nullptr;
+    half_t *x[2] = {nullptr, nullptr}, *t0 = nullptr, *t1 = nullptr, *t1u = nullptr, *t2 = nullptr, *t3 = nullptr, *r = nullptr;
+    half_t *a_T = nullptr, *a_theta = nullptr, *a_phi = nullptr, *a_gT = nullptr, *a_P = nullptr, *a_O = nullptr;
+};
+int glass_biggan_finalize(glass_engine* e);       // weights -> device layouts + activation buffers
+int glass_biggan_prepare(glass_engine* e, int P); // cond vectors + batch-norm tables for the population in d_z
+// synthesize candidates [c0, c0 + B) -> planar fp32 RGB in (-1, 1) at `y` [B][3][R][R]
+int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y);
+
 struct ProfEvent {
     std::string name;
     double flops, bytes;
@@ -86,6 +114,7 @@ struct glass_engine {
     int demod_max_n = 0;
     std::vector<GConv> gconv;
     std::vector<GRgb> grgb;
+    BgState bg;
     // ---- D ----
     float *d_frgb_w = nullptr, *d_frgb_b = nullptr;
     std::vector<DBlock> dblk;
@@ -137,6 +166,96 @@ struct glass_engine {
     std::vector<hipEvent_t> event_pool;
     size_t event_next = 0;
 };
+
+// ------------------------------------------------------------------------------------
+// helpers shared by engine.cpp and biggan.cpp
+// ------------------------------------------------------------------------------------
+#define REQUIRE(cond, code, msg)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            glass_set_error(msg);         \
+            return code;                  \
+        }                                 \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// allocation / upload helpers
+// ------------------------------------------------------------------------------------
+template <typename T>
+inline int dev_alloc(glass_engine* e, T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (err != hipSuccess) {
+        glass_set_error(std::string("hipMalloc failed: ") + hipGetErrorString(err));
+        return GLASS_ERR_NOMEM;
+    }
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return GLASS_OK;
+}
+template <typename T>
+inline int upload(glass_engine* e, T** p, const std::vector<T>& v) {
+    int rc = dev_alloc(e, p, v.size());
+    if (rc) return rc;
+    GLASS_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return GLASS_OK;
+}
+
+inline const HostTensor* find(glass_engine* e, const std::string& name) {
+    auto it = e->host.find(name);
+    return it == e->host.end() ? nullptr : &it->second;
+}
+#define GET(var, name)                                                            \
+    const HostTensor* var = find(e, name);                                        \
+    REQUIRE(var != nullptr, GLASS_ERR_STATE, std::string("missing tensor: ") + (name))
+
+inline size_t numel(const HostTensor* t) {
+    size_t n = 1;
+    for (auto d : t->dims) n *= (size_t)d;
+    return n;
+}
+
+// profiling scope (hipEvent pair per launch when enabled)
+struct Prof {
+    glass_engine* e;
+    bool on;
+    ProfEvent pe;
+    Prof(glass_engine* e_, const char* name, double flops, double bytes) : e(e_), on(e_->profiling) {
+        if (on && !e->prof_filter.empty()) {   // only launches whose kernel symbol (as of the previous pass) matches
+            auto it = e->tag_kernel.find(name);
+            on = it != e->tag_kernel.end() && it->second.find(e->prof_filter) != std::string::npos;
+        }
+        if (!on) return;
+        auto get = [&]() {
+            if (e->event_next == e->event_pool.size()) {
+                hipEvent_t ev;
+                hipEventCreate(&ev);
+                e->event_pool.push_back(ev);
+            }
+            return e->event_pool[e->event_next++];
+        };
+        pe.name = name;
+        pe.flops = flops;
+        pe.bytes = bytes;
+        pe.e0 = get();
+        pe.e1 = get();
+        hipEventRecord(pe.e0, e->cur);
+    }
+    ~Prof() {
+        if (!on) return;
+        hipEventRecord(pe.e1, e->cur);
+        e->prof_events.push_back(pe);
+    }
+};
+
+void collect_profile(glass_engine* e);
+void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes);
+void run_gemm(glass_engine* e, const GemmParams& p, const char* tag);
+ConvParams conv_defaults();
+void run_clip(glass_engine* e, int P);
+std::vector<_Float16> to_half(const float* p, size_t n, float scale = 1.f);
+std::vector<float> scaled(const float* p, size_t n, float scale);
+std::vector<float> transposed(const float* W, int N, int K, float coef);
 
 // engine_ops.cpp helpers shared with the diagnostic op ABI
 int glass_fold_upconv(const float* W, int cout, int cin, std::vector<_Float16>& out);  // [9][4*cout][cin]

@@ -11,6 +11,12 @@
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
+    if (p.batch > 1) {   // batched problems (BigGAN self-attention): one z-slice per problem
+        p.a += (long long)blockIdx.z * p.a_bs;
+        p.w += (long long)blockIdx.z * p.w_bs;
+        if (p.out16) p.out16 += (long long)blockIdx.z * p.o_bs;
+        if (p.out32) p.out32 += (long long)blockIdx.z * p.o_bs;
+    }
     constexpr int NJ = BN / 64;                  // 32-wide n tiles per wave
     constexpr int NVA = 128 * 8, NVB = BN * 8;   // 16-byte vectors per stage
     constexpr int NA = NVA / 256, NB = NVB / 256;
@@ -118,13 +124,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
 
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     if (p.K % 64 != 0 || p.ldo % 4 != 0 || p.M < 64) return nullptr;
-    const unsigned gx = (unsigned)((p.M + 127) / 128);
+    const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
     if (p.N % 128 == 0) {
-        hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<128>";
     }
     if (p.N % 64 == 0) {
-        hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(gx, p.N / 64), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(gx, p.N / 64, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<64>";
     }
     return nullptr;

@@ -65,6 +65,19 @@ void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, in
 void launch_cosine(const float* feat, const float* target, int P, int D, float* sim, hipStream_t st);
 void launch_assemble_F(const float* sim, const float* dis, int P, int n_obj, float* F, hipStream_t st);
 
+// --- BigGAN-deep glue (biggan_kernels.hip) ---------------------------------------------------------
+void launch_bg_cond(const float* x, int P, int L, int zd, int nc, const float* et, float* cond, hipStream_t st);
+void launch_bg_bn_tables(float* tab, int P, int C, const float* inv_std, const float* mean, const float* prebias,
+                         hipStream_t st);
+void launch_bg_to_half(const float* x, half_t* y, long long n, hipStream_t st);
+void launch_bg_affine_relu(const half_t* x, int B, long long hw, int C, const float* A, const float* S, int tstride,
+                           half_t* y, hipStream_t st);
+void launch_bg_gather(const half_t* x, int B, int H, int W, int C, int take, int up, half_t* y, hipStream_t st);
+void launch_bg_attn_split(const half_t* T, int B, int H, int W, int c8, int c2, half_t* theta, half_t* phi, half_t* gT,
+                          hipStream_t st);
+void launch_bg_softmax(const float* S, long long rows, int n, half_t* Pm, hipStream_t st);
+void launch_bg_rgb_tanh(const half_t* x, int B, long long hw, int C, float* y, hipStream_t st);
+
 // --- GPT-2 (fp32, gpt2.hip) ----------------------------------------------------------
 void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
                        hipStream_t st);

@@ -13,6 +13,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libglass.so")
 MAX_BLOCKS = 12
+MAX_BG_LAYERS = 16
+GEN_STYLEGAN2, GEN_BIGGAN_DEEP = 0, 1
 
 
 class GlassConfig(C.Structure):
@@ -22,7 +24,11 @@ class GlassConfig(C.Structure):
                 ("max_pop", C.c_int32), ("chunk", C.c_int32),
                 ("clip_width", C.c_int32), ("clip_layers", C.c_int32), ("clip_heads", C.c_int32),
                 ("clip_patch", C.c_int32), ("clip_res", C.c_int32), ("clip_embed", C.c_int32),
-                ("noise_mode", C.c_int32), ("noise_seed", C.c_uint64)]
+                ("noise_mode", C.c_int32), ("noise_seed", C.c_uint64),
+                ("generator", C.c_int32), ("bg_ch", C.c_int32), ("bg_z_dim", C.c_int32), ("bg_num_classes", C.c_int32),
+                ("bg_n_layers", C.c_int32), ("bg_layers", (C.c_int32 * 3) * MAX_BG_LAYERS),
+                ("bg_attention_pos", C.c_int32), ("bg_n_stats", C.c_int32), ("bg_eps", C.c_float),
+                ("bg_truncation", C.c_float)]
 
 
 class GlassNoise(C.Structure):
@@ -100,10 +106,25 @@ class Engine:
 
     def __init__(self, channels, latent_size=512, mapping_layers=8, batch_size=4, use_discriminator=True,
                  n_obj=2, max_pop=64, chunk=0, clip=(768, 12, 12, 32, 224, 512), noise_mode=1, noise_seed=0,
-                 mbstd_group=4, device=0):
+                 mbstd_group=4, device=0, biggan=None):
+        """`biggan` = dict(layers=[(up, in_mult, out_mult), ...], attention_pos, ch, z_dim, num_classes, n_stats, eps,
+        truncation) selects the BigGAN-deep generator (channels must then be empty, no discriminator)."""
         self.lib = load_library()
         cfg = GlassConfig()
         cfg.device = device
+        if biggan is not None:
+            layers = list(biggan["layers"])
+            cfg.generator = GEN_BIGGAN_DEEP
+            cfg.bg_ch, cfg.bg_z_dim = int(biggan.get("ch", 128)), int(biggan.get("z_dim", 128))
+            cfg.bg_num_classes = int(biggan.get("num_classes", 1000))
+            cfg.bg_n_layers = len(layers)
+            for i, (up, a, b) in enumerate(layers):
+                cfg.bg_layers[i][0], cfg.bg_layers[i][1], cfg.bg_layers[i][2] = int(up), int(a), int(b)
+            cfg.bg_attention_pos = int(biggan.get("attention_pos", 8))
+            cfg.bg_n_stats, cfg.bg_eps = int(biggan.get("n_stats", 51)), float(biggan.get("eps", 1e-4))
+            cfg.bg_truncation = float(biggan.get("truncation", 1.0))
+            latent_size = cfg.bg_z_dim + cfg.bg_num_classes
+            channels, use_discriminator, n_obj, noise_mode = [], False, 1, 0
         cfg.n_blocks = len(channels)
         for i, c in enumerate(channels):  # LOW -> HIGH resolution
             cfg.channels[i] = int(c)
@@ -115,6 +136,8 @@ class Engine:
         self.cfg = cfg
         self.channels = list(channels)
         self.res = 4 << (len(channels) - 1) if channels else 0
+        if biggan is not None:
+            self.res = 4 << sum(1 for l in biggan["layers"] if l[0])
         self.n_noise = 1 + 2 * (len(channels) - 1) if channels else 0
         self._h = C.c_void_p()
         _check(self.lib, self.lib.glass_engine_create(C.byref(cfg), C.byref(self._h)))

@@ -269,3 +269,94 @@ def make_target(feats, seed=0, spread=0.6):
     r = normal(seed, "target", f0.shape).astype(np.float64)
     t = f0 / np.linalg.norm(f0) + spread * r / np.linalg.norm(r)
     return t.astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# BigGAN-deep (config C3).  Keys are pytorch-pretrained-biggan's state-dict keys under "biggan."
+# (spectral-norm modules hold weight_orig / weight_u / weight_v); layer tables are the released
+# biggan-deep-128/256/512 configs.
+# --------------------------------------------------------------------------
+BIGGAN_LAYERS = {
+    128: [(0, 16, 16), (1, 16, 16), (0, 16, 16), (1, 16, 8), (0, 8, 8), (1, 8, 4), (0, 4, 4), (1, 4, 2), (0, 2, 2), (1, 2, 1)],
+    256: [(0, 16, 16), (1, 16, 16), (0, 16, 16), (1, 16, 8), (0, 8, 8), (1, 8, 8), (0, 8, 8), (1, 8, 4), (0, 4, 4), (1, 4, 2),
+          (0, 2, 2), (1, 2, 1)],
+    512: [(0, 16, 16), (1, 16, 16), (0, 16, 16), (1, 16, 8), (0, 8, 8), (1, 8, 8), (0, 8, 8), (1, 8, 4), (0, 4, 4), (1, 4, 2),
+          (0, 2, 2), (1, 2, 1), (0, 1, 1), (1, 1, 1)],
+}
+
+
+def biggan_spec(layers, attention_pos=8, ch=128, z_dim=128, num_classes=1000, n_stats=51):
+    """(name, shape, kind) of BigGAN-deep's generator; kind "sn" = spectral-normalised weight_orig
+    (make_biggan_state adds the matching weight_u / weight_v)."""
+    g = "biggan.generator."
+    cd = 2 * z_dim
+    spec = [("biggan.embeddings.weight", (z_dim, num_classes), ("n", 1.0)),
+            (g + "gen_z.weight_orig", (16 * 16 * ch, cd), "sn"), (g + "gen_z.bias", (16 * 16 * ch,), ("n", 1.0))]
+
+    def bn(p, c, conditional=True):
+        out = [(p + ".running_means", (n_stats, c), ("n", 0.3)), (p + ".running_vars", (n_stats, c), "var")]
+        if conditional:
+            out += [(p + ".scale.weight_orig", (c, cd), "sn"), (p + ".offset.weight_orig", (c, cd), "sn")]
+        else:
+            out += [(p + ".weight", (c,), ("ln_w", 0.2)), (p + ".bias", (c,), ("n", 0.2))]
+        return out
+
+    m = 0
+    for i, (up, cin, cout) in enumerate(layers):
+        if i == attention_pos:
+            p = g + "layers.%d" % m
+            c = ch * cin
+            spec += [(p + ".snconv1x1_theta.weight_orig", (c // 8, c, 1, 1), "sn"),
+                     (p + ".snconv1x1_phi.weight_orig", (c // 8, c, 1, 1), "sn"),
+                     (p + ".snconv1x1_g.weight_orig", (c // 2, c, 1, 1), "sn"),
+                     (p + ".snconv1x1_o_conv.weight_orig", (c, c // 2, 1, 1), "sn"),
+                     (p + ".gamma", (1,), ("gamma", 0.0))]
+            m += 1
+        p = g + "layers.%d" % m
+        ci, co = ch * cin, ch * cout
+        mid = ci // 4
+        for k, (a, b, ks) in enumerate([(ci, mid, 1), (mid, mid, 3), (mid, mid, 3), (mid, co, 1)]):
+            spec += bn(p + ".bn_%d" % k, a)
+            spec += [(p + ".conv_%d.weight_orig" % k, (b, a, ks, ks), "sn"), (p + ".conv_%d.bias" % k, (b,), ("n", 0.2))]
+        m += 1
+    spec += bn(g + "bn", ch, conditional=False)
+    spec += [(g + "conv_to_rgb.weight_orig", (ch, ch, 3, 3), "sn"), (g + "conv_to_rgb.bias", (ch,), ("n", 0.2))]
+    return spec
+
+
+def make_biggan_state(spec, seed=0, power_iters=8):
+    """Synthetic BigGAN-deep state: Gaussian weight_orig with (u, v) converged by power iteration, as a
+    trained checkpoint holds them (random u, v would make weight_orig / sigma explode)."""
+    sd = OrderedDict()
+    for name, shape, kind in spec:
+        if kind == "sn":
+            w = normal(seed, name, shape, 1.0)
+            wm = w.reshape(shape[0], -1).astype(np.float64)
+            u = normal(seed, name + "/u", (shape[0],)).astype(np.float64)
+            v = None
+            for _ in range(power_iters):
+                v = wm.T @ u
+                v /= np.linalg.norm(v) + 1e-12
+                u = wm @ v
+                u /= np.linalg.norm(u) + 1e-12
+            sd[name] = w
+            base = name[:-len("weight_orig")]
+            sd[base + "weight_u"] = u.astype(np.float32)
+            sd[base + "weight_v"] = v.astype(np.float32)
+        elif kind == "var":
+            sd[name] = (0.3 + 0.5 * _rng(seed, name).random(shape, dtype=np.float32)).astype(np.float32)
+        elif isinstance(kind, tuple) and kind[0] == "gamma":
+            sd[name] = np.asarray([0.7], dtype=np.float32)   # released checkpoints hold a learned non-zero gamma
+        else:
+            sd[name] = make_tensor(seed, name, shape, kind)
+    return sd
+
+
+def biggan_population(seed, pop, dim_z=128, num_classes=1000, p_class=5 / 1000):
+    """Rows [z | class bits] as the reference samples them (operators.py:15,47): truncnorm(-2,2) and
+    Bernoulli(5/1000) bits; float64 like pymoo's mixed-variable population after `.astype(float)`."""
+    from scipy.stats import truncnorm
+    rs = np.random.RandomState(seed)
+    z = truncnorm.rvs(-2, 2, size=(pop, dim_z), random_state=rs).astype(np.float32)
+    bits = rs.random_sample((pop, num_classes)) < p_class
+    return np.concatenate([z.astype(np.float64), bits.astype(np.float64)], axis=1)

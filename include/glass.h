@@ -31,6 +31,9 @@ extern "C" {
 #define GLASS_ERR_NOMEM -4
 
 #define GLASS_MAX_BLOCKS 12
+#define GLASS_MAX_BG_LAYERS 16
+#define GLASS_GEN_STYLEGAN2 0
+#define GLASS_GEN_BIGGAN_DEEP 1
 
 typedef struct glass_engine glass_engine;
 
@@ -54,6 +57,20 @@ typedef struct glass_config {
     int32_t clip_width, clip_layers, clip_heads, clip_patch, clip_res, clip_embed; /* 768,12,12,32,224,512 */
     int32_t noise_mode;           /* 0 none, 1 device Philox N(0,1) planes, 2 caller-provided planes */
     uint64_t noise_seed;
+    /* --- BigGAN-deep generator (configs DeepMindBigGAN256/512, config.py:31-74; models.py:64-86 calls
+     * pytorch-pretrained-biggan's BigGAN.forward(z, class_label, truncation)).  With generator =
+     * GLASS_GEN_BIGGAN_DEEP: n_blocks = 0, use_discriminator = 0, latent_size = bg_z_dim + bg_num_classes
+     * (one population row = [z | class bits], latent.py:16-18), output = 4 * 2^(#up layers) px. */
+    int32_t generator;            /* GLASS_GEN_STYLEGAN2 (0, default) | GLASS_GEN_BIGGAN_DEEP */
+    int32_t bg_ch;                /* channel_width (128) */
+    int32_t bg_z_dim;             /* config.dim_z (128) */
+    int32_t bg_num_classes;       /* config.num_classes (1000) */
+    int32_t bg_n_layers;          /* GenBlocks (14 for biggan-deep-512) */
+    int32_t bg_layers[GLASS_MAX_BG_LAYERS][3]; /* (up_sample, in_mult, out_mult) per GenBlock */
+    int32_t bg_attention_pos;     /* SelfAttn inserted before this GenBlock index (8); -1 = none */
+    int32_t bg_n_stats;           /* stored truncation steps of the batch-norm statistics (51) */
+    float bg_eps;                 /* batch-norm eps (1e-4) */
+    float bg_truncation;          /* config.truncation (1.0): selects / blends the statistics row */
 } glass_config;
 
 /* Caller-provided noise (noise_mode 2): planes[m * n_layers + l] points at a host

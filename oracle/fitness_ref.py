@@ -61,3 +61,16 @@ def evaluate(sd, x, text_features, batch_size, use_discriminator, noise_fn=None,
         else:
             Fv = -sim
     return Fv, np.zeros((np.asarray(x).shape[0]))
+
+
+def evaluate_biggan(sd, x, text_features, dim_z, batch_size, truncation, layers, clip_size=224, detail=None, **kw):
+    """problem.py:14-29 for the DeepMindBigGAN configs (n_obj = 1, no discriminator: config.py:38,60).
+    The generator itself is pytorch-pretrained-biggan's (source absent; oracle/biggan_ref.py, parity unpinned)."""
+    from . import biggan_ref
+    with torch.no_grad():
+        img = biggan_ref.generate(sd, x, dim_z, batch_size, truncation, layers, **kw)
+        sim, feats = clip_similarity(sd, img, text_features, clip_size)
+        if detail is not None:
+            detail["image"] = img
+            detail["features"] = feats
+        return -sim.numpy(), np.zeros((np.asarray(x).shape[0],))

@@ -43,3 +43,33 @@ def noise_planes(name, seed, generation, n_mb, first_mb=0):
 
 
 make_target = synth.make_target
+
+
+# ---- BigGAN-deep (config C3) -------------------------------------------------------------------------
+BIGGAN_CONFIGS = {
+    # 64 px, 6 GenBlocks + attention at 16x16; CLIP-mini at 32 px (resize 64 -> 32)
+    "bg_mini": dict(layers=[(0, 16, 16), (1, 16, 8), (1, 8, 4), (0, 4, 4), (1, 4, 2), (1, 2, 1)], attention_pos=3, ch=64,
+                    z_dim=16, num_classes=24, clip=(128, 2, 2, 8, 32, 64)),
+    # the released biggan-deep-512 geometry + CLIP ViT-B/32
+    "bg512": dict(layers=synth.BIGGAN_LAYERS[512], attention_pos=8, ch=128, z_dim=128, num_classes=1000,
+                  clip=(768, 12, 12, 32, 224, 512)),
+}
+
+
+def make_biggan_state(name, seed=0):
+    c = BIGGAN_CONFIGS[name]
+    sd = synth.make_biggan_state(synth.biggan_spec(c["layers"], c["attention_pos"], c["ch"], c["z_dim"], c["num_classes"]), seed)
+    w, layers, heads, patch, res, emb = c["clip"]
+    sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), seed))
+    return sd
+
+
+def make_biggan_engine(name, sd, *, batch_size=4, max_pop=8, chunk=0, truncation=1.0):
+    from clip_glass_amd.engine import Engine
+    c = BIGGAN_CONFIGS[name]
+    e = Engine([], batch_size=batch_size, max_pop=max_pop, chunk=chunk, clip=c["clip"],
+               biggan=dict(layers=c["layers"], attention_pos=c["attention_pos"], ch=c["ch"], z_dim=c["z_dim"],
+                           num_classes=c["num_classes"], truncation=truncation))
+    e.load_state(sd)
+    e.finalize()
+    return e

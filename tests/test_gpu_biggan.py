@@ -1,0 +1,80 @@
+"""BigGAN-deep path (config C3) through the drop-in C ABI vs the oracle restatement
+(oracle/biggan_ref.py — parity unpinned: pytorch-pretrained-biggan's source is absent, see its header).
+Tolerance on CLIP similarity: 1e-3 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from clip_glass_amd import synth
+from oracle import fitness_ref
+import glass_models as M
+from util import check, diag
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(sd):
+    return {k: torch.as_tensor(v) for k, v in sd.items()}
+
+
+def _run_case(name, P, batch_size, chunk=0, seed=0, truncation=1.0):
+    c = M.BIGGAN_CONFIGS[name]
+    sd = M.make_biggan_state(name, seed)
+    x = synth.biggan_population(seed + 1, P, c["z_dim"], c["num_classes"])
+    x[0, :c["z_dim"]] *= 3.0   # exercise the clip to [-2, 2] (latent.py:21)
+    detail = {}
+    kw = dict(attention_pos=c["attention_pos"], ch=c["ch"])
+    fitness_ref.evaluate_biggan(_t(sd), x, np.ones(c["clip"][5], np.float32), c["z_dim"], batch_size, truncation,
+                                c["layers"], clip_size=c["clip"][4], detail=detail, **kw)
+    feats = detail["features"].numpy()
+    target = M.make_target(feats)
+    sim_o = torch.cosine_similarity(detail["features"], torch.tensor(target)[None]).numpy()
+    e = M.make_biggan_engine(name, sd, batch_size=batch_size, max_pop=P, chunk=chunk, truncation=truncation)
+    e.set_target(target)
+    Fe = e.evaluate(x)
+    det = e.details(P)
+    img = e.generate(x)
+    e.close()
+    tag = "%s P%d bs%d ch%d" % (name, P, batch_size, chunk)
+    ref_img = detail["image"].numpy()
+    rms = float(np.sqrt(((img - ref_img) ** 2).mean()))
+    diag("[biggan] %s image rms err %.3e max %.3e" % (tag, rms, np.abs(img - ref_img).max()))
+    assert rms < 2e-3, "image rms error %.3e" % rms
+    check(tag + " clip features", det["features"], feats, 5e-3)
+    rel = np.abs(det["sim"] - sim_o) / np.abs(sim_o)
+    diag("[biggan] %s sim range [%.3f, %.3f] max rel err %.3e" % (tag, sim_o.min(), sim_o.max(), rel.max()))
+    assert rel.max() < 1e-3, "CLIP similarity relative error %.3e > 1e-3" % rel.max()
+    np.testing.assert_allclose(Fe[:, 0], -det["sim"], rtol=0, atol=1e-7)
+    assert Fe.shape == (P, 1)
+    return Fe
+
+
+def test_biggan_mini_matches_oracle():
+    _run_case("bg_mini", 8, 4)
+
+
+def test_biggan_mini_chunking_invariant():
+    a = _run_case("bg_mini", 8, 4, chunk=4)
+    b = _run_case("bg_mini", 8, 8, chunk=8)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)   # candidates are independent: minibatch / chunk are not semantic
+
+
+def test_biggan_truncation_blend():
+    _run_case("bg_mini", 4, 4, truncation=0.41)
+
+
+def test_biggan_512_two_candidates():
+    _run_case("bg512", 2, 2)
+
+
+def test_biggan_error_paths():
+    from clip_glass_amd.engine import Engine
+    c = M.BIGGAN_CONFIGS["bg_mini"]
+    with pytest.raises(RuntimeError, match="channel-drop"):
+        Engine([], batch_size=4, max_pop=4, clip=c["clip"],
+               biggan=dict(layers=[(0, 16, 16), (1, 16, 4), (1, 4, 1)], attention_pos=-1, ch=64, z_dim=16, num_classes=24))
+    e = Engine([], batch_size=4, max_pop=4, clip=c["clip"],
+               biggan=dict(layers=c["layers"], attention_pos=c["attention_pos"], ch=c["ch"], z_dim=16, num_classes=24))
+    with pytest.raises(RuntimeError, match="missing tensor"):
+        e.finalize()
+    e.close()
