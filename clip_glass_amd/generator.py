@@ -86,12 +86,16 @@ class Generator:
         need_text = getattr(config, "target_features", None) is None
         clip_state, geom = _load_clip_state(config, need_text)
         pop = (pop + config.batch_size - 1) // config.batch_size * config.batch_size
-        self.engine = Engine(self.model.channels[::-1], latent_size=config.dim_z,
-                             mapping_layers=getattr(config, "mapping_layers", 8), batch_size=config.batch_size,
-                             use_discriminator=bool(config.use_discriminator and config.problem_args["n_obj"] == 2),
-                             n_obj=config.problem_args["n_obj"], max_pop=pop, chunk=getattr(config, "chunk", 0),
-                             clip=geom, noise_mode=getattr(config, "noise_mode", 1),
-                             noise_seed=getattr(config, "noise_seed", 0), device=device)
+        if hasattr(self.model, "geometry"):     # BigGAN-deep (models.py:64-86)
+            self.engine = Engine([], batch_size=config.batch_size, max_pop=pop, chunk=getattr(config, "chunk", 0),
+                                 clip=geom, device=device, biggan=self.model.geometry)
+        else:
+            self.engine = Engine(self.model.channels[::-1], latent_size=config.dim_z,
+                                 mapping_layers=getattr(config, "mapping_layers", 8), batch_size=config.batch_size,
+                                 use_discriminator=bool(config.use_discriminator and config.problem_args["n_obj"] == 2),
+                                 n_obj=config.problem_args["n_obj"], max_pop=pop, chunk=getattr(config, "chunk", 0),
+                                 clip=geom, noise_mode=getattr(config, "noise_mode", 1),
+                                 noise_seed=getattr(config, "noise_seed", 0), device=device)
         self.engine.load_state(self.model.state)
         self.engine.load_state(clip_state)
         self.engine.finalize()
@@ -122,7 +126,7 @@ class Generator:
             texts = self.model.generate(*ls())
             self.last_texts = texts
             return -self.clip_similarity_texts(texts)[:, None]
-        (z,) = ls()
+        z = ls.population()
         F = self.engine.evaluate(z, generation=self.generation, first_minibatch=first_minibatch, noise=noise)
         self.generation += 1
         return F
@@ -131,7 +135,7 @@ class Generator:
         """generator.py:29-34 — images [P,3,R,R] float32 after config.norm (biggan_norm); texts for img2txt."""
         if self.config.task == "img2txt":
             return self.model.generate(*ls())
-        (z,) = ls()
+        z = ls.population()
         bs = self.config.batch_size
         P = z.shape[0]
         if minibatch is None:                       # run.py:118: whole input as ONE G call

@@ -21,12 +21,16 @@ class StyleGAN2LatentSpace:
 
     __call__ = forward
 
+    def population(self):
+        return self.z
+
     def state_dict(self):                                           # run.py:101 torch.save(ls.state_dict())
         return {"z": self.z}
 
 
 class DeepMindBigGANLatentSpace:
-    """latent.py:4-24 — config C3; the BigGAN-deep engine path is a later §8 row."""
+    """latent.py:4-24 — config C3.  `forward()` mirrors the reference (clip z, softmax the class bits); the engine
+    takes the raw population rows (`population()`) and applies the same two ops on the device."""
 
     def __init__(self, config):
         self.config = config
@@ -47,6 +51,13 @@ class DeepMindBigGANLatentSpace:
         return z, e / e.sum(axis=1, keepdims=True)
 
     __call__ = forward
+
+    def population(self):
+        """Raw rows [z | class bits] float32 — what glass_engine_evaluate takes for the BigGAN generator."""
+        return np.concatenate([self.z, self.class_labels], axis=1).astype(np.float32)
+
+    def state_dict(self):                                           # run.py:101
+        return {"z": self.z, "class_labels": self.class_labels}
 
 
 class GPT2LatentSpace:

@@ -64,9 +64,47 @@ class StyleGAN2:
 
 
 class DeepMindBigGAN:
+    """models.py:64-86 — BigGAN-deep as released in pytorch-pretrained-biggan (`BigGAN.from_pretrained(config.weights)`).
+
+    `config.weights`: "synthetic[:seed]" (deterministic synthetic weights of the geometry in `config.biggan_geometry`,
+    default = the released biggan-deep-<res> layer table), or a directory / file holding the package's
+    `pytorch_model.bin` state dict (+ optional `config.json`), i.e. what `from_pretrained` caches.  Tensors go to the
+    engine under "biggan." + the package's own key (spectral-norm weight_orig / weight_u / weight_v included)."""
+
     def __init__(self, config):
-        raise NotImplementedError("BigGAN-deep (BASELINE config C3) is a later row of SURVEY §8; "
-                                  "pytorch-pretrained-biggan's source is absent (parity unpinned)")
+        self.config = config
+        w = str(config.weights)
+        geo = dict(getattr(config, "biggan_geometry", {}) or {})
+        res = int(geo.get("output_dim", 512 if "512" in getattr(config, "config", w) + w else 256 if "256" in getattr(config, "config", w) + w else 128))
+        if w.startswith("synthetic"):
+            seed = int(w.split(":")[1]) if ":" in w else 0
+            self.geometry = dict(layers=geo.get("layers", synth.BIGGAN_LAYERS[res]), attention_pos=geo.get("attention_pos", 8),
+                                 ch=geo.get("ch", 128), z_dim=config.dim_z, num_classes=config.num_classes,
+                                 n_stats=geo.get("n_stats", 51), eps=geo.get("eps", 1e-4))
+            g = self.geometry
+            self.state = synth.make_biggan_state(synth.biggan_spec(g["layers"], g["attention_pos"], g["ch"], g["z_dim"],
+                                                                    g["num_classes"], g["n_stats"]), seed)
+        else:
+            path = os.path.join(w, "pytorch_model.bin") if os.path.isdir(w) else w
+            if not os.path.exists(path):
+                print("Weights not found!\nExpected the pytorch-pretrained-biggan checkpoint at %s" % path)
+                sys.exit(1)
+            import json
+            import torch
+            sd = torch.load(path, map_location="cpu")
+            self.state = {"biggan." + k: v.float().numpy() for k, v in sd.items()}
+            cj = os.path.join(os.path.dirname(path), "config.json")
+            pc = json.load(open(cj)) if os.path.exists(cj) else {}
+            layers = [(int(bool(u)), int(a), int(b)) for u, a, b in pc.get("layers", synth.BIGGAN_LAYERS[res])]
+            self.geometry = dict(layers=layers, attention_pos=pc.get("attention_layer_position", 8),
+                                 ch=pc.get("channel_width", 128), z_dim=pc.get("z_dim", config.dim_z),
+                                 num_classes=pc.get("num_classes", config.num_classes), n_stats=pc.get("n_stats", 51),
+                                 eps=pc.get("eps", 1e-4))
+        self.geometry["truncation"] = float(getattr(config, "truncation", 1.0))     # models.py:78,84
+        self.D = None
+
+    def has_discriminator(self):
+        return False
 
 
 class GPT2:

@@ -65,7 +65,7 @@ def main(argv=None, extra_config=None):
     operators = get_operators(config)
     os.makedirs(config.tmp_folder, exist_ok=True)
     res = search.minimize(problem, config.algorithm, config.pop_size, config.generations, operators["sampling"],
-                          seed=config.seed, callback=save_callback, verbose=True)
+                          seed=config.seed, callback=save_callback, verbose=True, mask=operators.get("mask"))
     with open(os.path.join(config.tmp_folder, "genetic_result"), "wb") as f:   # run.py:79-84
         pickle.dump(dict(X=res.X, F=res.F, G=res.G, CV=res.CV), f)
     if config.problem_args["n_obj"] == 2:

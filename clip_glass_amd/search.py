@@ -72,6 +72,47 @@ def polynomial_mutation(rng, x, xl, xu, eta=3.0, prob=0.5):
     return np.where(rng.random((n, nv)) < prob, y, x)
 
 
+def hux(rng, pa, pb, prob=0.2, prob_hux=0.5):
+    """Half-uniform crossover on boolean matrices (pymoo "bin_hux"): with probability `prob` per mating,
+    exchange ceil(prob_hux * #differing) randomly chosen differing bits."""
+    ca, cb = pa.copy(), pb.copy()
+    for i in np.nonzero(rng.random(pa.shape[0]) < prob)[0]:
+        diff = np.nonzero(pa[i] != pb[i])[0]
+        n = int(np.ceil(len(diff) * prob_hux))
+        if n:
+            sw = rng.permutation(diff)[:n]
+            ca[i, sw], cb[i, sw] = pb[i, sw], pa[i, sw]
+    return ca, cb
+
+
+def bitflip(rng, x, prob=0.01):
+    """pymoo "bin_bitflip": flip every bit independently with probability `prob`."""
+    flip = rng.random(x.shape) < prob
+    return np.where(flip, 1.0 - x, x)
+
+
+def vary(rng, A, B, xl, xu, mask, eta_c, eta_m, prob_m, n_off):
+    """Crossover + mutation for a (possibly mixed-variable) population: real / int columns get SBX + polynomial
+    mutation (int: rounded, as pymoo's int_sbx / int_pm do), bool columns HUX + bit-flip
+    (operators.py:38-63 MixedVariable* with the reference's probabilities)."""
+    mask = np.asarray(mask)
+    num = mask != "bool"
+    ca, cb = A.copy(), B.copy()
+    if num.any():
+        ca[:, num], cb[:, num] = sbx_vectorised(rng, A[:, num], B[:, num], xl[num], xu[num], eta_c)
+    if (~num).any():
+        ca[:, ~num], cb[:, ~num] = hux(rng, A[:, ~num], B[:, ~num], 0.2)
+    off = np.concatenate([ca, cb])[rng.permutation(2 * A.shape[0])[:n_off]]
+    if num.any():
+        off[:, num] = polynomial_mutation(rng, off[:, num], xl[num], xu[num], eta_m, prob_m)
+    if (~num).any():
+        off[:, ~num] = bitflip(rng, off[:, ~num], 10 / 1000)
+    ints = mask == "int"
+    if ints.any():
+        off[:, ints] = np.clip(np.rint(off[:, ints]), xl[ints], xu[ints])
+    return off
+
+
 # ----------------------------- NSGA-II machinery ------------------------------------------
 def fast_non_dominated_sort(F):
     n = F.shape[0]
@@ -126,16 +167,19 @@ class Result:
 
 
 def minimize(problem, algorithm, pop_size, n_gen, sampling, seed=1, callback=None, eta_c=3.0, eta_m=3.0,
-             prob_m=0.5, verbose=False):
+             prob_m=0.5, verbose=False, mask=None):
     """pymoo.optimize.minimize(problem, algorithm, ("n_gen", n_gen)) stand-in.
 
     problem: has n_var, n_obj, xl, xu and _evaluate(x, out) (GenerationProblem);
-    algorithm: "ga" | "nsga2"; sampling: object with _do(problem, n) (operators.get_operators)."""
+    algorithm: "ga" | "nsga2"; sampling: object with _do(problem, n) (operators.get_operators);
+    mask: per-variable type "real" | "int" | "bool" (None = all real) — the BigGAN configs mix real z with
+    boolean class bits (operators.py:39), the GPT2 config is all-int."""
     rng = np.random.default_rng(seed)
     np.random.seed(seed)   # the reference's Sampling classes draw from numpy's global RNG (operators.py:24-25)
     xl = np.broadcast_to(np.asarray(problem.xl, float), (problem.n_var,))
     xu = np.broadcast_to(np.asarray(problem.xu, float), (problem.n_var,))
     nsga = algorithm == "nsga2"
+    mask = np.asarray(["real"] * problem.n_var if mask is None else list(mask))
 
     def evaluate(X):
         out = {}
@@ -176,14 +220,13 @@ def minimize(problem, algorithm, pop_size, n_gen, sampling, seed=1, callback=Non
         a, b = rng.integers(0, n, (2, pop_size)), rng.integers(0, n, (2, pop_size))
         better = (rank[a] < rank[b]) | ((rank[a] == rank[b]) & (cd[a] >= cd[b]))
         parents = np.where(better, a, b)
-        ca, cb = sbx_vectorised(rng, X[parents[0]], X[parents[1]], xl, xu, eta_c)
-        off = np.concatenate([ca, cb])[rng.permutation(2 * pop_size)[:pop_size]]
-        off = polynomial_mutation(rng, off, xl, xu, eta_m, prob_m)
+        off = vary(rng, X[parents[0]], X[parents[1]], xl, xu, mask, eta_c, eta_m, prob_m, pop_size)
         off = off[_eliminate_duplicates(off, X)]
         bs = getattr(getattr(problem, "config", None), "batch_size", 1)
         if off.shape[0] % bs:
             extra = bs - off.shape[0] % bs
-            off = np.concatenate([off, polynomial_mutation(rng, X[rng.integers(0, n, extra)], xl, xu, eta_m, 1.0)])
+            pick = rng.integers(0, n, (2, extra))
+            off = np.concatenate([off, vary(rng, X[pick[0]], X[pick[1]], xl, xu, mask, eta_c, eta_m, 1.0, extra)])
         Fo = evaluate(off)
         X, F, rank, cd = survive(np.concatenate([X, off]), np.concatenate([F, Fo]), pop_size)
         algo.pop = [Individual(x, f if nsga else f[0]) for x, f in zip(X, F)]

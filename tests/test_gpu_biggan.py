@@ -78,3 +78,47 @@ def test_biggan_error_paths():
     with pytest.raises(RuntimeError, match="missing tensor"):
         e.finalize()
     e.close()
+
+
+def test_biggan_generation_problem_and_cli(tmp_path):
+    """The reference-facing surface for the DeepMindBigGAN configs (run.py's default): GenerationProblem._evaluate on
+    mixed [z | class bits] rows, then the CLI mirror with the native mixed-variable GA (pymoo absent)."""
+    import os, pickle, types
+    from clip_glass_amd import config as gconfig, run
+    from clip_glass_amd.problem import GenerationProblem
+    c = M.BIGGAN_CONFIGS["bg_mini"]
+    sd = M.make_biggan_state("bg_mini", 0)
+    x = synth.biggan_population(4, 8, c["z_dim"], c["num_classes"])
+    kw = dict(attention_pos=c["attention_pos"], ch=c["ch"])
+    detail = {}
+    fitness_ref.evaluate_biggan(_t(sd), x, np.ones(c["clip"][5], np.float32), c["z_dim"], 4, 1.0, c["layers"],
+                                clip_size=c["clip"][4], detail=detail, **kw)
+    target = M.make_target(detail["features"].numpy())
+    Fo, Go = fitness_ref.evaluate_biggan(_t(sd), x, target, c["z_dim"], 4, 1.0, c["layers"], clip_size=c["clip"][4], **kw)
+    n_var = c["z_dim"] + c["num_classes"]
+    extra = dict(weights="synthetic:0", clip_weights="synthetic:0", dim_z=c["z_dim"], num_classes=c["num_classes"],
+                 biggan_geometry=dict(layers=c["layers"], attention_pos=c["attention_pos"], ch=c["ch"]),
+                 clip_geometry=c["clip"], target_features=target, batch_size=4,
+                 problem_args=dict(n_var=n_var, n_obj=1, n_constr=c["z_dim"], xl=-2, xu=2))
+    cfg = types.SimpleNamespace(config="DeepMindBigGAN512", device="cuda", target="unused")
+    vars(cfg).update(gconfig.get_config("DeepMindBigGAN512"))
+    vars(cfg).update(extra)
+    prob = GenerationProblem(cfg)
+    out = {}
+    prob._evaluate(x.astype(object), out)        # pymoo hands mixed-variable populations over as object arrays
+    assert out["F"].shape == (8,) and out["F"].dtype == np.float32 and out["G"].shape == (8,)
+    rel = np.abs(out["F"] - Fo) / np.abs(Fo)
+    diag("[biggan] GenerationProblem drop-in: sim rel err %.3e" % rel.max())
+    assert rel.max() < 1e-3
+    ls = cfg.latent(cfg)
+    ls.set_from_population(x[:3])
+    img = prob.generator.generate(ls)
+    assert img.shape == (3, 3, 64, 64) and img.min() >= 0 and img.max() <= 1
+    prob.generator.engine.close()
+    argv = ["--config", "DeepMindBigGAN512", "--generations", "3", "--save-each", "2", "--tmp-folder", str(tmp_path),
+            "--pop-size", "8"]
+    res = run.main(argv, extra_config=extra)
+    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result.npz", "output.jpg"):
+        assert os.path.getsize(os.path.join(str(tmp_path), f)) > 0, f
+    d = pickle.load(open(os.path.join(str(tmp_path), "genetic_result"), "rb"))
+    assert np.atleast_2d(d["X"]).shape[1] == n_var
