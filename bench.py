@@ -80,22 +80,41 @@ def main():
     from clip_glass_amd.parallel import ShardedEvaluator
 
     cfgs = {"ffhq": dict(channels=synth.FFHQ_CHANNELS, latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
-            "mid": dict(channels=[32, 64, 64, 64, 64], latent=64, mapping=3, clip=(128, 2, 2, 8, 32, 64))}
+            "mid": dict(channels=[32, 64, 64, 64, 64], latent=64, mapping=3, clip=(128, 2, 2, 8, 32, 64)),
+            # BASELINE.json configs[2] (not the headline): DeepMindBigGAN512 + CLIP ViT-B/32, batch_size 8 (config.py:66)
+            "biggan512": dict(biggan=dict(layers=synth.BIGGAN_LAYERS[512], attention_pos=8, ch=128, z_dim=128, num_classes=1000),
+                              clip=(768, 12, 12, 32, 224, 512))}
     cfg = cfgs[args.config]
     P = args.pop
-    sd = synth.make_state(synth.stylegan2_g_spec(cfg["channels"], cfg["latent"], cfg["mapping"]), 0)
-    sd.update(synth.make_state(synth.stylegan2_d_spec(cfg["channels"]), 0))
+    biggan = cfg.get("biggan")
     w, layers, heads, patch, res, emb = cfg["clip"]
-    sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), 0))
+    if biggan:
+        global BATCH
+        BATCH = 8
+        b = biggan
+        sd = synth.make_biggan_state(synth.biggan_spec(b["layers"], b["attention_pos"], b["ch"], b["z_dim"], b["num_classes"]), 0)
+        sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), 0))
+        eng = Engine([], batch_size=BATCH, max_pop=P, chunk=args.chunk, clip=cfg["clip"], device=local_rank, biggan=biggan)
+        n_obj = 1
 
-    eng = Engine(cfg["channels"][::-1], latent_size=cfg["latent"], mapping_layers=cfg["mapping"], batch_size=BATCH,
-                 use_discriminator=True, n_obj=2, max_pop=P, chunk=args.chunk, clip=cfg["clip"], noise_mode=1,
-                 noise_seed=1234, device=local_rank)
+        def population(seed, n):
+            return synth.biggan_population(seed, n, b["z_dim"], b["num_classes"])
+    else:
+        sd = synth.make_state(synth.stylegan2_g_spec(cfg["channels"], cfg["latent"], cfg["mapping"]), 0)
+        sd.update(synth.make_state(synth.stylegan2_d_spec(cfg["channels"]), 0))
+        sd.update(synth.make_state(synth.clip_visual_spec(w, layers, patch, res, emb), 0))
+        eng = Engine(cfg["channels"][::-1], latent_size=cfg["latent"], mapping_layers=cfg["mapping"], batch_size=BATCH,
+                     use_discriminator=True, n_obj=2, max_pop=P, chunk=args.chunk, clip=cfg["clip"], noise_mode=1,
+                     noise_seed=1234, device=local_rank)
+        n_obj = 2
+
+        def population(seed, n):
+            return synth.latents(seed, n, cfg["latent"])
     eng.load_state(sd)
     eng.finalize()
     # synthetic target: a pass with a dummy target to get features, then sims in ~[0.5, 0.9]
     eng.set_target(np.ones(emb, np.float32))
-    eng.evaluate(synth.latents(999, BATCH, cfg["latent"]))
+    eng.evaluate(population(999, BATCH))
     target = synth.make_target(eng.details(BATCH)["features"])
     eng.set_target(target)
 
@@ -112,7 +131,7 @@ def main():
     eng.set_profiling(True)
     warm = {}
     for s in range(max(args.warmup, 1)):
-        ev.evaluate_local(synth.latents(1000 * rank + s, P, cfg["latent"]), generation=s)
+        ev.evaluate_local(population(1000 * rank + s, P), generation=s)
         warm = {}
         for r in eng.profile():
             kern = r["name"].split("@")[1] if "@" in r["name"] else r["name"]
@@ -129,7 +148,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        F_all = ev.evaluate_local(synth.latents(1000 * rank + 100 + s, P, cfg["latent"]), generation=100 + s)
+        F_all = ev.evaluate_local(population(1000 * rank + 100 + s, P), generation=100 + s)
         for r in eng.profile():
             a = prof.setdefault(r["name"], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
             for k in a:
@@ -142,7 +161,7 @@ def main():
     eng.set_overlap(False)
     eng.set_profile_filter("")
     eng.set_profiling(True)
-    ev.evaluate_local(synth.latents(1000 * rank + 500, P, cfg["latent"]), generation=500)
+    ev.evaluate_local(population(1000 * rank + 500, P), generation=500)
     iso = {}
     for r in eng.profile():
         kk = r["name"].split("@")[1] if "@" in r["name"] else r["name"]
@@ -154,7 +173,7 @@ def main():
         tt = torch.tensor([dt], device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert F_all.shape == (P * world, 2) and np.isfinite(F_all).all()
+    assert F_all.shape == (P * world, n_obj) and np.isfinite(F_all).all()
 
     if rank == 0:
         # dominant kernel = the kernel symbol with the largest share of device time
@@ -201,15 +220,20 @@ def main():
                                      if os.environ.get("GLASS_OVERLAP") else "single stream"),
                         whole_pass_tflops=total_flops / (total_ms * 1e-3) / 1e12 if total_ms else None,
                         whole_pass_frac_of_mfma_peak=(total_flops / (total_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if total_ms else None)
-        out = dict(metric=METRIC, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=world,
+        if biggan:
+            metric = "candidate latents scored/sec (GAN→CLIP fitness), DeepMindBigGAN512 pop=%d" % P
+            workload = ("DeepMindBigGAN512: BigGAN-deep 512px G + CLIP ViT-B/32, pop=%d per GPU, batch_size=%d, n_obj=1" % (P, BATCH))
+        else:
+            metric = METRIC
+            workload = ("StyleGAN2_ffhq_d: StyleGAN2 config-f %dpx G+D + CLIP ViT-B/32, pop=%d per GPU, batch_size=%d, n_obj=2"
+                        % (4 << (len(cfg["channels"]) - 1), P, BATCH))
+        out = dict(metric=metric, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
-                   config=dict(workload="StyleGAN2_ffhq_d: StyleGAN2 config-f %dpx G+D + CLIP ViT-B/32, pop=%d per GPU, "
-                                        "batch_size=%d, n_obj=2" % (4 << (len(cfg["channels"]) - 1), P, BATCH),
-                               pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,
+                   config=dict(workload=workload, pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,
                                device=device_info(local_rank)["name"]),
                    roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not biggan:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, target)
         if os.environ.get("GLASS_BENCH_DETAIL"):
             with open(os.environ["GLASS_BENCH_DETAIL"], "w") as f:

@@ -8,8 +8,10 @@
 //   * every BigGANBatchNorm folded to one per-(candidate, channel) affine  y = x*A + S, the tables for ALL
 //     56 norms of the network produced by ONE dense launch (cond[P,256] x [256, 2*Ctot]) + one table kernel;
 //     the conv biases feeding a norm are folded into its shift
-//   * bn1..bn3 + ReLU ride in the epilogue of the conv that produces their input (scale, shift, relu),
-//     so each GenBlock is 4 MFMA convs + 1 affine-relu (bn0) + the skip gather
+//   * bn1..bn3 + ReLU ride in the epilogue of the conv that produces their input (scale, shift, relu); bn0 + ReLU
+//     (and the final bn) ride in the STAGING of the conv that consumes them (relu(x*A + S) on in-bounds pixels);
+//     nearest x2 is an addressing mode of conv1's input and of the skip read; the channel-drop skip is a strided
+//     residual read in conv3's epilogue -> a GenBlock is exactly 4 MFMA conv launches, nothing else
 //   * self-attention = one 1x1 conv for theta|phi|g, a split/max-pool kernel, two batched MFMA GEMMs
 //     around an fp32 row softmax, and the output 1x1 conv with gamma folded in and the residual fused
 //   * activations NHWC fp16 (fp32 accumulate), images leave as planar fp32 like the StyleGAN2 path.
@@ -219,29 +221,23 @@ int glass_biggan_finalize(glass_engine* e) {
     }
     // ---- activation buffers (per chunk of candidates) ---------------------------------------------------
     const size_t P = c.max_pop, CH = e->chunk;
-    size_t mx = 0, mt0 = 0, mt1 = 0, mtu = 0, mr = 0;
+    size_t mx = 0, mt1 = 0, mtu = 0;
     for (auto& b : g.blocks) {
         const size_t hi = (size_t)b.res_in * b.res_in, ro = (size_t)(b.res_in << b.up), ho = ro * ro;
         mx = std::max(mx, std::max(hi * b.cin, ho * b.cout));
-        mt0 = std::max(mt0, hi * b.cin);
         mt1 = std::max(mt1, hi * b.mid);
         mtu = std::max(mtu, ho * b.mid);
-        mr = std::max(mr, ho * b.cout);
     }
     const size_t RR = (size_t)g.R * g.R;
-    mt0 = std::max(mt0, RR * ch);
     mtu = std::max(mtu, RR * g.rgb_cpad);
     if ((rc = dev_alloc(e, &g.cond, P * cd))) return rc;
     if ((rc = dev_alloc(e, &g.tab, P * 2 * g.Ctot))) return rc;
     if ((rc = dev_alloc(e, &g.h32, CH * 16 * g.c0))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(e, &g.x[i], CH * mx))) return rc;
-    if ((rc = dev_alloc(e, &g.t0, CH * mt0))) return rc;
     if ((rc = dev_alloc(e, &g.t1, CH * mt1))) return rc;
-    if ((rc = dev_alloc(e, &g.t1u, CH * mtu))) return rc;
     if ((rc = dev_alloc(e, &g.t2, CH * mtu))) return rc;
     if ((rc = dev_alloc(e, &g.t3, CH * mtu))) return rc;
-    if ((rc = dev_alloc(e, &g.r, CH * mr))) return rc;
     if (g.attn_before >= 0) {
         const size_t hw = (size_t)g.attn_res * g.attn_res, hq = hw / 4, C = g.attn_C, c8 = C / 8, c2 = C / 2;
         if ((rc = dev_alloc(e, &g.a_T, CH * hw * (2 * c8 + c2)))) return rc;
@@ -272,36 +268,64 @@ int glass_biggan_prepare(glass_engine* e, int P) {
 
 namespace {
 
-// one conv of the BigGAN path: x [B][res][res][cin] -> y [B][res][res][cout]; bn >= 0: fused scale/shift + relu
-void bg_conv(glass_engine* e, const char* tag, int c0, int B, int res, int cin, int cout, int ks, const half_t* w,
-             const half_t* x, half_t* y, int bn_off, const float* bias, const half_t* resid) {
+// one conv of the BigGAN path: x [B][res >> in_up]^2 [cin] -> y [B][res][res][cout]
+//   pre_bn >= 0: batch norm + ReLU of the INPUT applied while staging (x <- relu(x*A + S), padding stays zero)
+//   in_up      : the input is read through a nearest x2 upsample
+//   bn_off >= 0: batch norm + ReLU of the OUTPUT fused in the epilogue (the next conv's input norm)
+//   resid      : residual [B][res >> res_up]^2 [res_cs] (first cout channels), nearest x2 when res_up
+struct BgConv {
+    int res, cin, cout, ks;
+    const half_t* w;
+    const half_t* x;
+    half_t* y;
+    int pre_bn = -1, in_up = 0, bn_off = -1;
+    const float* bias = nullptr;
+    const half_t* resid = nullptr;
+    int res_cs = 0, res_up = 0;
+};
+void bg_conv(glass_engine* e, const char* tag, int c0, int B, const BgConv& q) {
     BgState& g = e->bg;
     ConvParams p = conv_defaults();
-    p.x = x;
-    p.x_bstride = (long long)res * res * cin;
-    p.B = B; p.H = res; p.W = res; p.Cin = cin;
-    p.Hc = res; p.Wc = res; p.Ho = res; p.Wo = res;
-    p.KS = ks; p.stride = 1; p.pad = ks / 2;
-    p.w = w;
-    p.Neff = cout; p.Cout = cout;
-    if (bn_off >= 0) {
-        p.dscale = g.tab + (size_t)c0 * 2 * g.Ctot + bn_off;
-        p.shift = p.dscale + g.Ctot;
+    const int rin = q.res >> q.in_up;
+    p.x = q.x;
+    p.x_bstride = (long long)rin * rin * q.cin;
+    p.B = B; p.H = q.res; p.W = q.res; p.Cin = q.cin;
+    p.Hc = q.res; p.Wc = q.res; p.Ho = q.res; p.Wo = q.res;
+    p.KS = q.ks; p.stride = 1; p.pad = q.ks / 2;
+    p.in_up = q.in_up;
+    p.w = q.w;
+    p.Neff = q.cout; p.Cout = q.cout;
+    const float* tab = g.tab + (size_t)c0 * 2 * g.Ctot;
+    if (q.pre_bn >= 0) {
+        p.sn = tab + q.pre_bn;
+        p.pre_shift = tab + g.Ctot + q.pre_bn;
+        p.sn_stride = 2 * g.Ctot;
+    }
+    if (q.bn_off >= 0) {
+        p.dscale = tab + q.bn_off;
+        p.shift = tab + g.Ctot + q.bn_off;
         p.ds_stride = 2 * g.Ctot;
         p.act = 2;
     }
-    p.bias = bias;
-    p.res = resid;
-    p.y = y;
-    const double M = (double)B * res * res;
-    run_conv(e, p, tag, 2.0 * M * cout * cin * ks * ks, 2.0 * (M * cin + M * cout + (double)cout * cin * ks * ks));
+    p.bias = q.bias;
+    p.res = q.resid;
+    p.res_cs = q.res_cs;
+    p.res_up = q.res_up;
+    p.y = q.y;
+    const double M = (double)B * q.res * q.res, Min = (double)B * rin * rin;
+    const double rbytes = q.resid ? M * q.cout / (q.res_up ? 4 : 1) : 0.0;
+    run_conv(e, p, tag, 2.0 * M * q.cout * q.cin * q.ks * q.ks,
+             2.0 * (Min * q.cin + M * q.cout + rbytes + (double)q.cout * q.cin * q.ks * q.ks));
 }
 
 void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
     BgState& g = e->bg;
     const int res = g.attn_res, C = g.attn_C, c8 = C / 8, c2 = C / 2, CT = 2 * c8 + c2;
     const int hw = res * res, hq = hw / 4;
-    bg_conv(e, "bg.attn.theta_phi_g", 0, B, res, C, CT, 1, g.attn_w_tpg, x, g.a_T, -1, nullptr, nullptr);
+    {
+        BgConv q{res, C, CT, 1, g.attn_w_tpg, x, g.a_T};
+        bg_conv(e, "bg.attn.theta_phi_g", 0, B, q);
+    }
     {
         Prof pr(e, "bg.attn.split_pool", 0, 2.0 * B * ((double)hw * CT + (double)hw * c8 + (double)hq * (c8 + c2)));
         launch_bg_attn_split(g.a_T, B, res, res, c8, c2, g.a_theta, g.a_phi, g.a_gT, e->cur);
@@ -330,15 +354,16 @@ void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
         if (pr.on) pr.pe.name = std::string("bg.attn.values@") + k;
     }
     // out = x + gamma * o_conv(attn_g): gamma folded into the weights, x as the fused residual
-    bg_conv(e, "bg.attn.o_conv", 0, B, res, c2, C, 1, g.attn_w_o, g.a_O, y, -1, nullptr, x);
+    BgConv oc{res, c2, C, 1, g.attn_w_o, g.a_O, y};
+    oc.resid = x;
+    bg_conv(e, "bg.attn.o_conv", 0, B, oc);
 }
 
 }  // namespace
 
 int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
     BgState& g = e->bg;
-    const int cd = 2 * g.zd, TS = 2 * g.Ctot;
-    const float* tabA = g.tab + (size_t)c0 * TS;
+    const int cd = 2 * g.zd;
     {   // gen_z: cond -> [B][4][4][16ch] (the package views the linear output as NHWC before permuting)
         Prof pr(e, "bg.gen_z", 2.0 * B * cd * 16.0 * g.c0, 4.0 * (double)cd * 16 * g.c0);
         launch_dense(g.cond + (size_t)c0 * cd, cd, B, cd, g.genz_wt, 16 * g.c0, g.genz_b, g.h32, 16 * g.c0, 0, 0, nullptr, 0,
@@ -355,46 +380,45 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
         const BgBlock& b = g.blocks[i];
         const int ri = b.res_in, ro = b.res_in << b.up;
         const half_t* x = g.x[cur];
+        {   // bn0 + relu ride in conv0's staging; bn1 + relu in its epilogue
+            BgConv q{ri, b.cin, b.mid, 1, b.w[0], x, g.t1};
+            q.pre_bn = b.bn_off[0];
+            q.bn_off = b.bn_off[1];
+            snprintf(tag, sizeof tag, "bg.b%zu.conv0.r%d.%dx%d", i, ri, b.cin, b.mid);
+            bg_conv(e, tag, c0, B, q);
+        }
+        {   // nearest x2 (up blocks) is an addressing mode of conv1's input
+            BgConv q{ro, b.mid, b.mid, 3, b.w[1], g.t1, g.t2};
+            q.in_up = b.up;
+            q.bn_off = b.bn_off[2];
+            snprintf(tag, sizeof tag, "bg.b%zu.conv1.r%d.%dx%d", i, ro, b.mid, b.mid);
+            bg_conv(e, tag, c0, B, q);
+        }
         {
-            snprintf(tag, sizeof tag, "bg.b%zu.bn0_relu", i);
-            Prof pr(e, tag, 0, 4.0 * B * ri * ri * (double)b.cin);
-            launch_bg_affine_relu(x, B, (long long)ri * ri, b.cin, tabA + b.bn_off[0], tabA + g.Ctot + b.bn_off[0], TS, g.t0,
-                                  e->cur);
+            BgConv q{ro, b.mid, b.mid, 3, b.w[2], g.t2, g.t3};
+            q.bn_off = b.bn_off[3];
+            snprintf(tag, sizeof tag, "bg.b%zu.conv2.r%d.%dx%d", i, ro, b.mid, b.mid);
+            bg_conv(e, tag, c0, B, q);
         }
-        snprintf(tag, sizeof tag, "bg.b%zu.conv0.r%d.%dx%d", i, ri, b.cin, b.mid);
-        bg_conv(e, tag, c0, B, ri, b.cin, b.mid, 1, b.w[0], g.t0, g.t1, b.bn_off[1], nullptr, nullptr);
-        const half_t* t1 = g.t1;
-        if (b.up) {
-            snprintf(tag, sizeof tag, "bg.b%zu.upsample", i);
-            Prof pr(e, tag, 0, 2.0 * B * (double)(ri * ri + ro * ro) * b.mid);
-            launch_bg_gather(g.t1, B, ri, ri, b.mid, b.mid, 1, g.t1u, e->cur);
-            t1 = g.t1u;
+        {   // skip = x0[:, :cout] (channel drop), nearest x2 when up: read straight from the block input
+            BgConv q{ro, b.mid, b.cout, 1, b.w[3], g.t3, g.x[cur ^ 1]};
+            q.bias = b.b3;
+            q.resid = x;
+            q.res_cs = b.cin;
+            q.res_up = b.up;
+            snprintf(tag, sizeof tag, "bg.b%zu.conv3.r%d.%dx%d", i, ro, b.mid, b.cout);
+            bg_conv(e, tag, c0, B, q);
         }
-        snprintf(tag, sizeof tag, "bg.b%zu.conv1.r%d.%dx%d", i, ro, b.mid, b.mid);
-        bg_conv(e, tag, c0, B, ro, b.mid, b.mid, 3, b.w[1], t1, g.t2, b.bn_off[2], nullptr, nullptr);
-        snprintf(tag, sizeof tag, "bg.b%zu.conv2.r%d.%dx%d", i, ro, b.mid, b.mid);
-        bg_conv(e, tag, c0, B, ro, b.mid, b.mid, 3, b.w[2], g.t2, g.t3, b.bn_off[3], nullptr, nullptr);
-        const half_t* skip = x;
-        if (b.up || b.cin != b.cout) {   // x0[:, :in/2] and / or nearest x2
-            snprintf(tag, sizeof tag, "bg.b%zu.skip", i);
-            Prof pr(e, tag, 0, 2.0 * B * (double)(ri * ri + ro * ro) * b.cout);
-            launch_bg_gather(x, B, ri, ri, b.cin, b.cout, b.up, g.r, e->cur);
-            skip = g.r;
-        }
-        snprintf(tag, sizeof tag, "bg.b%zu.conv3.r%d.%dx%d", i, ro, b.mid, b.cout);
-        bg_conv(e, tag, c0, B, ro, b.mid, b.cout, 1, b.w[3], g.t3, g.x[cur ^ 1], -1, b.b3, skip);
         cur ^= 1;
     }
-    {   // bn - relu - conv_to_rgb[:3] - tanh
+    {   // bn - relu (staging of the conv) - conv_to_rgb[:3] - tanh
         const int R = g.R, ch = e->cfg.bg_ch;
-        {
-            Prof pr(e, "bg.final.bn_relu", 0, 4.0 * B * R * R * (double)ch);
-            launch_bg_affine_relu(g.x[cur], B, (long long)R * R, ch, tabA + g.final_bn_off, tabA + g.Ctot + g.final_bn_off, TS,
-                                  g.t0, e->cur);
-        }
-        bg_conv(e, "bg.final.conv_to_rgb", c0, B, R, ch, g.rgb_cpad, 3, g.rgb_w, g.t0, g.t1u, -1, g.rgb_b, nullptr);
+        BgConv q{R, ch, g.rgb_cpad, 3, g.rgb_w, g.x[cur], g.t2};
+        q.pre_bn = g.final_bn_off;
+        q.bias = g.rgb_b;
+        bg_conv(e, "bg.final.conv_to_rgb", c0, B, q);
         Prof pr(e, "bg.final.tanh", 0, B * (double)R * R * (2.0 * g.rgb_cpad + 12.0));
-        launch_bg_rgb_tanh(g.t1u, B, (long long)R * R, g.rgb_cpad, y, e->cur);
+        launch_bg_rgb_tanh(g.t2, B, (long long)R * R, g.rgb_cpad, y, e->cur);
     }
     return GLASS_OK;
 }

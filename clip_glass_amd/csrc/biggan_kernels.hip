@@ -4,8 +4,9 @@
 // affine tables:
 //   cond      latent.py:20-24 (clip z, softmax class bits) + BigGAN.forward (embeddings, cat)
 //   bn tables BigGANBatchNorm folded to  y = x * A[b,c] + S[b,c]   (A = gain * rsqrt(var + eps))
-//   affine_relu, nearest x2 / channel-drop gather (GenBlock skip path), attention split + 2x2 max-pool,
-//   row softmax, tanh + NHWC -> planar RGB.
+//   attention split + 2x2 max-pool, row softmax, tanh + NHWC -> planar RGB.
+// (batch norm + ReLU, nearest x2 and the channel-drop skip are fused into the conv kernels: common.h ConvParams
+//  pre_shift / in_up / shift / res_cs / res_up.)
 #include "common.h"
 #include "kernels.h"
 
@@ -78,49 +79,6 @@ __global__ void bg_to_half_kernel(const float* __restrict__ x, half_t* __restric
 void launch_bg_to_half(const float* x, half_t* y, long long n, hipStream_t st) {
     const long long n4 = n / 4;
     hipLaunchKernelGGL(bg_to_half_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, y, n4);
-}
-
-// ---- y = relu(x * A[b,c] + S[b,c]) : conditional batch norm + ReLU ahead of a 1x1 conv -----------------
-__global__ void bg_affine_relu_kernel(const half_t* __restrict__ x, long long hw, int C, const float* __restrict__ A,
-                                      const float* __restrict__ S, int tstride, half_t* __restrict__ y, long long n8) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    const int c8 = C >> 3;
-    const int c = (int)(i % c8) * 8;
-    const long long b = i / (c8 * hw);
-    const h8 v = ((const h8*)x)[i];
-    const float* a = A + b * tstride + c;
-    const float* s = S + b * tstride + c;
-    h8 o;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = (half_t)fmaxf((float)v[q] * a[q] + s[q], 0.f);
-    ((h8*)y)[i] = o;
-}
-void launch_bg_affine_relu(const half_t* x, int B, long long hw, int C, const float* A, const float* S, int tstride,
-                           half_t* y, hipStream_t st) {
-    const long long n8 = (long long)B * hw * C / 8;
-    hipLaunchKernelGGL(bg_affine_relu_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, x, hw, C, A, S, tstride,
-                       y, n8);
-}
-
-// ---- out[b][oy][ox][0..take) = x[b][oy >> up][ox >> up][0..take) : nearest x2 and/or channel drop ---------
-__global__ void bg_gather_kernel(const half_t* __restrict__ x, int H, int W, int C, int take, int up,
-                                 half_t* __restrict__ y, long long n8) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    const int t8 = take >> 3;
-    const int c = (int)(i % t8) * 8;
-    long long r = i / t8;
-    const int Wo = W << up, Ho = H << up;
-    const int ox = (int)(r % Wo);
-    r /= Wo;
-    const int oy = (int)(r % Ho);
-    const long long b = r / Ho;
-    ((h8*)y)[i] = *(const h8*)(x + ((b * H + (oy >> up)) * W + (ox >> up)) * C + c);
-}
-void launch_bg_gather(const half_t* x, int B, int H, int W, int C, int take, int up, half_t* y, hipStream_t st) {
-    const long long n8 = (long long)B * (H << up) * (W << up) * take / 8;
-    hipLaunchKernelGGL(bg_gather_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, x, H, W, C, take, up, y, n8);
 }
 
 // ---- SelfAttn split: T [B][H][W][c8 + c8 + c2] (theta | phi | g) ->

@@ -38,6 +38,9 @@ struct ConvParams {
     int Ho, Wo;             // output grid
     const float* sn;        // [B][sn_stride] normalised style (nullable)
     int sn_stride;
+    const float* pre_shift; // [B][sn_stride] (nullable; needs sn): x <- relu(x * sn + pre_shift) on the way in, in-bounds
+                            // pixels only (zero padding stays zero) — BigGAN batch norm + ReLU ahead of the conv
+    int in_up;              // 1: the input is read through a nearest x2 upsample (H, W = upsampled dims; x holds H/2 x W/2)
     const float* dscale;    // [B][ds_stride] demod * smax (nullable)
     int ds_stride;
     const float* noise;     // [n_minibatch][Ho][Wo] (nullable)
@@ -46,7 +49,9 @@ struct ConvParams {
     const float* bias;      // [Cout] (nullable)
     const float* shift;     // [B][ds_stride] per-sample per-channel shift added after bias (nullable; BigGAN conditional BN)
     int act;                // 1: leaky-relu(0.2) * sqrt(2); 2: relu
-    const half_t* res;      // residual [B][Ho][Wo][Cout] added after activation (nullable)
+    const half_t* res;      // residual [B][Ho][Wo][res_cs] added after activation (nullable)
+    int res_cs;             // channel stride of the residual rows (0 = Cout): first Cout of res_cs channels are used
+    int res_up;             // 1: the residual is read through a nearest x2 upsample (it holds Ho/2 x Wo/2)
     float out_scale;
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout

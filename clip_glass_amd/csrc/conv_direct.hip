@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 
     const half_t* xb = p.x + (long long)b * p.x_bstride + kh * 8;
     const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + kh * 8 : nullptr;
+    const float* psb = p.pre_shift ? p.pre_shift + (long long)b * p.sn_stride + kh * 8 : nullptr;
     const int cps = p.Cin >> 4;                 // 16-channel steps per tap
     const int total = p.KS * p.KS * cps;
     bool nvalid[NW];
@@ -58,10 +59,18 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
         const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
 #pragma unroll
         for (int j = 0; j < 8; ++j) f.a[j] = (half_t)0.f;
-        if (v) f.a = *(const h8*)(xb + ((long long)iy * p.W + ix) * p.Cin + i0);
+        if (v) f.a = *(const h8*)(xb + ((long long)(iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + i0);
         if (snb) {
             f.s0 = *(const f4*)(snb + i0);
             f.s1 = *(const f4*)(snb + i0 + 4);
+        }
+        if (psb) {   // pre-activation: relu(x * s + shift) for in-bounds pixels (applied here, where validity is known)
+            const f4 t0 = *(const f4*)(psb + i0), t1 = *(const f4*)(psb + i0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f.a[j] = (half_t)(v ? fmaxf((float)f.a[j] * f.s0[j] + t0[j], 0.f) : 0.f);
+                f.a[j + 4] = (half_t)(v ? fmaxf((float)f.a[j + 4] * f.s1[j] + t1[j], 0.f) : 0.f);
+            }
         }
         const half_t* wp = p.w + ((long long)tap * p.Neff + n0 + r) * p.Cin + kh * 8 + i0;
 #pragma unroll
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
     };
     auto compute = [&](Frag& f) {
         h8 a = f.a;
-        if (snb) {
+        if (snb && !psb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[j] = (half_t)((float)a[j] * f.s0[j]);
@@ -138,7 +147,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
             if (p.act == 1) val = lrelu_sqrt2(val);
             else if (p.act == 2) val = fmaxf(val, 0.f);
             const long long oidx = (((long long)rb * p.Ho + py) * p.Wo + px) * p.Cout + o;
-            if (p.res) val += (float)p.res[oidx];
+            if (p.res) {
+                const int rcs = p.res_cs ? p.res_cs : p.Cout;
+                const long long ridx = p.res_up ? (((long long)rb * (p.Ho >> 1) + (py >> 1)) * (p.Wo >> 1) + (px >> 1)) * rcs + o
+                                                : (((long long)rb * p.Ho + py) * p.Wo + px) * rcs + o;
+                val += (float)p.res[ridx];
+            }
             val *= p.out_scale;
             if (p.y32) p.y32[oidx] = val;
             else p.y[oidx] = (half_t)val;

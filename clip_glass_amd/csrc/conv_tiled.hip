@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     const half_t* xb = p.x;
     const half_t* wb = p.w;
     const float* snb = nullptr;
+    const float* psb = nullptr;
     int ld_n0 = 0;
     auto aim = [&](const Tile& w) {
 #pragma unroll
@@ -79,18 +80,20 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const int pr = pix / PW, pc = pix - pr * PW;
             const int iy = w.ty0 * S - p.pad + pr, ix = w.tx0 * S - p.pad + pc;
             const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
+            a_goff[k] = ok ? ((iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + part * 8 : -1;
         }
         xb = p.x + (long long)w.b * p.x_bstride;
         wb = p.w + (long long)w.b * p.w_bstride;
         snb = p.sn ? p.sn + (long long)w.b * p.sn_stride + part * 8 : nullptr;
+        psb = p.pre_shift ? p.pre_shift + (long long)w.b * p.sn_stride + part * 8 : nullptr;
         ld_n0 = w.n0;
     };
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
+    h8 shf;  // pre-activation shift of the same channels (BigGAN: relu(x * sh + shf))
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sh[j] = (half_t)1.f;
+    for (int j = 0; j < 8; ++j) { sh[j] = (half_t)1.f; shf[j] = (half_t)0.f; }
 
     auto load_a = [&](int c0) {
 #pragma unroll
@@ -103,6 +106,11 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const f4 s0 = *(const f4*)(snb + c0), s1 = *(const f4*)(snb + c0 + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
+        }
+        if (psb) {
+            const f4 s0 = *(const f4*)(psb + c0), s1 = *(const f4*)(psb + c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { shf[j] = (half_t)s0[j]; shf[j + 4] = (half_t)s1[j]; }
         }
     };
     auto load_b = [&](int c0, int ty) {
@@ -122,7 +130,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const int v = t + 256 * k;
             if (NVA % 256 == 0 || v < NVA) {
                 h8 a = ra[k];
-                if (p.sn) a = a * sh;   // 4 x v_pk_mul_f16
+                if (p.pre_shift) {      // 4 x v_pk_fma_f16 + 4 x v_pk_max_f16; padding pixels stay zero
+                    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                    a = a_goff[k] >= 0 ? __builtin_elementwise_max(a * sh + shf, zero) : zero;
+                } else if (p.sn) a = a * sh;   // 4 x v_pk_mul_f16
                 *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
             }
         }
@@ -249,7 +260,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     }
                     const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
                     if (p.res) {
-                        const h4 r = *(const h4*)(p.res + oidx);
+                        const int rcs = p.res_cs ? p.res_cs : p.Cout;
+                        const long long ridx = p.res_up ? (((long long)b * (p.Ho >> 1) + (py >> 1)) * (p.Wo >> 1) + (px >> 1)) * rcs + o
+                                                        : (((long long)b * p.Ho + py) * p.Wo + px) * rcs + o;
+                        const h4 r = *(const h4*)(p.res + ridx);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
                     }
@@ -332,6 +346,7 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
     if (KS == 1 && S == 1 && p.pad == 0) {
         if (p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<1, 1, 8, 128>(p, st, "conv_tiled_kernel<1,1,8,128>");
         if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<1, 1, 8, 64>(p, st, "conv_tiled_kernel<1,1,8,64>");
+        if (p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<1, 1, 8, 32>(p, st, "conv_tiled_kernel<1,1,8,32>");
         return nullptr;
     }
     return nullptr;

@@ -73,7 +73,7 @@ struct BgState {
     float* rgb_b = nullptr;
     // activations
     float *cond = nullptr, *tab = nullptr, *h32 = nullptr, *a_S = nullptr;
-    half_t *x[2] = {nullptr, nullptr}, *t0 = nullptr, *t1 = nullptr, *t1u = nullptr, *t2 = nullptr, *t3 = nullptr, *r = nullptr;
+    half_t *x[2] = {nullptr, nullptr}, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
     half_t *a_T = nullptr, *a_theta = nullptr, *a_phi = nullptr, *a_gT = nullptr, *a_P = nullptr, *a_O = nullptr;
 };
 int glass_biggan_finalize(glass_engine* e);       // weights -> device layouts + activation buffers

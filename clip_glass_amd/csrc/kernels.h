@@ -70,9 +70,6 @@ void launch_bg_cond(const float* x, int P, int L, int zd, int nc, const float* e
 void launch_bg_bn_tables(float* tab, int P, int C, const float* inv_std, const float* mean, const float* prebias,
                          hipStream_t st);
 void launch_bg_to_half(const float* x, half_t* y, long long n, hipStream_t st);
-void launch_bg_affine_relu(const half_t* x, int B, long long hw, int C, const float* A, const float* S, int tstride,
-                           half_t* y, hipStream_t st);
-void launch_bg_gather(const half_t* x, int B, int H, int W, int C, int take, int up, half_t* y, hipStream_t st);
 void launch_bg_attn_split(const half_t* T, int B, int H, int W, int c8, int c2, half_t* theta, half_t* phi, half_t* gT,
                           hipStream_t st);
 void launch_bg_softmax(const float* S, long long rows, int n, half_t* Pm, hipStream_t st);
