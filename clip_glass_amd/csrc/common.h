@@ -53,6 +53,7 @@ struct ConvParams {
     int res_cs;             // channel stride of the residual rows (0 = Cout): first Cout of res_cs channels are used
     int res_up;             // 1: the residual is read through a nearest x2 upsample (it holds Ho/2 x Wo/2)
     float out_scale;
+    int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout
 };

@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
-    h8 shf;  // pre-activation shift of the same channels (BigGAN: relu(x * sh + shf))
+    int ld_c0 = 0;   // chunk offset of the patch held in ra (pre-activation shift is fetched at store time)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { sh[j] = (half_t)1.f; shf[j] = (half_t)0.f; }
+    for (int j = 0; j < 8; ++j) sh[j] = (half_t)1.f;
 
     auto load_a = [&](int c0) {
 #pragma unroll
@@ -107,11 +107,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
             for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
         }
-        if (psb) {
-            const f4 s0 = *(const f4*)(psb + c0), s1 = *(const f4*)(psb + c0 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { shf[j] = (half_t)s0[j]; shf[j + 4] = (half_t)s1[j]; }
-        }
+        ld_c0 = c0;
     };
     auto load_b = [&](int c0, int ty) {
 #pragma unroll
@@ -125,6 +121,12 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         }
     };
     auto store_a = [&]() {
+        h8 shf;   // pre-activation shift (BigGAN: relu(x * sh + shf)); fetched here to keep it out of the K-loop registers
+        if (psb) {
+            const f4 s0 = *(const f4*)(psb + ld_c0), s1 = *(const f4*)(psb + ld_c0 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { shf[j] = (half_t)s0[j]; shf[j + 4] = (half_t)s1[j]; }
+        }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             const int v = t + 256 * k;
@@ -210,8 +212,15 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             ty = nty;
         }
 
-        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ----
+        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad.  The finished
+        // fp16 quads of one tile row (32 px x NT ch) go through a per-wave LDS image and leave as 16-byte
+        // vectors in row order: each store instruction writes 1 KB of whole 64-byte lines instead of 64
+        // scattered 8-byte pieces (4x fewer line writes at the L2 for the store-heavy high-resolution layers).
         const int b = cur.b;
+        constexpr int OROW = NT * 2 + 16;                 // bytes per staged pixel (+16: bank spread)
+        const bool tstore = !p.up && (p.Cout & 7) == 0 && !p.no_tstore;
+        char* Os = smem + wave * (32 * OROW);
+        if (tstore) __syncthreads();                      // every wave is done reading As / Bs
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
@@ -270,8 +279,20 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     h4 out;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
-                    *(h4*)(p.y + oidx) = out;
+                    if (tstore) *(h4*)(Os + lr * OROW + (j * 32 + 8 * g + 4 * kh) * 2) = out;
+                    else *(h4*)(p.y + oidx) = out;
                 }
+            }
+            if (tstore) {
+                __builtin_amdgcn_wave_barrier();          // LDS is in-order per wave: only pin the compiler's order
+                half_t* yrow = p.y + (((long long)b * p.Ho + oy) * p.Wo + cur.tx0) * p.Cout + cur.n0;
+#pragma unroll
+                for (int k = 0; k < NT / 16; ++k) {
+                    const int v = lane + 64 * k;
+                    const int pix = v / (NT / 8), chv = v % (NT / 8);
+                    *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + pix * OROW + chv * 16);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (!has_next) break;
@@ -284,7 +305,8 @@ template <int KS, int S, int TH, int NT, bool PERSIST = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
-    constexpr int LDS = A_BYTES + KS * NT * ROWB;
+    constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = 4 * 32 * (NT * 2 + 16);   // K-loop images | epilogue image
+    constexpr int LDS = LDS_K > LDS_O ? LDS_K : LDS_O;
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
@@ -317,7 +339,10 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     return name;
 }
 
-const char* launch_conv_tiled(const ConvParams& p, hipStream_t st) {
+const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
+    ConvParams p = p0;
+    static const bool no_ts = getenv("GLASS_NO_TSTORE") != nullptr;   // experiment knob
+    if (no_ts) p.no_tstore = 1;
     if (p.y32 || !p.y) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;  // broadcast input (4x4 const): direct path
     if (p.Cin % 32 != 0 || p.Wc % 32 != 0 || p.Cout % 4 != 0) return nullptr;
