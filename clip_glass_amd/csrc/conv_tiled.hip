@@ -224,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
             const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
+            float nz_pix = 0.f;   // noise of this lane's pixel: one load per tile row, not one per quad
+            if (p.noise && !p.up) nz_pix = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy) * p.Wo + ox];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                         for (int q = 0; q < 4; ++q) v[q] *= d[q];
                     }
                     if (p.noise) {
-                        const float nz = p.noise_strength *
+                        const float nz = !p.up ? nz_pix : p.noise_strength *
                                          p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] += nz;
