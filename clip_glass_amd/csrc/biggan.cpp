@@ -232,6 +232,7 @@ int glass_biggan_finalize(glass_engine* e) {
     mtu = std::max(mtu, RR * g.rgb_cpad);
     if ((rc = dev_alloc(e, &g.cond, P * cd))) return rc;
     if ((rc = dev_alloc(e, &g.tab, P * 2 * g.Ctot))) return rc;
+    if ((rc = dev_alloc(e, &g.tab16, P * 2 * g.Ctot))) return rc;
     if ((rc = dev_alloc(e, &g.h32, CH * 16 * g.c0))) return rc;
     for (int i = 0; i < 2; ++i)
         if ((rc = dev_alloc(e, &g.x[i], CH * mx))) return rc;
@@ -262,6 +263,7 @@ int glass_biggan_prepare(glass_engine* e, int P) {
         Prof pr(e, "bg.bn_tables", 2.0 * P * cd * 2.0 * g.Ctot, 4.0 * ((double)cd * 2 * g.Ctot + 2.0 * P * 2 * g.Ctot));
         launch_dense(g.cond, cd, P, cd, g.bn_wt, 2 * g.Ctot, g.bn_bias, g.tab, 2 * g.Ctot, 0, 0, nullptr, 0, e->cur);
         launch_bg_bn_tables(g.tab, P, g.Ctot, g.bn_inv_std, g.bn_mean, g.bn_prebias, e->cur);
+        launch_bg_to_half(g.tab, g.tab16, (long long)P * 2 * g.Ctot, e->cur);
     }
     return GLASS_OK;
 }
@@ -299,6 +301,8 @@ void bg_conv(glass_engine* e, const char* tag, int c0, int B, const BgConv& q) {
     if (q.pre_bn >= 0) {
         p.sn = tab + q.pre_bn;
         p.pre_shift = tab + g.Ctot + q.pre_bn;
+        p.sn16 = g.tab16 + (size_t)c0 * 2 * g.Ctot + q.pre_bn;
+        p.pre_shift16 = p.sn16 + g.Ctot;
         p.sn_stride = 2 * g.Ctot;
     }
     if (q.bn_off >= 0) {

@@ -38,6 +38,9 @@ struct ConvParams {
     int Ho, Wo;             // output grid
     const float* sn;        // [B][sn_stride] normalised style (nullable)
     int sn_stride;
+    const half_t* sn16;     // fp16 copy of sn, same indexing: what the LDS-tiled kernels read (one 16-byte load per chunk, no
+                            // convert on the load path — a convert there would make the kernel wait for its own prefetch)
+    const half_t* pre_shift16;  // fp16 copy of pre_shift
     const float* pre_shift; // [B][sn_stride] (nullable; needs sn): x <- relu(x * sn + pre_shift) on the way in, in-bounds
                             // pixels only (zero padding stays zero) — BigGAN batch norm + ReLU ahead of the conv
     int in_up;              // 1: the input is read through a nearest x2 upsample (H, W = upsampled dims; x holds H/2 x W/2)

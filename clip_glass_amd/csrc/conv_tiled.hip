@@ -69,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     int a_goff[NA];   // element offset into the image (without chunk offset), -1 = zero fill
     const half_t* xb = p.x;
     const half_t* wb = p.w;
-    const float* snb = nullptr;
-    const float* psb = nullptr;
+    const half_t* snb = nullptr;
+    const half_t* psb = nullptr;
     int ld_n0 = 0;
     auto aim = [&](const Tile& w) {
 #pragma unroll
@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         }
         xb = p.x + (long long)w.b * p.x_bstride;
         wb = p.w + (long long)w.b * p.w_bstride;
-        snb = p.sn ? p.sn + (long long)w.b * p.sn_stride + part * 8 : nullptr;
-        psb = p.pre_shift ? p.pre_shift + (long long)w.b * p.sn_stride + part * 8 : nullptr;
+        snb = p.sn16 ? p.sn16 + (long long)w.b * p.sn_stride + part * 8 : nullptr;
+        psb = p.pre_shift16 ? p.pre_shift16 + (long long)w.b * p.sn_stride + part * 8 : nullptr;
         ld_n0 = w.n0;
     };
 
@@ -102,11 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
             if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
         }
-        if (snb) {
-            const f4 s0 = *(const f4*)(snb + c0), s1 = *(const f4*)(snb + c0 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
-        }
+        if (snb) sh = *(const h8*)(snb + c0);
         ld_c0 = c0;
     };
     auto load_b = [&](int c0, int ty) {
@@ -122,20 +118,16 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     };
     auto store_a = [&]() {
         h8 shf;   // pre-activation shift (BigGAN: relu(x * sh + shf)); fetched here to keep it out of the K-loop registers
-        if (psb) {
-            const f4 s0 = *(const f4*)(psb + ld_c0), s1 = *(const f4*)(psb + ld_c0 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { shf[j] = (half_t)s0[j]; shf[j + 4] = (half_t)s1[j]; }
-        }
+        if (psb) shf = *(const h8*)(psb + ld_c0);
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             const int v = t + 256 * k;
             if (NVA % 256 == 0 || v < NVA) {
                 h8 a = ra[k];
-                if (p.pre_shift) {      // 4 x v_pk_fma_f16 + 4 x v_pk_max_f16; padding pixels stay zero
+                if (psb) {              // 4 x v_pk_fma_f16 + 4 x v_pk_max_f16; padding pixels stay zero
                     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                     a = a_goff[k] >= 0 ? __builtin_elementwise_max(a * sh + shf, zero) : zero;
-                } else if (p.sn) a = a * sh;   // 4 x v_pk_mul_f16
+                } else if (snb) a = a * sh;    // 4 x v_pk_mul_f16
                 *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
             }
         }
@@ -346,6 +338,7 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     static const bool no_ts = getenv("GLASS_NO_TSTORE") != nullptr;   // experiment knob
     if (no_ts) p.no_tstore = 1;
     if (p.y32 || !p.y) return nullptr;
+    if ((p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16)) return nullptr;   // fp16 tables not provided: direct path
     if (p.x_bstride == 0 && p.B > 1) return nullptr;  // broadcast input (4x4 const): direct path
     if (p.Cin % 32 != 0 || p.Wc % 32 != 0 || p.Cout % 4 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;

@@ -530,6 +530,7 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_w0, (size_t)P * L))) return rc;
     if ((rc = dev_alloc(e, &e->d_w1, (size_t)P * L))) return rc;
     if ((rc = dev_alloc(e, &e->d_s, (size_t)P * e->S_total))) return rc;
+    if ((rc = dev_alloc(e, &e->d_s16, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
@@ -732,6 +733,7 @@ void collect_profile(glass_engine* e) {
 void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
     Prof pr(e, tag, flops, bytes);
     const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
+    if (!k) k = launch_conv_stream(p, e->cur);
     if (!k) k = launch_conv_tiled(p, e->cur);
     if (!k) k = launch_conv_direct(p, e->cur);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
@@ -804,6 +806,7 @@ static void run_styles(glass_engine* e, int P) {
                      e->cur);
         launch_style_norm(e->d_s, e->S_total, P, e->n_style, e->d_style_off, e->d_style_len, e->d_smax, e->d_epsrow,
                           1e-8f, e->cur);
+        launch_bg_to_half(e->d_s, e->d_s16, (long long)P * e->S_total, e->cur);   // fp16 table for the LDS-tiled kernels
     }
     {
         Prof pr(e, "demod", 0, 0);
@@ -853,6 +856,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             p.Neff = g.up ? 4 * g.cout : g.cout;
             p.Ho = p.Wo = g.res_out;
             p.sn = e->d_s + (size_t)c0 * e->S_total + g.style_off;
+            p.sn16 = e->d_s16 + (size_t)c0 * e->S_total + g.style_off;
             p.sn_stride = e->S_total;
             p.dscale = e->d_dscale + (size_t)c0 * e->D_total + g.ds_off;
             p.ds_stride = e->D_total;
@@ -865,6 +869,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             p.act = 1;
             if (g.premod) {   // weights already carry style and demod of each sample
                 p.sn = nullptr;
+                p.sn16 = nullptr;
                 p.dscale = nullptr;
                 p.w_bstride = g.welems;
                 if (g.up) { p.w_up = g.wm + (size_t)c0 * g.welems; p.w = nullptr; }

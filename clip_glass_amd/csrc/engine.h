@@ -72,6 +72,7 @@ struct BgState {
     half_t* rgb_w = nullptr;
     float* rgb_b = nullptr;
     // activations
+    half_t* tab16 = nullptr;   // fp16 copy of tab
     float *cond = nullptr, *tab = nullptr, *h32 = nullptr, *a_S = nullptr;
     half_t *x[2] = {nullptr, nullptr}, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
     half_t *a_T = nullptr, *a_theta = nullptr, *a_phi = nullptr, *a_gT = nullptr, *a_P = nullptr, *a_O = nullptr;
@@ -140,6 +141,7 @@ struct glass_engine {
     float* d_target = nullptr;
 
     // ---- activations / scratch ----
+    half_t* d_s16 = nullptr;   // fp16 copy of d_s (normalised styles)
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;
     std::vector<float*> d_noise;  // per noise layer: [n_mb_max][res*res]

@@ -8,6 +8,8 @@ const char* launch_gemm_direct(const GemmParams& p, hipStream_t st);
 // LDS-tiled fast paths; return nullptr when the shape is not supported (caller falls back to direct).
 const char* launch_conv_tiled(const ConvParams& p, hipStream_t st);
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
+// persistent streaming 3x3 conv for the 32 -> 32 channel 1024^2 layers (conv_stream.hip); nullptr when unsupported
+const char* launch_conv_stream(const ConvParams& p, hipStream_t st);
 // fused transposed-conv + FIR + epilogue (upfir.hip); nullptr when unsupported
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);
 

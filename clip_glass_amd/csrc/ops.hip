@@ -91,6 +91,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         p.w_up = dv.up16v(pk2);
     }
     p.sn = dv.up32(d->sn, (size_t)d->B * d->Cin); p.sn_stride = d->Cin;
+    p.sn16 = dv.up16(d->sn, (size_t)d->B * d->Cin);
     p.dscale = dv.up32(d->dscale, (size_t)d->B * d->Cout); p.ds_stride = d->Cout;
     p.batch_size = d->batch_size > 0 ? d->batch_size : 1;
     p.noise = dv.up32(d->noise, (size_t)(d->B / p.batch_size) * d->Ho * d->Wo);
@@ -108,7 +109,9 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 2) {
         if (!launch_conv_tiled(p, 0)) { glass_set_error("tiled conv: unsupported shape"); return GLASS_ERR_ARG; }
-    } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
+    } else if (d->impl == 4) {
+        if (!launch_conv_stream(p, 0)) { glass_set_error("streaming conv: unsupported shape"); return GLASS_ERR_ARG; }
+    } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
     int rc = finish();
     if (rc) return rc;
     return down16(d->y, y, nout);

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     }
     const half_t* xb = p.x + (long long)b * p.x_bstride;
     const half_t* wb = p.w_up + (long long)b * p.w_bstride;
-    const float* snb = p.sn ? p.sn + (long long)b * p.sn_stride + part * 8 : nullptr;
+    const half_t* snb = p.sn16 ? p.sn16 + (long long)b * p.sn_stride + part * 8 : nullptr;
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
@@ -71,11 +71,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
             if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
         }
-        if (snb) {
-            const f4 s0 = *(const f4*)(snb + c0), s1 = *(const f4*)(snb + c0 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sh[j] = (half_t)s0[j]; sh[j + 4] = (half_t)s1[j]; }
-        }
+        if (snb) sh = *(const h8*)(snb + c0);
     };
     auto load_b = [&](int c0) {
 #pragma unroll
@@ -236,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
 }
 
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
-    if (!p.up || !p.w_up || p.y32 || !p.y || p.res) return nullptr;
+    if (!p.up || !p.w_up || p.y32 || !p.y || p.res || (p.sn && !p.sn16)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.W < 16 || p.KS != 3) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;

@@ -77,6 +77,29 @@ def _modconv_case(up, impl, B=4, H=8, Cin=32, Cout=48, L=24, batch_size=2, broad
     return got, ref
 
 
+def test_conv_stream_matches_tiled_and_direct():
+    """conv_stream.hip (persistent, 3 tiles in flight) on a shape with uneven tile ranges per workgroup, image borders
+    in every direction, per-sample style + demod + noise + bias + lrelu: same numbers as the tiled / direct kernels."""
+    rng = np.random.default_rng(5)
+    B, H, W, C = 5, 256, 1024 + 32, 32       # 5 * 32 * 33 = 5280 tiles over 512 workgroups: 11/10-tile ranges, sample switches
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    sn = rng.uniform(0.5, 1.0, (B, C)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, C)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32) * 0.2
+    res = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    kw = dict(sn=sn, dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, out_scale=0.7)
+    got = ops.conv(x, w, impl=4, **kw)
+    ref_t = ops.conv(x, w, impl=2, **kw)
+    ref_d = ops.conv(x, w, impl=1, **kw)
+    # same staging and MFMA order as the tiled kernel; the epilogue contracts v*d + noise into one fma, so a few
+    # outputs differ by one fp16 ulp
+    assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max())), float(np.abs(got - ref_t).max())
+    assert (got != ref_t).mean() < 1e-2
+    check("conv_stream vs direct", got, ref_d, 4e-3)
+
+
 @pytest.mark.parametrize("impl", [1, 2])
 def test_conv_modulated_demod_noise(impl):
     got, ref = _modconv_case(False, impl)
