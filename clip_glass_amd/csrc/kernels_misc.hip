@@ -423,43 +423,51 @@ __global__ __launch_bounds__(256) void blur_kernel(const half_t* x, int H, int W
     const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
     const half_t* xb = x + (long long)b * H * W * C + g * 8;
     half_t* ob = out + (long long)b * Ho * Wo * C + g * 8;
-    int ixs[4];
-    bool xok[4];
+    // Loads are UNCONDITIONAL (clamped column / row, the tap weight carries the zero padding): a load under a
+    // branch makes the compiler wait for it at the join, i.e. one load in flight per thread.
+    int xoff[4];
+    float fx[4];
 #pragma unroll
     for (int jx = 0; jx < 4; ++jx) {
-        ixs[jx] = ox * STRIDE + jx - PAD;
-        xok[jx] = ixs[jx] >= 0 && ixs[jx] < W;
+        const int ix = ox * STRIDE + jx - PAD;
+        const bool ok = ix >= 0 && ix < W;
+        xoff[jx] = (ok ? ix : 0) * C;
+        fx[jx] = ok ? f[jx] : 0.f;
     }
     constexpr int NR = (RS - 1) * STRIDE + 4;            // input rows touched by this strip
+    constexpr int RB = STRIDE == 1 ? 2 : 2;              // input rows fetched per batch (RB * 4 loads in flight)
     float hs[4][8];                                      // sliding window of horizontal sums
     const int iy0 = oy0 * STRIDE - PAD;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int iy = iy0 + r;
-        float h[8];
+    for (int r0 = 0; r0 < NR; r0 += RB) {
+        h8 v[RB][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) h[j] = 0.f;
-        if (iy >= 0 && iy < H) {
+        for (int q = 0; q < RB; ++q) {
+            const int iy = min(max(iy0 + r0 + q, 0), H - 1);
 #pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                if (!xok[jx]) continue;
-                const h8 v = *(const h8*)(xb + ((long long)iy * W + ixs[jx]) * C);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] += f[jx] * (float)v[j];
-            }
+            for (int jx = 0; jx < 4; ++jx) v[q][jx] = *(const h8*)(xb + (long long)iy * W * C + xoff[jx]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) hs[r & 3][j] = h[j];
-        // output row whose 4-row window ends at input row r
-        if (r >= 3 && (r - 3) % STRIDE == 0) {
-            const int oy = oy0 + (r - 3) / STRIDE;
-            if (oy < Ho) {
-                h8 o;
+        for (int q = 0; q < RB; ++q) {
+            const int r = r0 + q;
+            if (r >= NR) break;
+            const int iy = iy0 + r;
+            const float rw = (iy >= 0 && iy < H) ? 1.f : 0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = (half_t)(f[0] * hs[(r - 3) & 3][j] + f[1] * hs[(r - 2) & 3][j] + f[2] * hs[(r - 1) & 3][j] +
-                                    f[3] * hs[r & 3][j]);
-                *(h8*)(ob + ((long long)oy * Wo + ox) * C) = o;
+            for (int j = 0; j < 8; ++j)
+                hs[r & 3][j] = rw * (fx[0] * (float)v[q][0][j] + fx[1] * (float)v[q][1][j] + fx[2] * (float)v[q][2][j] +
+                                     fx[3] * (float)v[q][3][j]);
+            // output row whose 4-row window ends at input row r
+            if (r >= 3 && (r - 3) % STRIDE == 0) {
+                const int oy = oy0 + (r - 3) / STRIDE;
+                if (oy < Ho) {
+                    h8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        o[j] = (half_t)(f[0] * hs[(r - 3) & 3][j] + f[1] * hs[(r - 2) & 3][j] + f[2] * hs[(r - 1) & 3][j] +
+                                        f[3] * hs[r & 3][j]);
+                    *(h8*)(ob + ((long long)oy * Wo + ox) * C) = o;
+                }
             }
         }
     }
