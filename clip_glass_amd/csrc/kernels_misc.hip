@@ -253,12 +253,15 @@ __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int 
         for (int c = 0; c < 3; ++c) yout[((long long)b * 3 + c) * hw + pix] = r[c];
     }
 }
-// Thread-per-pixel variant: best for C <= 64 (a pixel's channels are <= 128 contiguous bytes).
-__global__ __launch_bounds__(256) void torgb_pix_kernel(const half_t* x, int H, int W, int C, const float* wrgb,
+// Thread-per-pixel variant: best for C <= 64 (a pixel's channels are <= 128 contiguous bytes).  C is a template
+// parameter so the pixel's C/8 16-byte loads are all issued before the first use (a runtime loop keeps ONE load in
+// flight per thread), and the skip-image taps are unconditional (clamped index, zero weight) for the same reason.
+template <int C>
+__global__ __launch_bounds__(256) void torgb_pix_kernel(const half_t* x, int H, int W, const float* wrgb,
                                                         const float* bias, const float* sn, int sn_stride,
                                                         const float* smax, int smax_stride, const float* yprev,
                                                         float* yout) {
-    extern __shared__ float wl[];  // [3][C] modulated weights of this sample
+    __shared__ float wl[3 * C];  // modulated weights of this sample
     const int b = blockIdx.y;
     const float sm = smax[(long long)b * smax_stride];
     for (int e = threadIdx.x; e < 3 * C; e += 256) wl[e] = wrgb[e] * sn[(long long)b * sn_stride + e % C] * sm;
@@ -267,36 +270,41 @@ __global__ __launch_bounds__(256) void torgb_pix_kernel(const half_t* x, int H, 
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= hw) return;
     const half_t* xp = x + ((long long)b * hw + pix) * C;
-    float r[3] = {bias[0], bias[1], bias[2]};
-    for (int i = 0; i < C; i += 8) {
-        const h8 v = *(const h8*)(xp + i);
+    h8 v[C / 8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float f = (float)v[j];
-            r[0] += f * wl[i + j]; r[1] += f * wl[C + i + j]; r[2] += f * wl[2 * C + i + j];
-        }
-    }
+    for (int i = 0; i < C / 8; ++i) v[i] = *(const h8*)(xp + i * 8);
+    float ys[3][4];      // skip-image taps (previous resolution), fetched alongside
+    float wt[4];
     if (yprev) {
         const int py = pix / W, px = pix - py * W;
         const int h2 = H >> 1, w2_ = W >> 1;
         const int my = py >> 1, mx = px >> 1;
         const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2_;
-            float s = 0.f;
+        for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const int sy = my - 1 + dy;
-                if (sy < 0) continue;
-                const float wy = dy ? 1.f - wy0 : wy0;
+            for (int dx = 0; dx < 2; ++dx) {
+                const int sy = my - 1 + dy, sx = mx - 1 + dx;
+                wt[dy * 2 + dx] = (sy >= 0 && sx >= 0) ? (dy ? 1.f - wy0 : wy0) * (dx ? 1.f - wx0 : wx0) : 0.f;
+                const int off = max(sy, 0) * w2_ + max(sx, 0);
 #pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    const int sx = mx - 1 + dx;
-                    if (sx < 0) continue;
-                    s += wy * (dx ? 1.f - wx0 : wx0) * yp[sy * w2_ + sx];
-                }
+                for (int c = 0; c < 3; ++c) ys[c][dy * 2 + dx] = yprev[((long long)b * 3 + c) * h2 * w2_ + off];
             }
+    }
+    float r[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+    for (int i = 0; i < C / 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[i][j];
+            r[0] += f * wl[i * 8 + j]; r[1] += f * wl[C + i * 8 + j]; r[2] += f * wl[2 * C + i * 8 + j];
+        }
+    if (yprev) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;   // same accumulation order as before: (dy, dx) = (0,0), (0,1), (1,0), (1,1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s += wt[q] * ys[c][q];
             r[c] += s;
         }
     }
@@ -316,11 +324,10 @@ static void launch_torgb_t(const half_t* x, int B, int H, int W, int C, const fl
 void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                   const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
                   float* yout, hipStream_t st) {
-    if (C <= 64) {
-        hipLaunchKernelGGL(torgb_pix_kernel, dim3((H * W + 255) / 256, B), dim3(256), 3 * C * sizeof(float), st, x, H, W,
-                           C, wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout);
-        return;
-    }
+#define TORGB_PIX(CC) if (C == CC) { hipLaunchKernelGGL(torgb_pix_kernel<CC>, dim3((H * W + 255) / 256, B), dim3(256), 0, st, x, H, W, \
+                                                       wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout); return; }
+    TORGB_PIX(16) TORGB_PIX(32) TORGB_PIX(64)
+#undef TORGB_PIX
 #define TORGB_CASE(L) case L: launch_torgb_t<L>(x, B, H, W, C, wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout, st); break;
     switch (C / 8) {
         TORGB_CASE(2) TORGB_CASE(4) TORGB_CASE(8) TORGB_CASE(16) TORGB_CASE(32) TORGB_CASE(64)
@@ -375,20 +382,24 @@ void launch_resize_patches(const float* y, int B, int R, int clip_res, int ps, h
 // (stylegan2/models.py:1125-1143).  One thread per pixel, 16-byte NHWC stores.
 __global__ __launch_bounds__(256) void fromrgb_kernel(const float* y, int hw, int Cout, const float* w,
                                                       const float* bias, half_t* out) {
-    extern __shared__ float wl[];  // [Cout][3] then bias[Cout]
+    extern __shared__ float wl[];  // [Cout][3], bias[Cout], then the per-wave output image [4][64 px][Cout*2 + 16 B]
     for (int e = threadIdx.x; e < Cout * 3; e += 256) wl[e] = w[e];
     for (int e = threadIdx.x; e < Cout; e += 256) wl[Cout * 3 + e] = bias[e];
     __syncthreads();
     const int b = blockIdx.y;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= hw) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pix0 = blockIdx.x * 256 + wave * 64;             // first pixel of this wave
+    const int pix = min(pix0 + lane, hw - 1);
     float v[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float n = fminf(fmaxf((y[((long long)b * 3 + c) * hw + pix] + 1.f) * 0.5f, 0.f), 1.f);
         v[c] = n * 2.f - 1.f;
     }
-    half_t* op = out + ((long long)b * hw + pix) * Cout;
+    // one thread computes all channels of its pixel; the wave's 64 x Cout block goes through LDS and leaves as
+    // 16-byte vectors in row order (whole 64-byte lines per store instruction instead of 64 scattered pieces)
+    const int orow = Cout * 2 + 16;
+    char* Os = (char*)(wl + Cout * 4) + wave * 64 * orow;
     for (int o = 0; o < Cout; o += 8) {
         h8 r;
 #pragma unroll
@@ -396,14 +407,21 @@ __global__ __launch_bounds__(256) void fromrgb_kernel(const float* y, int hw, in
             const float* wp = wl + (o + j) * 3;
             r[j] = (half_t)lrelu_sqrt2(wp[0] * v[0] + wp[1] * v[1] + wp[2] * v[2] + wl[Cout * 3 + o + j]);
         }
-        *(h8*)(op + o) = r;
+        *(h8*)(Os + lane * orow + o * 2) = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int cg = Cout >> 3;
+    half_t* ob = out + ((long long)b * hw + pix0) * Cout;
+    for (int u = lane; u < 64 * cg; u += 64) {
+        const int p = u / cg, g = u - p * cg;
+        if (pix0 + p < hw) *(h8*)(ob + (long long)p * Cout + g * 8) = *(const h8*)(Os + p * orow + g * 16);
     }
 }
 void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, const float* bias, half_t* out,
                     hipStream_t st) {
     const int hw = R * R;
-    hipLaunchKernelGGL(fromrgb_kernel, dim3((hw + 255) / 256, B), dim3(256), Cout * 4 * sizeof(float), st, y, hw,
-                       Cout, w, bias, out);
+    const size_t lds = Cout * 4 * sizeof(float) + 4 * 64 * (Cout * 2 + 16);
+    hipLaunchKernelGGL(fromrgb_kernel, dim3((hw + 255) / 256, B), dim3(256), lds, st, y, hw, Cout, w, bias, out);
 }
 
 // ---- FIR filters of the D down path (modules.py:1204-1220, 499-523) -----------------
