@@ -154,6 +154,29 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     }
     __syncthreads();   // everyone is done with the staging area: overlay T
 
+    // Everything the epilogue needs from global memory is fetched HERE, unconditionally and in one batch (a load
+    // under a branch, consumed at once, costs a full round trip each: 32 serial demod loads + 12 serial noise
+    // loads per block before): 4 demod quads, 2 bias quads, this thread's 12 noise values.
+    const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
+    const int px = min(txi * 60 + oxl, p.Wo - 1);
+    f4 dq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dq[g] = f4{1.f, 1.f, 1.f, 1.f};
+        if (p.dscale) dq[g] = *(const f4*)(p.dscale + (long long)b * p.ds_stride + n0 + 8 * g + 4 * kh);
+    }
+    f4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        bq0 = *(const f4*)(p.bias + n0 + cg * 8);
+        bq1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
+    }
+    float nzv[12];
+    if (p.noise) {
+        const float* nzp = p.noise + (long long)(b / p.batch_size) * p.Ho * p.Wo + px;
+#pragma unroll
+        for (int r = 0; r < 12; ++r) nzv[r] = nzp[(long long)min(tyi * 12 + r, p.Ho - 1) * p.Wo];
+    }
+
     // ---- t tile -> LDS (demod applied; it commutes with the FIR) ---------------------------------
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -162,9 +185,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             const int lty = 2 * (wave * 2 + i) + (ph >> 1), ltx = 2 * lr + (ph & 1);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int ch = 8 * g + 4 * kh;
-                f4 d = {1.f, 1.f, 1.f, 1.f};
-                if (p.dscale) d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + n0 + ch);
+                const f4 d = dq[g];
                 h4 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][g * 4 + q] * d[q]);
@@ -179,20 +200,11 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     // ---- FIR (separable [1,3,3,1]/4 per axis, sliding window) + noise + bias + lrelu -----------
     // Packed-fp16 arithmetic (v_pk_fma_f16): the t tile is fp16 already; 4+4 taps with weights
     // {1/4,3/4} add ~2 fp16 roundings per output — same class as the fp16 activation store.
-    if (t >= 240) return;
-    const int cg = t & 3, oxl = t >> 2;              // 8-channel group, local output column 0..59
-    const int px = txi * 60 + oxl;
-    if (px >= p.Wo) return;
+    if (t >= 240 || txi * 60 + oxl >= p.Wo) return;
     const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
     h8 bias8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bias8[j] = (half_t)0.f;
-    if (p.bias) {
-        const f4 b0 = *(const f4*)(p.bias + n0 + cg * 8), b1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)b0[j]; bias8[j + 4] = (half_t)b1[j]; }
-    }
-    const float* nz = p.noise ? p.noise + (long long)(b / p.batch_size) * p.Ho * p.Wo : nullptr;
+    for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)bq0[j]; bias8[j + 4] = (half_t)bq1[j]; }
     const half_t k1 = (half_t)(GLASS_SQRT2 * p.out_scale), k2 = (half_t)(0.2f * GLASS_SQRT2 * p.out_scale);
     h8 hs[4];
 #pragma unroll
@@ -216,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             if (py < p.Ho) {
                 h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + (hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft;
                 half_t nv = (half_t)0.f;
-                if (nz) nv = (half_t)(p.noise_strength * nz[(long long)py * p.Wo + px]);
+                if (p.noise) nv = (half_t)(p.noise_strength * nzv[r - 4]);
                 v = v + bias8 + nv;
                 if (p.act) {
                     const h8 a = v * k1, c2 = v * k2;     // lrelu(v)*sqrt2*scale = max(v*k1, v*k2) for k1 > k2 > 0
