@@ -36,6 +36,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     constexpr int NVB = KS * NT * 4;           // 16-byte vectors in one weight stage
     constexpr int NB = (NVB + 255) / 256;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
+    constexpr int LDS_K_ = A_BYTES + KS * NT * ROWB, LDS_O_ = TH * 32 * (NT * 2 + 16);
+    constexpr int CC_OFF = LDS_K_ > LDS_O_ ? LDS_K_ : LDS_O_;   // epilogue constants sit behind both images
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     Tile cur = decode(id);
     while (id < n_work && !cur.valid) { id += gridDim.x; cur = decode(id); }   // skip padding items
     if (id >= n_work) return;
+    // per-channel epilogue constants of this block's n tile (demod scale, bias, shift) are parked in LDS by the epilogue
+    // prologue: one batched round trip instead of one per accumulator quad
+    const bool fast = !PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore;
+    float* Cc = (float*)(smem + CC_OFF);   // [3][NT]
     aim(cur);
     load_a(0);
     load_b(0, 0);
@@ -204,89 +210,152 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             ty = nty;
         }
 
-        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad.  The finished
-        // fp16 quads of one tile row (32 px x NT ch) go through a per-wave LDS image and leave as 16-byte
-        // vectors in row order: each store instruction writes 1 KB of whole 64-byte lines instead of 64
-        // scattered 8-byte pieces (4x fewer line writes at the L2 for the store-heavy high-resolution layers).
+        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ------------------
         const int b = cur.b;
-        constexpr int OROW = NT * 2 + 16;                 // bytes per staged pixel (+16: bank spread)
-        const bool tstore = !p.up && (p.Cout & 7) == 0 && !p.no_tstore;
-        char* Os = smem + wave * (32 * OROW);
-        if (tstore) __syncthreads();                      // every wave is done reading As / Bs
+        if (fast) {
+            // Fast path.  Nothing here waits on a global load it has just issued: the per-channel constants were staged
+            // in LDS at kernel start, the noise values and residual quads of a tile row are fetched as one batch, and
+            // the finished fp16 quads go through a per-wave LDS image and leave as 16-byte vectors in row order (one
+            // store instruction = 1 KB of whole 64-byte lines instead of 64 scattered 8-byte pieces).
+            constexpr int OROW = NT * 2 + 16;             // bytes per staged pixel (+16: bank spread)
+            char* Os = smem + wave * (RW * 32 * OROW);    // this wave's RW tile rows
+            const int oy0 = cur.ty0 + wave * RW, ox = cur.tx0 + lr;
+            // ONE batch of global loads: this thread's per-channel constants (threads < NT) and its pixels' noise values
+            float c_d = 1.f, c_b = 0.f, c_s = 0.f;
+            if (t < NT) {
+                const int o = cur.n0 + t;
+                if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
+                if (p.bias) c_b = p.bias[o];
+                if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
+            }
+            float nzr[RW];
 #pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
-            float nz_pix = 0.f;   // noise of this lane's pixel: one load per tile row, not one per quad
-            if (p.noise && !p.up) nz_pix = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy) * p.Wo + ox];
+            for (int i = 0; i < RW; ++i) {
+                nzr[i] = 0.f;
+                if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy0 + i) * p.Wo + ox];
+            }
+            if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }   // Cc sits behind As / Bs / Os
+            __syncthreads();                              // every wave is done reading As / Bs; constants visible
+            const int rcs = p.res_cs ? p.res_cs : p.Cout;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                h4 rq[4][RW];                             // residual quads of this 32-channel slice: one batch of loads
+                if (p.res) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        const int oy = oy0 + i;
+                        const half_t* rp = p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs
+                                                             : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + cur.n0 + j * 32 + 4 * kh;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rq[g][i] = *(const h4*)(rp + 8 * g);
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nb = cur.n0 + j * 32 + 8 * g + 4 * kh;  // first of 4 consecutive n
-                    int o = nb, py = oy, px = ox;
-                    if (p.up) {
-                        const int ph = nb / p.Cout;
-                        o = nb - ph * p.Cout;
-                        py = 2 * oy + (ph >> 1);
-                        px = 2 * ox + (ph & 1);
+                    const int nl = j * 32 + 8 * g + 4 * kh;   // first of 4 consecutive channels, local to the n tile
+                    const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q] = acc[i][j][g * 4 + q] * d[q];
+                            v[q] += nzr[i];
+                            v[q] += bb[q];
+                            v[q] += sh4[q];
+                        }
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                        } else if (p.act == 2) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        if (p.res) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += (float)rq[g][i][q];
+                        }
+                        h4 out;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                        *(h4*)(Os + (i * 32 + lr) * OROW + nl * 2) = out;
                     }
-                    float v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
-                    if (p.dscale) {
-                        const f4 d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] *= d[q];
-                    }
-                    if (p.noise) {
-                        const float nz = !p.up ? nz_pix : p.noise_strength *
-                                         p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += nz;
-                    }
-                    if (p.bias) {
-                        const f4 bb = *(const f4*)(p.bias + o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += bb[q];
-                    }
-                    if (p.shift) {
-                        const f4 sh4 = *(const f4*)(p.shift + (long long)b * p.ds_stride + o);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += sh4[q];
-                    }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
-                    } else if (p.act == 2) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                    }
-                    const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
-                    if (p.res) {
-                        const int rcs = p.res_cs ? p.res_cs : p.Cout;
-                        const long long ridx = p.res_up ? (((long long)b * (p.Ho >> 1) + (py >> 1)) * (p.Wo >> 1) + (px >> 1)) * rcs + o
-                                                        : (((long long)b * p.Ho + py) * p.Wo + px) * rcs + o;
-                        const h4 r = *(const h4*)(p.res + ridx);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
-                    }
-                    h4 out;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
-                    if (tstore) *(h4*)(Os + lr * OROW + (j * 32 + 8 * g + 4 * kh) * 2) = out;
-                    else *(h4*)(p.y + oidx) = out;
-                }
+                    __builtin_amdgcn_sched_barrier(0);    // keep one quad's constants live at a time (no hoisting of all
+                }                                         // 16 quads' LDS reads to the top: that spills)
             }
-            if (tstore) {
-                __builtin_amdgcn_wave_barrier();          // LDS is in-order per wave: only pin the compiler's order
-                half_t* yrow = p.y + (((long long)b * p.Ho + oy) * p.Wo + cur.tx0) * p.Cout + cur.n0;
+            __builtin_amdgcn_wave_barrier();              // LDS is in-order per wave: only pin the compiler's order
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + cur.tx0) * p.Cout + cur.n0;
 #pragma unroll
                 for (int k = 0; k < NT / 16; ++k) {
                     const int v = lane + 64 * k;
                     const int pix = v / (NT / 8), chv = v % (NT / 8);
-                    *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + pix * OROW + chv * 16);
+                    *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
                 }
-                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // generic path (folded up-conv with depth-to-space, odd channel counts, persistent variant)
+#pragma unroll
+            for (int i = 0; i < RW; ++i) {
+                const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = cur.n0 + j * 32 + 8 * g + 4 * kh;  // first of 4 consecutive n
+                        int o = nb, py = oy, px = ox;
+                        if (p.up) {
+                            const int ph = nb / p.Cout;
+                            o = nb - ph * p.Cout;
+                            py = 2 * oy + (ph >> 1);
+                            px = 2 * ox + (ph & 1);
+                        }
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
+                        if (p.dscale) {
+                            const f4 d = *(const f4*)(p.dscale + (long long)b * p.ds_stride + o);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] *= d[q];
+                        }
+                        if (p.noise) {
+                            const float nz = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += nz;
+                        }
+                        if (p.bias) {
+                            const f4 bb = *(const f4*)(p.bias + o);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += bb[q];
+                        }
+                        if (p.shift) {
+                            const f4 sh4 = *(const f4*)(p.shift + (long long)b * p.ds_stride + o);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += sh4[q];
+                        }
+                        if (p.act == 1) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                        } else if (p.act == 2) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                        }
+                        const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
+                        if (p.res) {
+                            const int rcs = p.res_cs ? p.res_cs : p.Cout;
+                            const long long ridx = p.res_up ? (((long long)b * (p.Ho >> 1) + (py >> 1)) * (p.Wo >> 1) + (px >> 1)) * rcs + o
+                                                            : (((long long)b * p.Ho + py) * p.Wo + px) * rcs + o;
+                            const h4 r = *(const h4*)(p.res + ridx);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[q] += (float)r[q];
+                        }
+                        h4 out;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                        *(h4*)(p.y + oidx) = out;
+                    }
+                }
             }
         }
         if (!has_next) break;
@@ -299,8 +368,8 @@ template <int KS, int S, int TH, int NT, bool PERSIST = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
-    constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = 4 * 32 * (NT * 2 + 16);   // K-loop images | epilogue image
-    constexpr int LDS = LDS_K > LDS_O ? LDS_K : LDS_O;
+    constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = TH * 32 * (NT * 2 + 16);   // K-loop images | epilogue image
+    constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4;
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
