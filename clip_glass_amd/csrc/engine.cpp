@@ -145,7 +145,7 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     glass_engine* e = new glass_engine();
     e->cfg = *cfg;
     e->R = cfg->n_blocks > 0 ? 4 << (cfg->n_blocks - 1) : bg_res;
-    int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (16 / cfg->batch_size) * cfg->batch_size);
+    int chunk = cfg->chunk > 0 ? cfg->chunk : std::max(cfg->batch_size, (64 / cfg->batch_size) * cfg->batch_size);   // 288 GB of HBM: one chunk of 64 candidates (36 GB of activations at 1024 px) keeps every launch large
     chunk = std::min(chunk, cfg->max_pop);
     if (chunk % cfg->batch_size != 0) {
         delete e;
