@@ -208,49 +208,57 @@ __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int 
         w1[j] = wrgb[C + sub * 8 + j] * s;
         w2[j] = wrgb[2 * C + sub * 8 + j] * s;
     }
-    const int hw = H * W;
-    constexpr int PPB = 256 / LPP;                       // pixels per block per iteration
-    for (int pix = blockIdx.x * PPB + threadIdx.x / LPP; pix < hw; pix += gridDim.x * PPB) {
-        const h8 v = *(const h8*)(x + ((long long)b * hw + pix) * C + sub * 8);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int hw = H * W, h2 = H >> 1, w2_ = W >> 1;
+    constexpr int PPB = 256 / LPP;                       // pixels per block per sub-step
+    constexpr int U = 4;                                 // pixels per thread per iteration: U feature loads (+ 4 U skip
+    const int cch = sub < 3 ? sub : 0;                   // taps on lanes 0..2 of a pixel) in flight, all unconditional
+    const float bc = bias[cch];
+    const float* yp = yprev ? yprev + ((long long)b * 3 + cch) * h2 * w2_ : nullptr;
+    for (int base = blockIdx.x * PPB * U; base < hw; base += gridDim.x * PPB * U) {
+        h8 v[U];
+        float ys[U][4], wt[U][4];
+        int pixv[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float f = (float)v[j];
-            a0 += f * w0[j]; a1 += f * w1[j]; a2 += f * w2[j];
-        }
+        for (int u = 0; u < U; ++u) {
+            const int pix = base + u * PPB + threadIdx.x / LPP;
+            pixv[u] = pix;
+            const int pc = min(pix, hw - 1);
+            v[u] = *(const h8*)(x + ((long long)b * hw + pc) * C + sub * 8);
+            if (yp) {
+                const int py = pc / W, px = pc - py * W;
+                const int my = py >> 1, mx = px >> 1;
+                const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
 #pragma unroll
-        for (int o = LPP / 2; o > 0; o >>= 1) {
-            a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o);
-        }
-        if (sub != 0) continue;
-        float r[3] = {a0 + bias[0], a1 + bias[1], a2 + bias[2]};
-        if (yprev) {
-            const int py = pix / W, px = pix - py * W;
-            const int h2 = H >> 1, w2_ = W >> 1;
-            const int my = py >> 1, mx = px >> 1;
-            const float wy0 = (py & 1) ? 0.25f : 0.75f, wx0 = (px & 1) ? 0.25f : 0.75f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* yp = yprev + ((long long)b * 3 + c) * h2 * w2_;
-                float s = 0.f;
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    const int sy = my - 1 + dy;
-                    if (sy < 0) continue;
-                    const float wy = dy ? 1.f - wy0 : wy0;
+                for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        const int sx = mx - 1 + dx;
-                        if (sx < 0) continue;
-                        const float wx = dx ? 1.f - wx0 : wx0;
-                        s += wy * wx * yp[sy * w2_ + sx];
+                        const int sy = my - 1 + dy, sx = mx - 1 + dx;
+                        wt[u][dy * 2 + dx] = (sy >= 0 && sx >= 0) ? (dy ? 1.f - wy0 : wy0) * (dx ? 1.f - wx0 : wx0) : 0.f;
+                        ys[u][dy * 2 + dx] = yp[max(sy, 0) * w2_ + max(sx, 0)];
                     }
-                }
-                r[c] += s;
             }
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) yout[((long long)b * 3 + c) * hw + pix] = r[c];
+        for (int u = 0; u < U; ++u) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = (float)v[u][j];
+                a0 += f * w0[j]; a1 += f * w1[j]; a2 += f * w2[j];
+            }
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) {
+                a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o);
+            }
+            float r = (cch == 0 ? a0 : cch == 1 ? a1 : a2) + bc;   // lane c of the pixel finishes output channel c
+            if (yp) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += wt[u][q] * ys[u][q];
+                r += s;
+            }
+            if (sub < 3 && pixv[u] < hw) yout[((long long)b * 3 + sub) * hw + pixv[u]] = r;
+        }
     }
 }
 // Thread-per-pixel variant: best for C <= 64 (a pixel's channels are <= 128 contiguous bytes).  C is a template
@@ -315,7 +323,7 @@ template <int LPP>
 static void launch_torgb_t(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                            const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
                            float* yout, hipStream_t st) {
-    const int ppb = 256 / LPP;
+    const int ppb = (256 / LPP) * 4;                     // U = 4 pixels per thread per iteration
     int gx = (H * W + ppb - 1) / ppb;
     if (gx > 2048) gx = 2048;                            // grid-stride the rest
     hipLaunchKernelGGL(torgb_kernel<LPP>, dim3(gx, B), dim3(256), 0, st, x, H, W, C, wrgb, bias, sn, sn_stride, smax,
