@@ -52,7 +52,17 @@ __device__ __forceinline__ void dense_body(const float* x, int ldx, int P, int K
         __syncthreads();
         if (n < N) {
             const int kmax = min(DENSE_KT, K - k0);
-            for (int kk = 0; kk < kmax; ++kk) {
+            int kk = 0;
+            for (; kk + 16 <= kmax; kk += 16) {      // 16 weight loads in flight (a one-load-per-iteration loop is a chain
+                float w[16];                         // of L2 round trips: 512 of them per mapping layer)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[u] = wt[(long long)(k0 + kk + u) * N + n];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += w[u] * xs[pg * 4 + j][kk + u];
+            }
+            for (; kk < kmax; ++kk) {
                 const float w = wt[(long long)(k0 + kk) * N + n];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[j] += w * xs[pg * 4 + j][kk];
