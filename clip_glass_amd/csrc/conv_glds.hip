@@ -1,0 +1,254 @@
+// conv_glds.hip — 3x3 stride-1 convolution for the MFMA-bound mid-resolution layers (Cin >= 128, 128-wide n tiles),
+// staged by LDS-DMA (`global_load_lds_dwordx4`) instead of registers.
+//
+// conv_tiled.hip sits at the VGPR cap (256) with a ONE-stage register prefetch: the loads of stage s+1 get the
+// MFMA block of stage s (~0.64 us) to cover ~1-2 us of loaded L2/HBM latency, and every stage stalls.  A deeper
+// register ring does not fit.  Here nothing is staged through registers:
+//   * block = 512 threads (8 waves, 2 per SIMD), tile = 16 rows x 32 px x 128 channels (twice conv_tiled's pixels per
+//     weight stage -> half the weight traffic per FLOP);
+//   * weights: ring of THREE LDS slots (one (chunk, tap-row) stage each, 24 KB), filled two stages ahead;
+//   * input patch (18 x 34 px x 32 ch, 39 KB): TWO LDS buffers, the next chunk's patch issued a whole chunk ahead;
+//   * LDS images are dense 64-byte rows (LDS-DMA writes lane-linear); fragment reads stay conflict-free through an
+//     XOR swizzle of the 16-byte chunk index, applied on the SOURCE address of each lane's load;
+//   * out-of-image patch pixels read a 64-byte zero page;
+//   * raw s_barrier + counted `s_waitcnt vmcnt(N)` (a __syncthreads() would drain the DMA queue every stage).
+// The input must need no transformation on the way in (no style multiply / pre-activation): D convs, BigGAN 3x3 convs,
+// and modulated layers whose weights were pre-modulated per sample.  Epilogue = conv_tiled's fast path.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+constexpr int TH = 16, NT = 128, NTHR = 512;
+constexpr int PH = TH + 2, PW = 34;
+constexpr int NVA = PH * PW * 4;                         // 2448 16-byte vectors in a patch
+constexpr int NA = (NVA + NTHR - 1) / NTHR;              // 5 DMA loads per thread per chunk
+constexpr int A_BYTES = NA * NTHR * 16;                  // 40960
+constexpr int NB = 3 * NT * 4 / NTHR;                    // 3 DMA loads per thread per stage
+constexpr int B_BYTES = 3 * NT * 64;                     // 24576
+constexpr int OFF_B = 2 * A_BYTES;
+constexpr int OFF_C = OFF_B + 3 * B_BYTES;               // 155648: epilogue constants [3][NT] floats
+constexpr int LDS_BYTES = OFF_C + 3 * NT * 4;            // 157184 (one workgroup per CU)
+constexpr int OROW = NT * 2 + 16;
+
+__device__ __attribute__((aligned(64))) half_t g_zero_page[32];   // zero-initialised: source of the zero padding
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+__device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base) {
+    // LDS destination = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+#define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+__device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8}: the queue depths this pipeline produces
+    if (n >= 8) WAIT_VM(8);
+    else if (n >= 5) WAIT_VM(5);
+    else if (n >= 3) WAIT_VM(3);
+    else WAIT_VM(0);
+}
+}  // namespace
+
+__global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 31, kh = lane >> 5;
+    const int tpi = tiles_x * tiles_y;
+    // work item -> (pixel tile, n tile): the n tiles of one pixel tile sit on one XCD (id % 8) and share its L2
+    const int id = blockIdx.x;
+    const int lo = id & 7, rest = id >> 3;
+    const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
+    if (pt >= PT) return;
+    const int b = pt / tpi, trem = pt - b * tpi;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
+    const int n0 = nt * NT;
+
+    // ---- per-thread DMA sources -----------------------------------------------------------------------------
+    // vector v = k * 512 + t of an LDS image sits at byte v * 16: row = v >> 2, physical chunk = v & 3 and holds the
+    // row's LOGICAL 8-channel chunk (v & 3) ^ ((row >> 2) & 3)
+    const half_t* xb = p.x + (long long)b * p.x_bstride;
+    long long a_src[NA];      // element offset into the image, or -1 = zero page
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int v = k * NTHR + t, pix = v >> 2;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        const int iy = ty0 - 1 + pr, ix = tx0 - 1 + pc;
+        const int lc = (v & 3) ^ ((pix >> 2) & 3);
+        const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        a_src[k] = ok ? ((long long)iy * p.W + ix) * p.Cin + lc * 8 : -1;
+    }
+    const half_t* wb = p.w + (long long)b * p.w_bstride;
+    long long b_src[NB];      // element offset of (tap-in-row tx, n, chunk) within one tap row, without ty / c0
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int v = k * NTHR + t, row = v >> 2;          // row = tx * 128 + n
+        const int tx = row >> 7, n = row & 127;
+        const int lc = (v & 3) ^ ((row >> 2) & 3);
+        b_src[k] = ((long long)tx * p.Neff + n0 + n) * p.Cin + lc * 8;
+    }
+    auto issue_a = [&](int c, int buf) {
+        char* dst = smem + buf * A_BYTES + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            dma16(a_src[k] >= 0 ? xb + a_src[k] + c * 32 : g_zero_page + (t & 3) * 8, dst + k * (NTHR * 16));
+    };
+    auto issue_b = [&](int c, int ty, int slot) {
+        char* dst = smem + OFF_B + slot * B_BYTES + wave * 1024;
+        const half_t* src = wb + (long long)ty * 3 * p.Neff * p.Cin + c * 32;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) dma16(src + b_src[k], dst + k * (NTHR * 16));
+    };
+
+    f16x acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int n_chunks = p.Cin >> 5;
+    const int n_stages = n_chunks * 3;
+    // prologue: patch of chunk 0, weights of stages 0 and 1
+    issue_a(0, 0);
+    issue_b(0, 0, 0);
+    if (n_stages > 1) issue_b(0, 1, 1);
+
+    int c = 0, ty = 0;
+    for (int s = 0; s < n_stages; ++s) {
+        // DMA loads issued after those this stage needs (B(s), and A(c) which is older): B(s+1) [3], and the next chunk's
+        // patch [5] when it was issued after B(s), i.e. during the two preceding stages
+        int younger = (s + 1 < n_stages) ? NB : 0;
+        if (ty != 0 && c + 1 < n_chunks) younger += NA;
+        wait_vm(younger);
+        __builtin_amdgcn_s_barrier();      // data of this stage visible to every wave; slot (s+2)%3 and patch buffer
+                                           // (c+1)&1 are no longer being read by anyone
+        if (s + 2 < n_stages) {
+            int c2 = c, t2 = ty + 2;
+            if (t2 >= 3) { t2 -= 3; c2 = c + 1; }
+            issue_b(c2, t2, (s + 2) % 3);
+        }
+        if (ty == 0 && c + 1 < n_chunks) issue_a(c + 1, (c + 1) & 1);
+
+        const char* As = smem + (c & 1) * A_BYTES;
+        const char* Bs = smem + OFF_B + (s % 3) * B_BYTES;
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int lc = kk * 2 + kh;
+                h8 wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int row = tx * NT + j * 32 + lr;
+                    wf[j] = *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int pix = (wave * 2 + i + ty) * PW + lr + tx;
+                    const h8 xf = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                }
+            }
+        }
+        if (++ty == 3) { ty = 0; ++c; }
+    }
+
+    // ---- epilogue (conv_tiled's fast path): constants via LDS, batched noise / residual loads, row-order stores -----
+    float* Cc = (float*)(smem + OFF_C);
+    char* Os = smem + wave * (2 * 32 * OROW);
+    const int oy0 = ty0 + wave * 2, ox = tx0 + lr;
+    float c_d = 1.f, c_b = 0.f, c_s = 0.f;
+    if (t < NT) {
+        const int o = n0 + t;
+        if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
+        if (p.bias) c_b = p.bias[o];
+        if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
+    }
+    float nzr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        nzr[i] = 0.f;
+        if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy0 + i) * p.Wo + ox];
+    }
+    if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }
+    __syncthreads();                       // every wave is done with the patch / weight images (Os overlays them)
+    const int rcs = p.res_cs ? p.res_cs : p.Cout;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h4 rq[4][2];
+        if (p.res) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int oy = oy0 + i;
+                const half_t* rp = p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs
+                                                     : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + n0 + j * 32 + 4 * kh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rq[g][i] = *(const h4*)(rp + 8 * g);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nl = j * 32 + 8 * g + 4 * kh;
+            const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = acc[i][j][g * 4 + q] * d[q];
+                    v[q] += nzr[i];
+                    v[q] += bb[q];
+                    v[q] += sh4[q];
+                }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (p.res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += (float)rq[g][i][q];
+                }
+                h4 out;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                *(h4*)(Os + (i * 32 + lr) * OROW + nl * 2) = out;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + tx0) * p.Cout + n0;
+#pragma unroll
+        for (int k = 0; k < NT / 16; ++k) {
+            const int v = lane + 64 * k;
+            const int pix = v >> 4, chv = v & 15;
+            *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
+        }
+    }
+}
+
+const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
+    static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
+    if ((!on && !force) || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
+    if (p.sn || p.pre_shift || p.in_up || (p.x_bstride == 0 && p.B > 1)) return nullptr;
+    if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Wc % 32 != 0 || p.Hc % TH != 0) return nullptr;
+    if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr = true;
+    }
+    const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
+    const int PT = p.B * tiles_x * tiles_y;
+    const int NTn = p.Neff / NT;
+    const int PT8 = (PT + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv_glds_kernel, dim3(PT8 * NTn), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+    return "conv_glds_kernel";
+}

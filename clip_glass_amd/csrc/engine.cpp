@@ -734,6 +734,7 @@ void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flop
     Prof pr(e, tag, flops, bytes);
     const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
     if (!k) k = launch_conv_stream(p, e->cur);
+    if (!k) k = launch_conv_glds(p, e->cur);
     if (!k) k = launch_conv_tiled(p, e->cur);
     if (!k) k = launch_conv_direct(p, e->cur);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;

@@ -111,6 +111,8 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         if (!launch_conv_tiled(p, 0)) { glass_set_error("tiled conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 4) {
         if (!launch_conv_stream(p, 0)) { glass_set_error("streaming conv: unsupported shape"); return GLASS_ERR_ARG; }
+    } else if (d->impl == 5) {
+        if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
     int rc = finish();
     if (rc) return rc;

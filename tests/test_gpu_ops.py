@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from clip_glass_amd import synth
 from oracle import stylegan2_ref as sg
-from util import check, nchw, nhwc, style_tables
+from util import check, diag, nchw, nhwc, style_tables
 
 pytestmark = pytest.mark.gpu
 ops = None
@@ -98,6 +98,27 @@ def test_conv_stream_matches_tiled_and_direct():
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max())), float(np.abs(got - ref_t).max())
     assert (got != ref_t).mean() < 1e-2
     check("conv_stream vs direct", got, ref_d, 4e-3)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 64, 128, 128), (3, 16, 32, 256, 256), (1, 64, 64, 160, 128)])
+def test_conv_glds_matches_tiled(B, H, W, Cin, Cout):
+    """conv_glds.hip (LDS-DMA staged, swizzled dense LDS images, 3-slot weight ring): same arithmetic as the tiled kernel
+    (same MFMA order per accumulator), image borders through the zero page, full epilogue."""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, Cout)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32) * 0.2
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float16).astype(np.float32)
+    kw = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, res=res, out_scale=0.7)
+    got = ops.conv(x, w, impl=5, **kw)
+    ref_t = ops.conv(x, w, impl=2, **kw)
+    ref_d = ops.conv(x, w, impl=1, **kw)
+    diag("[glds] B%d %dx%d %d->%d max|glds-tiled| %.3e  max|glds-direct| %.3e" % (B, H, W, Cin, Cout, np.abs(got - ref_t).max(),
+                                                                                 np.abs(got - ref_d).max()))
+    assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
+    check("conv_glds vs direct", got, ref_d, 4e-3)
 
 
 @pytest.mark.parametrize("impl", [1, 2])
