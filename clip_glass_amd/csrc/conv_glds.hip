@@ -12,8 +12,9 @@
 //     XOR swizzle of the 16-byte chunk index, applied on the SOURCE address of each lane's load;
 //   * out-of-image patch pixels read a 64-byte zero page;
 //   * raw s_barrier + counted `s_waitcnt vmcnt(N)` (a __syncthreads() would drain the DMA queue every stage).
-// The input must need no transformation on the way in (no style multiply / pre-activation): D convs, BigGAN 3x3 convs,
-// and modulated layers whose weights were pre-modulated per sample.  Epilogue = conv_tiled's fast path.
+//   * activation-side style modulation is applied to the weight fragments (same product W*s*x; rounding of W*s instead
+//     of x*s), so modulated G layers qualify too; inputs needing a pre-activation (BigGAN bn+relu staging) do not.
+// Epilogue = conv_tiled's fast path.
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
@@ -28,7 +29,8 @@ constexpr int NB = 3 * NT * 4 / NTHR;                    // 3 DMA loads per thre
 constexpr int B_BYTES = 3 * NT * 64;                     // 24576
 constexpr int OFF_B = 2 * A_BYTES;
 constexpr int OFF_C = OFF_B + 3 * B_BYTES;               // 155648: epilogue constants [3][NT] floats
-constexpr int LDS_BYTES = OFF_C + 3 * NT * 4;            // 157184 (one workgroup per CU)
+constexpr int OFF_S = OFF_C + 3 * NT * 4;                // 157184: this sample's style row, Cin <= 1024 halfs
+constexpr int LDS_BYTES = OFF_S + 2048;                  // 159232 (one workgroup per CU)
 constexpr int OROW = NT * 2 + 16;
 
 __device__ __attribute__((aligned(64))) half_t g_zero_page[32];   // zero-initialised: source of the zero padding
@@ -110,6 +112,13 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 
     const int n_chunks = p.Cin >> 5;
     const int n_stages = n_chunks * 3;
+    // Activation-side modulation (x * s[b,i]) is applied to the WEIGHT fragments instead — same product, and the patch
+    // needs no transformation on its way into LDS.  The sample's style row is parked in LDS before the first DMA.
+    const half_t* Ss = (const half_t*)(smem + OFF_S);
+    if (p.sn16) {
+        if (t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = *(const h8*)(p.sn16 + (long long)b * p.sn_stride + t * 8);
+        __syncthreads();
+    }
     // prologue: patch of chunk 0, weights of stages 0 and 1
     issue_a(0, 0);
     issue_b(0, 0, 0);
@@ -143,6 +152,11 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
                 for (int j = 0; j < 4; ++j) {
                     const int row = tx * NT + j * 32 + lr;
                     wf[j] = *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                }
+                if (p.sn16) {
+                    const h8 sv = *(const h8*)(Ss + c * 32 + lc * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wf[j] = wf[j] * sv;   // 16 x v_pk_mul_f16 per 8 MFMAs
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
     static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
     if ((!on && !force) || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
-    if (p.sn || p.pre_shift || p.in_up || (p.x_bstride == 0 && p.B > 1)) return nullptr;
+    if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Wc % 32 != 0 || p.Hc % TH != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     static bool attr = false;

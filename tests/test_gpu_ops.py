@@ -119,6 +119,11 @@ def test_conv_glds_matches_tiled(B, H, W, Cin, Cout):
                                                                                  np.abs(got - ref_d).max()))
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     check("conv_glds vs direct", got, ref_d, 4e-3)
+    # style-modulated input: the LDS-DMA kernel multiplies the weight fragments by s (W*s rounded instead of x*s)
+    sn = rng.uniform(-1.0, 1.0, (B, Cin)).astype(np.float32)
+    got_s = ops.conv(x, w, impl=5, sn=sn, **kw)
+    ref_s = ops.conv(x, w, impl=1, sn=sn, **kw)
+    check("conv_glds (style on weights) vs direct", got_s, ref_s, 4e-3)
 
 
 @pytest.mark.parametrize("impl", [1, 2])
