@@ -56,6 +56,11 @@ struct ConvParams {
     int res_cs;             // channel stride of the residual rows (0 = Cout): first Cout of res_cs channels are used
     int res_up;             // 1: the residual is read through a nearest x2 upsample (it holds Ho/2 x Wo/2)
     float out_scale;
+    // conv_stream only: build the 32-channel input map on the fly from the skip image (D fromRGB fused into the first D conv)
+    const float* rgb_y;     // [B][3][H][W] fp32 (nullable: normal input x)
+    const float* rgb_w;     // [32][3]
+    const float* rgb_b;     // [32]
+    half_t* rgb_x_out;      // [B][H][W][32]: the fromRGB map, written as a side output (skip path input)
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout

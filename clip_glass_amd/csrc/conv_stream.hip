@@ -29,6 +29,10 @@ constexpr int C_BYTES = 32 * 4 + 32 * 4 + 32 * 2;          // per-sample demod s
 constexpr int LDS_BYTES = W_BYTES + A_BYTES + O_BYTES + C_BYTES;   // 60800 -> 2 workgroups per CU
 }  // namespace
 
+// FRGB: the input map is produced on the fly from the skip image y (D's fromRGB, stylegan2/models.py:1125-1143: biggan
+// denorm(norm(y)) -> 1x1 conv 3 -> 32 + bias + lrelu*sqrt2), 12 bytes per pixel read instead of 64; the tile's interior
+// of that map is also written out (p.rgb_x_out) for the D block's skip path, so the separate fromRGB pass disappears.
+template <bool FRGB>
 __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int tiles_x, int tiles_y, int PT, int per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ws = smem;
@@ -53,7 +57,18 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         const int pix = v >> 2;
         const int pr = pix / PW, pc = pix - pr * PW;
         prc[k] = v < NVA ? (pr << 8 | pc) : -1;
-        rel[k] = (pr * p.W + pc) * 32 + part * 8;
+        rel[k] = FRGB ? pr * p.W + pc : (pr * p.W + pc) * 32 + part * 8;
+    }
+    // FRGB: this thread's 8 output channels of the 1x1 fromRGB conv (part is fixed per thread)
+    float fw[FRGB ? 8 : 1][3], fb[FRGB ? 8 : 1];
+    if (FRGB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fw[j][0] = p.rgb_w[(part * 8 + j) * 3];
+            fw[j][1] = p.rgb_w[(part * 8 + j) * 3 + 1];
+            fw[j][2] = p.rgb_w[(part * 8 + j) * 3 + 2];
+            fb[j] = p.rgb_b[part * 8 + j];
+        }
     }
 
     const int first = blockIdx.x * per_block;
@@ -66,26 +81,39 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         const int iy = ty0 - 1 + (prc[k] >> 8), ix = tx0 - 1 + (prc[k] & 255);
         return id < last && prc[k] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     };
-    auto load = [&](int id, h8* ra, float* nzr) {   // issue the patch (+ noise) loads of tile `id`
+    struct RSet { h8 a[FRGB ? 1 : NA]; float y3[FRGB ? NA : 1][3]; float nz[2]; };   // one tile's loads in flight
+    auto load = [&](int id, RSet& R) {   // issue the patch (+ noise) loads of tile `id`
         const int idc = id < last ? id : first;
         const int b = idc / tpi, trem = idc - b * tpi;
         const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
-        const half_t* img = p.x + (long long)b * p.x_bstride;
-        const long long org = ((long long)(ty0 - 1) * p.W + (tx0 - 1)) * 32;
+        if (FRGB) {
+            const long long hw = (long long)p.H * p.W;
+            const float* yb = p.rgb_y + (long long)b * 3 * hw;
+            const long long org = (long long)(ty0 - 1) * p.W + (tx0 - 1);
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const long long off = tile_ok(id, k, ty0, tx0) ? org + rel[k] : 0;
-            ra[k] = *(const h8*)(img + off);
+            for (int k = 0; k < NA; ++k) {
+                const long long off = tile_ok(id, k, ty0, tx0) ? org + rel[k] : 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) R.y3[k][c] = yb[c * hw + off];
+            }
+        } else {
+            const half_t* img = p.x + (long long)b * p.x_bstride;
+            const long long org = ((long long)(ty0 - 1) * p.W + (tx0 - 1)) * 32;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                const long long off = tile_ok(id, k, ty0, tx0) ? org + rel[k] : 0;
+                R.a[k] = *(const h8*)(img + off);
+            }
         }
         if (p.noise) {
             const float* nzp = p.noise + ((long long)(b / p.batch_size) * p.Ho + ty0 + wave * 2) * p.Wo + tx0 + lr;
-            nzr[0] = nzp[0];
-            nzr[1] = nzp[p.Wo];
+            R.nz[0] = nzp[0];
+            R.nz[1] = nzp[p.Wo];
         }
     };
 
     int wb = -1;   // sample whose weights are resident in Ws
-    auto step = [&](int id, h8* ra, float* nzr) {   // returns after tile `id` is computed and stored; refills ra with tile id + 3
+    auto step = [&](int id, RSet& R) {   // returns after tile `id` is computed and stored; refills ra with tile id + 3
         const int b = id / tpi, trem = id - b * tpi;
         const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
         __syncthreads();                           // every wave is done reading As / Ws of the previous tile
@@ -109,15 +137,30 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
             for (int k = 0; k < NA; ++k) {
                 const int v = t + 256 * k;
                 if (NVA % 256 == 0 || v < NVA) {
-                    h8 a = tile_ok(id, k, ty0, tx0) ? ra[k] : zero;
-                    if (p.sn16) a = a * sh;
+                    const bool ok = tile_ok(id, k, ty0, tx0);
+                    h8 a;
+                    if (FRGB) {
+                        float c3[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) c3[c] = fminf(fmaxf((R.y3[k][c] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            a[j] = (half_t)lrelu_sqrt2(fw[j][0] * c3[0] + fw[j][1] * c3[1] + fw[j][2] * c3[2] + fb[j]);
+                        const int pr = prc[k] >> 8, pc = prc[k] & 255;
+                        if (ok && pr >= 1 && pr <= TH && pc >= 1 && pc <= 32)      // tile interior: the map itself, for the skip path
+                            *(h8*)(p.rgb_x_out + (((long long)b * p.H + ty0 - 1 + pr) * p.W + tx0 - 1 + pc) * 32 + part * 8) = a;
+                        if (!ok) a = zero;
+                    } else {
+                        a = ok ? R.a[k] : zero;
+                        if (p.sn16) a = a * sh;
+                    }
                     *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
                 }
             }
         }
         __syncthreads();
-        const float nz0 = p.noise ? p.noise_strength * nzr[0] : 0.f, nz1 = p.noise ? p.noise_strength * nzr[1] : 0.f;
-        load(id + 3, ra, nzr);                     // three tiles stay in flight
+        const float nz0 = p.noise ? p.noise_strength * R.nz[0] : 0.f, nz1 = p.noise ? p.noise_strength * R.nz[1] : 0.f;
+        load(id + 3, R);                           // three tiles stay in flight
 
         f16x acc[2];
 #pragma unroll
@@ -175,31 +218,33 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         }
     };
 
-    h8 r0[NA], r1[NA], r2[NA];
-    float z0[2], z1[2], z2[2];
-    load(first, r0, z0);
-    load(first + 1, r1, z1);
-    load(first + 2, r2, z2);
+    RSet r0, r1, r2;
+    load(first, r0);
+    load(first + 1, r1);
+    load(first + 2, r2);
     for (int id = first; id < last; id += 3) {
-        step(id, r0, z0);
+        step(id, r0);
         if (id + 1 >= last) break;
-        step(id + 1, r1, z1);
+        step(id + 1, r1);
         if (id + 2 >= last) break;
-        step(id + 2, r2, z2);
+        step(id + 2, r2);
     }
 }
 
 const char* launch_conv_stream(const ConvParams& p, hipStream_t st) {
     static const bool off = getenv("GLASS_NO_STREAM") != nullptr;   // experiment knob
     if (off || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return nullptr;
+    const bool frgb = p.rgb_y != nullptr;
+    if (frgb && (!p.rgb_w || !p.rgb_b || !p.rgb_x_out || p.sn)) return nullptr;
     if (p.Cin != 32 || p.Neff != 32 || p.Cout != 32 || p.res || p.shift || p.pre_shift || p.in_up || p.res_cs || p.res_up) return nullptr;
-    if (p.Wc % 32 != 0 || p.Hc % TH != 0 || p.W >= 256 * 32 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
+    if (p.Wc % 32 != 0 || p.Hc % TH != 0 || p.W >= 256 * 32 || (!frgb && p.x_bstride == 0 && p.B > 1)) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
     static int slots = 0;
     if (!slots) {
-        (void)hipFuncSetAttribute((const void*)conv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         hipDeviceProp_t prop;
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -209,6 +254,10 @@ const char* launch_conv_stream(const ConvParams& p, hipStream_t st) {
     if (PT < slots * 8) return nullptr;        // streaming only pays with many tiles per workgroup
     const int per_block = (PT + slots - 1) / slots;
     const int grid = (PT + per_block - 1) / per_block;
-    hipLaunchKernelGGL(conv_stream_kernel, dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);
+    if (frgb) {
+        hipLaunchKernelGGL(conv_stream_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);
+        return "conv_stream_kernel<fromrgb>";
+    }
+    hipLaunchKernelGGL(conv_stream_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);
     return "conv_stream_kernel";
 }

@@ -904,8 +904,14 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
 
 // Discriminator conv blocks [i_lo, i_hi) (D order: block i works at resolution R >> i).
 // bufs: six scratch feature maps; X enters in `X`; the result pointer is returned.
-static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* X, half_t* const bufs[5]) {
-    char tag[48];
+static void run_fromrgb(glass_engine* e, int B, const float* y, half_t* X);
+
+// rgb_y != nullptr (only with i_lo == 0): X has NOT been produced yet — the first conv builds the fromRGB map from the
+// skip image on the fly and writes it to X as a side output (conv_stream<fromrgb>), or, where that kernel does not
+// apply, the separate fromRGB pass runs first.
+static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* X, half_t* const bufs[5],
+                            const float* rgb_y = nullptr) {
+    char tag[64];
     half_t *Hb = bufs[0], *HB = bufs[1], *XS = bufs[2], *S = bufs[3], *O = bufs[4];
     for (int i = i_lo; i < i_hi; ++i) {
         const DBlock& d = e->dblk[i];
@@ -914,8 +920,26 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         p.x = X; p.x_bstride = (long long)r * r * d.cin; p.B = B; p.H = p.W = r; p.Cin = d.cin;
         p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
         p.bias = d.b0; p.act = 1; p.y = Hb;
+        bool fused_rgb = false;
+        if (i == 0 && rgb_y) {
+            static const bool no_fuse = getenv("GLASS_NO_FRGB_FUSE") != nullptr;   // A/B knob
+            ConvParams q = p;
+            q.rgb_y = rgb_y; q.rgb_w = e->d_frgb_w; q.rgb_b = e->d_frgb_b; q.rgb_x_out = X;
+            snprintf(tag, sizeof tag, "D.fromrgb+conv0.r%d.%dx%d", r, d.cin, d.cin);
+            const double px = (double)B * r * r;
+            Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin), px * (12.0 + 4.0 * d.cin));
+            const char* k = no_fuse ? nullptr : launch_conv_stream(q, e->cur);
+            if (k) {
+                fused_rgb = true;
+                if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                if (e->profiling) e->tag_kernel[tag] = k;
+            } else {
+                pr.on = false;
+            }
+        }
+        if (i == 0 && rgb_y && !fused_rgb) run_fromrgb(e, B, rgb_y, X);
         snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
-        run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
+        if (!fused_rgb) run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
         {
             snprintf(tag, sizeof tag, "D.blur.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
@@ -1137,9 +1161,8 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
             }
             if (want_d) {
                 if (d_hi > 0) {
-                    run_fromrgb(e, B, y, e->act[0]);
                     half_t* const bufs[5] = {e->act[1], e->act[2], e->act[3], e->act[4], e->act[5]};
-                    half_t* Xo = run_d_blocks(e, B, 0, d_hi, e->act[0], bufs);
+                    half_t* Xo = run_d_blocks(e, B, 0, d_hi, e->act[0], bufs, y);   // fromRGB rides in the first conv
                     GLASS_HIP(hipMemcpyAsync(dmid + (size_t)c0 * dmid_bs, Xo, (size_t)B * dmid_bs * sizeof(half_t),
                                              hipMemcpyDeviceToDevice, e->cur));
                 } else {
