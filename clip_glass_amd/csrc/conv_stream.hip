@@ -60,14 +60,15 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         rel[k] = FRGB ? pr * p.W + pc : (pr * p.W + pc) * 32 + part * 8;
     }
     // FRGB: this thread's 8 output channels of the 1x1 fromRGB conv (part is fixed per thread)
-    float fw[FRGB ? 8 : 1][3], fb[FRGB ? 8 : 1];
+    // packed fp16, sqrt(2) folded in: lrelu(z) * sqrt2 = max(z', 0.2 z') with z' = z * sqrt2
+    h8 fw0, fw1, fw2, fbv;
     if (FRGB) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            fw[j][0] = p.rgb_w[(part * 8 + j) * 3];
-            fw[j][1] = p.rgb_w[(part * 8 + j) * 3 + 1];
-            fw[j][2] = p.rgb_w[(part * 8 + j) * 3 + 2];
-            fb[j] = p.rgb_b[part * 8 + j];
+            fw0[j] = (half_t)(p.rgb_w[(part * 8 + j) * 3] * GLASS_SQRT2);
+            fw1[j] = (half_t)(p.rgb_w[(part * 8 + j) * 3 + 1] * GLASS_SQRT2);
+            fw2[j] = (half_t)(p.rgb_w[(part * 8 + j) * 3 + 2] * GLASS_SQRT2);
+            fbv[j] = (half_t)(p.rgb_b[part * 8 + j] * GLASS_SQRT2);
         }
     }
 
@@ -143,9 +144,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
                         float c3[3];
 #pragma unroll
                         for (int c = 0; c < 3; ++c) c3[c] = fminf(fmaxf((R.y3[k][c] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            a[j] = (half_t)lrelu_sqrt2(fw[j][0] * c3[0] + fw[j][1] * c3[1] + fw[j][2] * c3[2] + fb[j]);
+                        const half_t h0 = (half_t)c3[0], h1 = (half_t)c3[1], h2 = (half_t)c3[2];
+                        const h8 z = fw0 * h0 + fw1 * h1 + fw2 * h2 + fbv;          // v_pk_fma_f16
+                        a = __builtin_elementwise_max(z, z * (half_t)0.2f);
                         const int pr = prc[k] >> 8, pc = prc[k] & 255;
                         if (ok && pr >= 1 && pr <= TH && pc >= 1 && pc <= 32)      // tile interior: the map itself, for the skip path
                             *(h8*)(p.rgb_x_out + (((long long)b * p.H + ty0 - 1 + pr) * p.W + tx0 - 1 + pc) * 32 + part * 8) = a;
