@@ -67,7 +67,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    json_fd = None
     if world > 1 or os.environ.get("GLASS_BENCH_FORCE_DIST"):   # torchrun path (RCCL); forced at world 1 for testing
+        # RCCL prints a version banner on the C-level stdout at init; keep stdout to the ONE JSON line: fd 1 -> stderr for
+        # everything else, the JSON goes to the saved descriptor
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -245,7 +251,10 @@ def main():
                         b2[k2] += a2[k2]
                 json.dump(dict(per_tag=full_prof, per_kernel=wk, seconds=dt / args.steps, note="per_tag/per_kernel: ONE fully "
                                "instrumented warm-up pass; timed region instruments only the dominant kernel"), f, indent=1)
-        print(json.dumps(out))
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
