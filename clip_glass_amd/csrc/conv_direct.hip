@@ -51,43 +51,50 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 #pragma unroll
     for (int nw = 0; nw < NW; ++nw) nvalid[nw] = n0 + nw * 32 + r < p.Neff;
 
-    struct Frag { h8 a; h8 bf[NW]; f4 s0, s1; };
+    // Every load of a K step is UNCONDITIONAL (out-of-image pixels / out-of-range weight rows read a valid clamped
+    // address): a load under a branch makes the compiler wait for it at the join, which drained the software pipeline
+    // every step.  Padding is applied when the fragment is consumed (`ok`); out-of-range columns are never stored.
+    struct Frag { h8 a; h8 bf[NW]; f4 s0, s1, t0, t1; bool ok; };
+    int nrow[NW];
+#pragma unroll
+    for (int nw = 0; nw < NW; ++nw) nrow[nw] = min(n0 + nw * 32 + r, p.Neff - 1);
     auto load = [&](int s, Frag& f) {
         const int tap = s / cps, i0 = (s - tap * cps) << 4;
         const int ty = tap / p.KS, tx = tap - ty * p.KS;
         const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
-        const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f.a[j] = (half_t)0.f;
-        if (v) f.a = *(const h8*)(xb + ((long long)(iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + i0);
+        f.ok = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const long long poff = f.ok ? ((long long)(iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin : 0;
+        f.a = *(const h8*)(xb + poff + i0);
         if (snb) {
             f.s0 = *(const f4*)(snb + i0);
             f.s1 = *(const f4*)(snb + i0 + 4);
         }
-        if (psb) {   // pre-activation: relu(x * s + shift) for in-bounds pixels (applied here, where validity is known)
-            const f4 t0 = *(const f4*)(psb + i0), t1 = *(const f4*)(psb + i0 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                f.a[j] = (half_t)(v ? fmaxf((float)f.a[j] * f.s0[j] + t0[j], 0.f) : 0.f);
-                f.a[j + 4] = (half_t)(v ? fmaxf((float)f.a[j + 4] * f.s1[j] + t1[j], 0.f) : 0.f);
-            }
+        if (psb) {
+            f.t0 = *(const f4*)(psb + i0);
+            f.t1 = *(const f4*)(psb + i0 + 4);
         }
-        const half_t* wp = p.w + ((long long)tap * p.Neff + n0 + r) * p.Cin + kh * 8 + i0;
+        const half_t* wp = p.w + (long long)tap * p.Neff * p.Cin + kh * 8 + i0;
 #pragma unroll
-        for (int nw = 0; nw < NW; ++nw) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f.bf[nw][j] = (half_t)0.f;
-            if (nvalid[nw]) f.bf[nw] = *(const h8*)(wp + (long long)nw * 32 * p.Cin);
-        }
+        for (int nw = 0; nw < NW; ++nw) f.bf[nw] = *(const h8*)(wp + (long long)nrow[nw] * p.Cin);
     };
     auto compute = [&](Frag& f) {
         h8 a = f.a;
-        if (snb && !psb) {
+        if (psb) {   // pre-activation: relu(x * s + shift) for in-bounds pixels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = (half_t)fmaxf((float)a[j] * f.s0[j] + f.t0[j], 0.f);
+                a[j + 4] = (half_t)fmaxf((float)a[j + 4] * f.s1[j] + f.t1[j], 0.f);
+            }
+        } else if (snb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 a[j] = (half_t)((float)a[j] * f.s0[j]);
                 a[j + 4] = (half_t)((float)a[j + 4] * f.s1[j]);
             }
+        }
+        if (!f.ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (half_t)0.f;
         }
 #pragma unroll
         for (int nw = 0; nw < NW; ++nw) acc[nw] = mfma32(a, f.bf[nw], acc[nw]);
