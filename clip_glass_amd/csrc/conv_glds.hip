@@ -20,17 +20,24 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int TH = 16, NT = 128, NTHR = 512;
-constexpr int PH = TH + 2, PW = 34;
-constexpr int NVA = PH * PW * 4;                         // 2448 16-byte vectors in a patch
-constexpr int NA = (NVA + NTHR - 1) / NTHR;              // 5 DMA loads per thread per chunk
-constexpr int A_BYTES = NA * NTHR * 16;                  // 40960
+constexpr int NT = 128, NTHR = 512;
+// Geometry<TW>: TW = 32 -> tile 16 rows x 32 px (two 32-lane rows per wave); TW = 16 -> tile 16 rows x 16 px (one 32-lane
+// row = two image rows per wave) for the 16 x 16 layers, one whole image per workgroup.
+template <int TW>
+struct Geo {
+    static constexpr int RW = TW == 32 ? 2 : 1;                 // 32-lane rows per wave
+    static constexpr int TH = 8 * RW * (32 / TW);                // image rows per tile (16)
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int NVA = PH * PW * 4;                      // 16-byte vectors in a patch
+    static constexpr int NA = (NVA + NTHR - 1) / NTHR;           // DMA loads per thread per chunk (5 / 3)
+    static constexpr int A_BYTES = NA * NTHR * 16;
+    static constexpr int OFF_B = 2 * A_BYTES;
+    static constexpr int OFF_C = OFF_B + 3 * (3 * NT * 64);      // epilogue constants [3][NT] floats
+    static constexpr int OFF_S = OFF_C + 3 * NT * 4;             // this sample's style row, Cin <= 1024 halfs
+    static constexpr int LDS_BYTES = OFF_S + 2048;
+};
 constexpr int NB = 3 * NT * 4 / NTHR;                    // 3 DMA loads per thread per stage
 constexpr int B_BYTES = 3 * NT * 64;                     // 24576
-constexpr int OFF_B = 2 * A_BYTES;
-constexpr int OFF_C = OFF_B + 3 * B_BYTES;               // 155648: epilogue constants [3][NT] floats
-constexpr int OFF_S = OFF_C + 3 * NT * 4;                // 157184: this sample's style row, Cin <= 1024 halfs
-constexpr int LDS_BYTES = OFF_S + 2048;                  // 159232 (one workgroup per CU)
 constexpr int OROW = NT * 2 + 16;
 
 __device__ __attribute__((aligned(64))) half_t g_zero_page[32];   // zero-initialised: source of the zero padding
@@ -52,7 +59,11 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8}: the que
 }
 }  // namespace
 
+template <int TW>
 __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
+    using G = Geo<TW>;
+    constexpr int RW = G::RW, TH = G::TH, PW = G::PW, NVA = G::NVA, NA = G::NA, A_BYTES = G::A_BYTES, OFF_B = G::OFF_B,
+                  OFF_C = G::OFF_C, OFF_S = G::OFF_S;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, kh = lane >> 5;
@@ -63,8 +74,11 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
     const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
     if (pt >= PT) return;
     const int b = pt / tpi, trem = pt - b * tpi;
-    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
     const int n0 = nt * NT;
+    // this lane's pixel within a 32-lane row: TW = 32 -> (0, lr); TW = 16 -> (lr >> 4, lr & 15)
+    const int l_row = TW == 32 ? 0 : lr >> 4, l_col = TW == 32 ? lr : lr & 15;
+    constexpr int RPL = 32 / TW;              // image rows per 32-lane row
 
     // ---- per-thread DMA sources -----------------------------------------------------------------------------
     // vector v = k * 512 + t of an LDS image sits at byte v * 16: row = v >> 2, physical chunk = v & 3 and holds the
@@ -102,9 +116,9 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
         for (int k = 0; k < NB; ++k) dma16(src + b_src[k], dst + k * (NTHR * 16));
     };
 
-    f16x acc[2][4];
+    f16x acc[RW][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -159,8 +173,8 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
                     for (int j = 0; j < 4; ++j) wf[j] = wf[j] * sv;   // 16 x v_pk_mul_f16 per 8 MFMAs
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int pix = (wave * 2 + i + ty) * PW + lr + tx;
+                for (int i = 0; i < RW; ++i) {
+                    const int pix = ((wave * RW + i) * RPL + l_row + ty) * PW + l_col + tx;
                     const h8 xf = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
@@ -172,8 +186,8 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 
     // ---- epilogue (conv_tiled's fast path): constants via LDS, batched noise / residual loads, row-order stores -----
     float* Cc = (float*)(smem + OFF_C);
-    char* Os = smem + wave * (2 * 32 * OROW);
-    const int oy0 = ty0 + wave * 2, ox = tx0 + lr;
+    char* Os = smem + wave * (RW * 32 * OROW);
+    const int oyb = ty0 + wave * RW * RPL + l_row, ox = tx0 + l_col;     // lane's pixel of 32-lane row i: (oyb + i * RPL, ox)
     float c_d = 1.f, c_b = 0.f, c_s = 0.f;
     if (t < NT) {
         const int o = n0 + t;
@@ -181,22 +195,22 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
         if (p.bias) c_b = p.bias[o];
         if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
     }
-    float nzr[2];
+    float nzr[RW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RW; ++i) {
         nzr[i] = 0.f;
-        if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy0 + i) * p.Wo + ox];
+        if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i * RPL) * p.Wo + ox];
     }
     if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }
     __syncthreads();                       // every wave is done with the patch / weight images (Os overlays them)
     const int rcs = p.res_cs ? p.res_cs : p.Cout;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        h4 rq[4][2];
+        h4 rq[4][RW];
         if (p.res) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int oy = oy0 + i;
+            for (int i = 0; i < RW; ++i) {
+                const int oy = oyb + i * RPL;
                 const half_t* rp = p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs
                                                      : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + n0 + j * 32 + 4 * kh;
 #pragma unroll
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
             const int nl = j * 32 + 8 * g + 4 * kh;
             const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < RW; ++i) {
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -237,32 +251,41 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + tx0) * p.Cout + n0;
+    for (int i = 0; i < RW; ++i) {
 #pragma unroll
         for (int k = 0; k < NT / 16; ++k) {
             const int v = lane + 64 * k;
-            const int pix = v >> 4, chv = v & 15;
-            *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
+            const int pix = v >> 4, chv = v & 15;       // pixel `pix` of the 32-lane row, 8-channel piece chv
+            const int prow = TW == 32 ? 0 : pix >> 4, pcol = TW == 32 ? pix : pix & 15;
+            half_t* dst = p.y + (((long long)b * p.Ho + ty0 + (wave * RW + i) * RPL + prow) * p.Wo + tx0 + pcol) * p.Cout + n0;
+            *(h8*)(dst + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
         }
     }
+}
+
+template <int TW>
+static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const char* name) {
+    using G = Geo<TW>;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_glds_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        attr = true;
+    }
+    const int tiles_x = p.Wc / TW, tiles_y = p.Hc / G::TH;
+    const int PT = p.B * tiles_x * tiles_y;
+    const int NTn = p.Neff / NT;
+    const int PT8 = (PT + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv_glds_kernel<TW>, dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+    return name;
 }
 
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
     static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
     if ((!on && !force) || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
-    if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Wc % 32 != 0 || p.Hc % TH != 0) return nullptr;
+    if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr = true;
-    }
-    const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
-    const int PT = p.B * tiles_x * tiles_y;
-    const int NTn = p.Neff / NT;
-    const int PT8 = (PT + 7) / 8 * 8;
-    hipLaunchKernelGGL(conv_glds_kernel, dim3(PT8 * NTn), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
-    return "conv_glds_kernel";
+    if (p.Wc % 32 == 0) return launch_glds_inst<32>(p, st, "conv_glds_kernel");
+    if (p.Wc % 16 == 0) return launch_glds_inst<16>(p, st, "conv_glds_kernel<w16>");
+    return nullptr;
 }
