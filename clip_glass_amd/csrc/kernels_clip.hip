@@ -85,12 +85,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* qkv, int L
     const int img = blockIdx.x / heads, h = blockIdx.x % heads;
     const int D = heads * hd;
     const half_t* base = qkv + (long long)img * L * 3 * D + h * hd;
-    for (int e = threadIdx.x; e < L * hd; e += 256) {
-        const int t = e / hd, d = e - t * hd;
-        const half_t* rp = base + (long long)t * 3 * D + d;
-        q[t * (hd + 1) + d] = (float)rp[0] * 0.125f;  // q * hd^-0.5 (hd = 64)
-        k[t * (hd + 1) + d] = (float)rp[D];
-        v[t * (hd + 1) + d] = (float)rp[2 * D];
+    // 16-byte loads, several in flight per thread (2-byte loads with one in flight each made this phase the kernel):
+    // piece e -> (token t, which of q|k|v, 8-wide slice d8)
+    for (int e0 = threadIdx.x; e0 < L * 24; e0 += 256 * 4) {
+        h8 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + 256 * u, L * 24 - 1);
+            const int t = e / 24, rem = e - t * 24, which = rem >> 3, d8 = rem & 7;
+            r[u] = *(const h8*)(base + (long long)t * 3 * D + which * D + d8 * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            if (e < L * 24) {
+                const int t = e / 24, rem = e - t * 24, which = rem >> 3, d8 = rem & 7;
+                float* dst = (which == 0 ? q : which == 1 ? k : v) + t * (hd + 1) + d8 * 8;
+                const float sc = which == 0 ? 0.125f : 1.f;   // q * hd^-0.5 (hd = 64)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dst[j] = (float)r[u][j] * sc;
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < L * L; e += 256) {
