@@ -80,10 +80,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
         }
     }
-    // epilogue: lane = output row m, quads of 4 consecutive n
+    // epilogue: lane = output row m, quads of 4 consecutive n.  Bias quads and (mode 2) the residual quads of a row are
+    // fetched as one batch of unconditional loads: a load consumed right after it is issued costs a full round trip, and
+    // there were two of them per accumulator quad here.
+    f4 bq[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bq[j][g] = f4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bq[j][g] = *(const f4*)(p.bias + n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * kh);
+        }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + lr;
+        const int mc = min(m, p.M - 1);                       // clamped row for the unconditional residual loads
+        f4 rq[NJ][4];
+        if (p.mode == 2) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    rq[j][g] = *(const f4*)(p.out32 + (long long)mc * p.ldo + n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * kh);
+        }
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -92,12 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + 8 * g + 4 * kh;
                 float v[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q];
-                if (p.bias) {
-                    const f4 bb = *(const f4*)(p.bias + n);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] += bb[q];
-                }
+                for (int q = 0; q < 4; ++q) v[q] = acc[i][j][g * 4 + q] + bq[j][g][q];
                 const long long oi = (long long)m * p.ldo + n;
                 if (p.mode <= 1) {
                     h4 o;
@@ -108,9 +122,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
                 } else {
                     f4 o;
                     if (p.mode == 2) {
-                        o = *(const f4*)(p.out32 + oi);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] += v[q];
+                        for (int q = 0; q < 4; ++q) o[q] = rq[j][g][q] + v[q];
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) o[q] = p.mode == 4 ? lrelu_sqrt2(v[q]) : v[q];
