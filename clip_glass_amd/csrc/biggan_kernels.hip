@@ -121,7 +121,42 @@ void launch_bg_attn_split(const half_t* T, int B, int H, int W, int c8, int c2, 
                        phi, gT);
 }
 
-// ---- row softmax: S fp32 [rows][n] -> P fp16 [rows][n]; one wave per row -------------------------------
+// ---- row softmax: S fp32 [rows][n] -> P fp16 [rows][n]; one wave per row, the row held in registers (one pass over
+// memory, all loads issued up front) for n <= 64 * 32; longer rows take the three-pass loop ---------------------------
+template <int NV>   // NV float4 per lane: n == NV * 256
+__global__ __launch_bounds__(256) void bg_softmax_reg_kernel(const float* __restrict__ S, long long rows, half_t* __restrict__ Pm) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int n = NV * 256;
+    const float* s = S + row * n;
+    f4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = *(const f4*)(s + (k * 64 + lane) * 4);
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx = fmaxf(mx, v[k][q]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[k][q] = expf(v[k][q] - mx);
+            sum += v[k][q];
+        }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        h4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = (half_t)(v[k][q] * inv);
+        *(h4*)(Pm + row * n + (k * 64 + lane) * 4) = o;
+    }
+}
 __global__ __launch_bounds__(256) void bg_softmax_kernel(const float* __restrict__ S, long long rows, int n,
                                                          half_t* __restrict__ Pm) {
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -138,7 +173,10 @@ __global__ __launch_bounds__(256) void bg_softmax_kernel(const float* __restrict
     for (int k = lane; k < n; k += 64) Pm[row * n + k] = (half_t)(expf(s[k] - mx) * inv);
 }
 void launch_bg_softmax(const float* S, long long rows, int n, half_t* Pm, hipStream_t st) {
-    hipLaunchKernelGGL(bg_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, n, Pm);
+    const dim3 g((unsigned)((rows + 3) / 4));
+    if (n == 1024) hipLaunchKernelGGL(bg_softmax_reg_kernel<4>, g, dim3(256), 0, st, S, rows, Pm);
+    else if (n == 256) hipLaunchKernelGGL(bg_softmax_reg_kernel<1>, g, dim3(256), 0, st, S, rows, Pm);
+    else hipLaunchKernelGGL(bg_softmax_kernel, g, dim3(256), 0, st, S, rows, n, Pm);
 }
 
 // ---- y[b][c][p] = tanh(x[b][p][c]), c < 3 : conv_to_rgb output (NHWC, C channels) -> planar fp32 -------
