@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         const int pix = v >> 2;
         const int pr = pix / PW, pc = pix - pr * PW;
         prc[k] = v < NVA ? (pr << 8 | pc) : -1;
-        rel[k] = FRGB ? pr * p.W + pc : (pr * p.W + pc) * 32 + part * 8;
+        // in_up (nearest x2 input): tile origins are even, so (ty0 - 1 + pr) >> 1 = ty0 / 2 + ((pr - 1) >> 1)
+        rel[k] = FRGB ? pr * p.W + pc
+                      : (p.in_up ? (((pr - 1) >> 1) * (p.W >> 1) + ((pc - 1) >> 1)) * 32 : (pr * p.W + pc) * 32) + part * 8;
     }
     // FRGB: this thread's 8 output channels of the 1x1 fromRGB conv (part is fixed per thread)
     // packed fp16, sqrt(2) folded in: lrelu(z) * sqrt2 = max(z', 0.2 z') with z' = z * sqrt2
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
             }
         } else {
             const half_t* img = p.x + (long long)b * p.x_bstride;
-            const long long org = ((long long)(ty0 - 1) * p.W + (tx0 - 1)) * 32;
+            const long long org = p.in_up ? ((long long)(ty0 >> 1) * (p.W >> 1) + (tx0 >> 1)) * 32
+                                          : ((long long)(ty0 - 1) * p.W + (tx0 - 1)) * 32;
 #pragma unroll
             for (int k = 0; k < NA; ++k) {
                 const long long off = tile_ok(id, k, ty0, tx0) ? org + rel[k] : 0;
@@ -118,13 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
         const int b = id / tpi, trem = id - b * tpi;
         const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * 32;
         __syncthreads();                           // every wave is done reading As / Ws of the previous tile
-        if (wb != b && (wb < 0 || p.w_bstride != 0 || p.dscale || p.sn16)) {
+        if (wb != b && (wb < 0 || p.w_bstride != 0 || p.dscale || p.shift || p.sn16)) {
             const half_t* wsrc = p.w + (long long)b * p.w_bstride;   // [9][32][32]
             for (int u = t; u < 9 * 32 * 4; u += 256)
                 *(h8*)(Ws + (u >> 2) * ROWB + (u & 3) * 16) = *(const h8*)(wsrc + (long long)(u >> 2) * 32 + (u & 3) * 8);
             if (t < 32) {
                 Cd[t] = p.dscale ? p.dscale[(long long)b * p.ds_stride + t] : 1.f;
-                Cb[t] = p.bias ? p.bias[t] : 0.f;
+                Cb[t] = (p.bias ? p.bias[t] : 0.f) + (p.shift ? p.shift[(long long)b * p.ds_stride + t] : 0.f);
                 Cs[t] = p.sn16 ? p.sn16[(long long)b * p.sn_stride + t] : (half_t)1.f;
             }
             wb = b;
@@ -237,7 +240,8 @@ const char* launch_conv_stream(const ConvParams& p, hipStream_t st) {
     if (off || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return nullptr;
     const bool frgb = p.rgb_y != nullptr;
     if (frgb && (!p.rgb_w || !p.rgb_b || !p.rgb_x_out || p.sn)) return nullptr;
-    if (p.Cin != 32 || p.Neff != 32 || p.Cout != 32 || p.res || p.shift || p.pre_shift || p.in_up || p.res_cs || p.res_up) return nullptr;
+    if (p.Cin != 32 || p.Neff != 32 || p.Cout != 32 || p.res || p.pre_shift || p.res_cs || p.res_up) return nullptr;
+    if (frgb && (p.in_up || p.shift)) return nullptr;
     if (p.Wc % 32 != 0 || p.Hc % TH != 0 || p.W >= 256 * 32 || (!frgb && p.x_bstride == 0 && p.B > 1)) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;

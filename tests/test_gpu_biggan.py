@@ -67,6 +67,12 @@ def test_biggan_512_two_candidates():
     _run_case("bg512", 2, 2)
 
 
+def test_biggan_512_eight_candidates_streaming_kernels():
+    """P = 8 makes the 512^2 layers large enough (>= 4096 tiles) for conv_stream (nearest-up input addressing and the
+    fused bn shift + relu epilogue), which the two-candidate case leaves to conv_tiled."""
+    _run_case("bg512", 8, 8)
+
+
 def test_biggan_error_paths():
     from clip_glass_amd.engine import Engine
     c = M.BIGGAN_CONFIGS["bg_mini"]
