@@ -130,7 +130,12 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                     a = a_goff[k] >= 0 ? __builtin_elementwise_max(a * sh + shf, zero) : zero;
                 } else if (snb) a = a * sh;    // 4 x v_pk_mul_f16
-                *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
+                int lrow = v >> 2;
+                if (S == 2) {   // de-interleave the patch columns (even | odd): a stride-2 fragment read then walks CONSECUTIVE
+                    const int pr = lrow / PW, pc = lrow - pr * PW;       // LDS rows (with pixel order it is 2-way bank-conflicted
+                    lrow = pr * PW + ((pc & 1) ? (PW + 1) / 2 + (pc >> 1) : (pc >> 1));   // for any 16-byte-aligned row pitch)
+                }
+                *(h8*)(As + lrow * ROWB + part * 16) = a;
             }
         }
     };
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
                         const int prow = (wave * RW + i) * S + ty;
-                        const h8 xf = *(const h8*)(As + (prow * PW + lr * S + tx) * ROWB + kk * 32 + kh * 16);
+                        const int pcol = S == 2 ? ((tx & 1) ? (PW + 1) / 2 + lr + (tx >> 1) : lr + (tx >> 1)) : lr + tx;
+                        const h8 xf = *(const h8*)(As + (prow * PW + pcol) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
                     }
