@@ -50,6 +50,9 @@ BIGGAN_CONFIGS = {
     # 64 px, 6 GenBlocks + attention at 16x16; CLIP-mini at 32 px (resize 64 -> 32)
     "bg_mini": dict(layers=[(0, 16, 16), (1, 16, 8), (1, 8, 4), (0, 4, 4), (1, 4, 2), (1, 2, 1)], attention_pos=3, ch=64,
                     z_dim=16, num_classes=24, clip=(128, 2, 2, 8, 32, 64)),
+    # the released biggan-deep-256 geometry (config DeepMindBigGAN256) + CLIP ViT-B/32
+    "bg256": dict(layers=synth.BIGGAN_LAYERS[256], attention_pos=8, ch=128, z_dim=128, num_classes=1000,
+                  clip=(768, 12, 12, 32, 224, 512)),
     # the released biggan-deep-512 geometry + CLIP ViT-B/32
     "bg512": dict(layers=synth.BIGGAN_LAYERS[512], attention_pos=8, ch=128, z_dim=128, num_classes=1000,
                   clip=(768, 12, 12, 32, 224, 512)),

@@ -63,6 +63,10 @@ def test_biggan_truncation_blend():
     _run_case("bg_mini", 4, 4, truncation=0.41)
 
 
+def test_biggan_256_two_candidates():
+    _run_case("bg256", 2, 2)
+
+
 def test_biggan_512_two_candidates():
     _run_case("bg512", 2, 2)
 
