@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void torgb_kernel(const half_t* x, int H, int 
     }
     const int hw = H * W, h2 = H >> 1, w2_ = W >> 1;
     constexpr int PPB = 256 / LPP;                       // pixels per block per sub-step
-    constexpr int U = 4;                                 // pixels per thread per iteration: U feature loads (+ 4 U skip
+    constexpr int U = 8;                                 // pixels per thread per iteration: U feature loads (+ 4 U skip
     const int cch = sub < 3 ? sub : 0;                   // taps on lanes 0..2 of a pixel) in flight, all unconditional
     const float bc = bias[cch];
     const float* yp = yprev ? yprev + ((long long)b * 3 + cch) * h2 * w2_ : nullptr;
@@ -333,7 +333,7 @@ template <int LPP>
 static void launch_torgb_t(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                            const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
                            float* yout, hipStream_t st) {
-    const int ppb = (256 / LPP) * 4;                     // U = 4 pixels per thread per iteration
+    const int ppb = (256 / LPP) * 8;                     // U = 8 pixels per thread per iteration
     int gx = (H * W + ppb - 1) / ppb;
     if (gx > 2048) gx = 2048;                            // grid-stride the rest
     hipLaunchKernelGGL(torgb_kernel<LPP>, dim3(gx, B), dim3(256), 0, st, x, H, W, C, wrgb, bias, sn, sn_stride, smax,
