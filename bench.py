@@ -47,20 +47,42 @@ def cpu_baseline(sd, cfg, target):
         best = dt if best is None else min(best, dt)
         if dt > 15:
             break
-    return dict(value=BATCH / best, unit="candidates/s", cores=torch.get_num_threads(), kind="port",
-                sample="oracle/ (torch-CPU fp32 restatement) on P=4 (one minibatch) of the same workload, best of <=2 calls, %.2f s" % best)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        phys = None
+    return dict(value=BATCH / best, unit="candidates/s", cores=torch.get_num_threads(), physical_cores=phys,
+                logical_cpus=os.cpu_count(), kind="port",
+                sample="oracle/ (torch-CPU fp32 restatement) on P=4 (one minibatch = one G call + one D call, models.py:108-129) of "
+                       "the same workload, torch intra-op threads = cores, best of <=2 calls, %.2f s" % best)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed _evaluate calls (the config runs 50 generations)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="ffhq", help="model size key (tests/models.py naming); ffhq = the headline")
     ap.add_argument("--pop", type=int, default=POP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare as `python bench.py --gpus N`: become the launcher — one process per GPU under torch.distributed.run
+        # (RCCL rendezvous on 127.0.0.1); rank 0's JSON line is the only thing on stdout
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("GLASS_BENCH_LAUNCH_DRYRUN"):      # CPU test hook: show the launch line, start nothing
+            print(json.dumps(cmd))
+            sys.exit(0)
+        sys.exit(subprocess.call(cmd))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -76,8 +98,17 @@ def main():
         os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("GLASS_BENCH_SHARE_GPU"):      # test knob: several ranks on the one GPU of a test box
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")    # "nccl" IS RCCL on ROCm; gloo only for the shared-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
+        if os.environ.get("GLASS_BENCH_FORCE_DIST") is None:
+            assert world == args.gpus, "--gpus %d but the launcher started %d ranks" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
 
@@ -176,7 +207,7 @@ def main():
             a3[k3] += r[k3]
     eng.set_profiling(False)
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda")
+        tt = torch.tensor([dt], device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert F_all.shape == (P * world, n_obj) and np.isfinite(F_all).all()
@@ -233,7 +264,7 @@ def main():
             metric = METRIC
             workload = ("StyleGAN2_ffhq_d: StyleGAN2 config-f %dpx G+D + CLIP ViT-B/32, pop=%d per GPU, batch_size=%d, n_obj=2"
                         % (4 << (len(cfg["channels"]) - 1), P, BATCH))
-        out = dict(metric=metric, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=world,
+        out = dict(metric=metric, value=P * world * args.steps / dt, unit="candidates/s", n_gpus=(dist.get_world_size() if dist is not None else 1),
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
                    config=dict(workload=workload, pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,

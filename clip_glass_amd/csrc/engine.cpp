@@ -97,9 +97,11 @@ std::vector<float> transposed(const float* W, int N, int K, float coef) {
 extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) {
     REQUIRE(cfg && out, GLASS_ERR_ARG, "null argument");
     REQUIRE(cfg->n_blocks >= 0 && cfg->n_blocks <= GLASS_MAX_BLOCKS, GLASS_ERR_ARG, "n_blocks out of range");
-    for (int i = 0; i < cfg->n_blocks; ++i)
-        REQUIRE(cfg->channels[i] > 0 && cfg->channels[i] % 16 == 0, GLASS_ERR_ARG,
-                "channels must be positive multiples of 16");
+    for (int i = 0; i < cfg->n_blocks; ++i) {
+        const int ch = cfg->channels[i];    // the toRGB / fromRGB kernels are instantiated for these widths (kernels_misc.hip)
+        REQUIRE(ch == 16 || ch == 32 || ch == 64 || ch == 128 || ch == 256 || ch == 512, GLASS_ERR_ARG,
+                "channels must be one of 16, 32, 64, 128, 256, 512");
+    }
     REQUIRE(cfg->latent_size > 0 && cfg->latent_size % 4 == 0, GLASS_ERR_ARG, "latent_size must be a multiple of 4");
     REQUIRE(cfg->batch_size > 0 && cfg->max_pop > 0, GLASS_ERR_ARG, "batch_size/max_pop must be positive");
     REQUIRE(cfg->max_pop % cfg->batch_size == 0, GLASS_ERR_ARG, "max_pop must be a multiple of batch_size");

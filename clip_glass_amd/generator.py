@@ -5,6 +5,8 @@ and exposes generate / clip_similarity / discriminate / save.  Here the GAN, the
 CLIP live on the device behind ONE call (`evaluate`), so `_evaluate` makes a single trip;
 `generate` / `save` serve run.py's callbacks (run.py:45-51,118-125).
 """
+import os
+
 import numpy as np
 
 from . import synth
@@ -14,8 +16,37 @@ from .utils import save_grid, save_image
 CLIP_VIT_B32 = (768, 12, 12, 32, 224, 512)
 
 
+def clip_geometry_from_state(state):
+    """(width, layers, heads, patch, input_res, embed) of the VISUAL tower from a CLIP state dict keyed as
+    clip/model.py:363-399 reads it (only `clip.visual.*` blocks count: the text tower has resblocks too)."""
+    width = state["clip.visual.conv1.weight"].shape[0]
+    patch = state["clip.visual.conv1.weight"].shape[-1]
+    grid = round((state["clip.visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    layers = len([k for k in state if k.startswith("clip.visual.") and k.endswith(".attn.in_proj_weight")])
+    return (width, layers, width // 64, patch, patch * grid, state["clip.visual.proj"].shape[1])
+
+
+def clip_state_from_checkpoint(sd, with_text):
+    """reference CLIP state dict (clip.load(...).state_dict(), clip/clip.py:64-78; keys as build_model reads them,
+    clip/model.py:363-399) -> engine tensors under "clip." + key.  The three geometry scalars of the jit archive and
+    logit_scale are not weights of either tower."""
+    state = {}
+    for k, v in sd.items():
+        if k in ("input_resolution", "context_length", "vocab_size", "logit_scale"):
+            continue
+        if k.startswith("visual.") or with_text:
+            state["clip." + k] = np.asarray(v.float().numpy() if hasattr(v, "float") else v, dtype=np.float32)
+    return state
+
+
 def _load_clip_state(config, with_text):
-    w = str(getattr(config, "clip_weights", "synthetic:0"))
+    w = getattr(config, "clip_weights", None)
+    if w is None:
+        # the reference always loads the pretrained ViT-B/32 (clip/clip.py:29-33); a silent random-weight CLIP would run a
+        # whole search against meaningless fitness values
+        raise RuntimeError("config.clip_weights is not set: pass the CLIP ViT-B/32 checkpoint (--clip-weights PATH), or "
+                           "'synthetic:<seed>' explicitly for tests / benchmarks")
+    w = str(w)
     if w.startswith("synthetic"):
         seed = int(w.split(":")[1]) if ":" in w else 0
         geom = tuple(getattr(config, "clip_geometry", CLIP_VIT_B32))
@@ -30,14 +61,8 @@ def _load_clip_state(config, with_text):
         sd = torch.jit.load(w, map_location="cpu").state_dict()
     except RuntimeError:
         sd = torch.load(w, map_location="cpu")
-    state = {"clip." + k: v.float().numpy() for k, v in sd.items()
-             if k.startswith("visual.") or (with_text and not k.startswith("visual.") and v.dim() > 0
-                                            and k not in ("input_resolution", "context_length", "vocab_size"))}
-    width = state["clip.visual.conv1.weight"].shape[0]
-    patch = state["clip.visual.conv1.weight"].shape[-1]
-    grid = round((state["clip.visual.positional_embedding"].shape[0] - 1) ** 0.5)
-    layers = len([k for k in state if k.endswith(".attn.in_proj_weight")])
-    return state, (width, layers, width // 64, patch, patch * grid, state["clip.visual.proj"].shape[1])
+    state = clip_state_from_checkpoint(sd, with_text)
+    return state, clip_geometry_from_state(state)
 
 
 def clip_preprocess(path_or_image, n_px=224):
@@ -65,9 +90,13 @@ class Generator:
         self.augmentation = None
         self.model = config.model(config)                                   # generator.py:19
         device = getattr(config, "device", 0)
-        device = int(str(device).split(":")[1]) if ":" in str(device) else (device if isinstance(device, int) else 0)
+        if ":" in str(device):
+            device = int(str(device).split(":")[1])
+        elif not isinstance(device, int):       # bare "cuda": under a one-process-per-GPU launch this rank's GPU
+            device = int(os.environ.get("LOCAL_RANK", "0")) if dist is not None else 0
         pop = int(getattr(config, "max_pop", max(config.pop_size, config.batch_size)))
         self.generation = 0
+        self.sharder = None
         if config.task == "img2txt":                                        # generator.py:25-27, 52-59
             clip_state, geom = _load_clip_state(config, True)
             self.engine = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1,
@@ -107,6 +136,9 @@ class Generator:
             self.tokens = tok.tokenize([self.config.target])
             self.text_features = self.engine.encode_text(self.tokens)
         self.engine.set_target(self.text_features[0])
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            from .parallel import ShardedEvaluator
+            self.sharder = ShardedEvaluator(self.engine, dist, dist.get_rank(), dist.get_world_size(), config.batch_size)
 
     def clip_similarity_texts(self, texts):
         """generator.py:52-59 (img2txt branch): tokenize -> encode_text -> cosine vs the target image feature;
@@ -127,7 +159,10 @@ class Generator:
             self.last_texts = texts
             return -self.clip_similarity_texts(texts)[:, None]
         z = ls.population()
-        F = self.engine.evaluate(z, generation=self.generation, first_minibatch=first_minibatch, noise=noise)
+        if self.sharder is not None:        # one process per GPU: this rank scores its shard, ONE all-gather of the rows
+            F = self.sharder.evaluate_global(z, generation=self.generation)
+        else:
+            F = self.engine.evaluate(z, generation=self.generation, first_minibatch=first_minibatch, noise=noise)
         self.generation += 1
         return F
 

@@ -21,6 +21,9 @@ class StyleGAN2LatentSpace:
 
     __call__ = forward
 
+    def state_dict(self):       # run.py:101 (the reference's nn.Module holds z as a plain tensor: its state_dict is empty;
+        return {"z": self.z}    # the tokens are kept here so ls_result is usable)
+
     def population(self):
         return self.z
 
@@ -77,3 +80,6 @@ class GPT2LatentSpace:
         return (self.z,)
 
     __call__ = forward
+
+    def state_dict(self):       # run.py:101 (the reference's nn.Module holds z as a plain tensor: its state_dict is empty;
+        return {"z": self.z}    # the tokens are kept here so ls_result is usable)

@@ -107,6 +107,27 @@ class DeepMindBigGAN:
         return False
 
 
+def remap_gpt2_state(sd):
+    """HF `gpt2-pytorch_model.bin` keys -> engine tensors, as gpt2/utils.py:10-51 does: TF-style LayerNorm names
+    (.g/.b/.w -> .weight/.bias), the missing `transformer.` prefix; the causal-mask buffers `h.N.attn.bias`
+    (NOT `h.N.attn.c_attn.bias`, the QKV bias) and the tied `lm_head` are not weights."""
+    import re
+    state = {}
+    for k, v in sd.items():
+        for old, new in ((".g", ".weight"), (".b", ".bias"), (".w", ".weight")):                 # gpt2/utils.py:13-26
+            if k.endswith(old):
+                k = k[:-len(old)] + new
+                break
+        if k.startswith("lm_head."):                                                             # tied to wte (model.py:175-178)
+            continue
+        if not k.startswith("transformer."):                                                     # utils.py:46-48
+            k = "transformer." + k
+        if re.fullmatch(r"transformer\.h\.\d+\.attn\.(bias|masked_bias)", k):
+            continue
+        state["gpt2." + k] = np.asarray(v.float().numpy() if hasattr(v, "float") else v, dtype=np.float32)
+    return state
+
+
 class GPT2:
     """models.py:13-62 — GPT-2 small as a token-latent text generator (img2txt).  Host part: weights
     (HF `gpt2-pytorch_model.bin` remapped as gpt2/utils.py:10-51 does, or synthetic), BPE, parse_out; the
@@ -124,18 +145,7 @@ class GPT2:
                 print("Weights not found!\nRun: ./download-weights.sh GPT2")                 # models.py:18-20
                 sys.exit(1)
             import torch
-            sd = torch.load(w, map_location="cpu")
-            self.state = {}
-            for k, v in sd.items():                                                          # gpt2/utils.py:13-26
-                for old, new in ((".g", ".weight"), (".b", ".bias"), (".w", ".weight")):
-                    if k.endswith(old):
-                        k = k[:-len(old)] + new
-                        break
-                if not k.startswith("transformer."):                                         # utils.py:46-48
-                    k = "transformer." + k
-                if k.endswith("attn.bias"):       # the causal-mask buffer, not a weight
-                    continue
-                self.state["gpt2." + k] = v.float().numpy()
+            self.state = remap_gpt2_state(torch.load(w, map_location="cpu"))
         self.enc = None
         enc_path, vocab_path = getattr(config, "encoder", None), getattr(config, "vocab", None)
         if enc_path and vocab_path and os.path.exists(enc_path) and os.path.exists(vocab_path):

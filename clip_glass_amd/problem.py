@@ -29,9 +29,10 @@ from .generator import Generator
 
 class GenerationProblem(Problem):
     def __init__(self, config, dist=None):
-        self.generator = Generator(config)
+        """dist: an initialised torch.distributed module (one process per GPU; backend "nccl" = RCCL).  Every rank calls
+        _evaluate with the SAME x; each scores its contiguous shard and one all-gather returns all rows (parallel.py)."""
+        self.generator = Generator(config, dist=dist)
         self.config = config
-        self._dist = dist
         super().__init__(**self.config.problem_args)
 
     def _evaluate(self, x, out, *args, **kwargs):

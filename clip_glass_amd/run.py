@@ -3,9 +3,9 @@
     python -m clip_glass_amd.run --config StyleGAN2_ffhq_d --target "a wolf at night ..." \\
         --generations 50 --tmp-folder ./tmp [--weights synthetic:0 --clip-weights synthetic:0]
 
-Uses pymoo's minimize() when pymoo is importable, otherwise the native driver in search.py.
-Outputs (run.py:29-51, 79-125): genetic-it-*.jpg every --save-each generations,
-genetic_result (pickle: X, F, G, CV), F.jpg (Pareto scatter, two objectives), ls_result, output.jpg.
+The search runs on the native GA / NSGA-II driver in search.py (pymoo 0.4.2.1 does not import under numpy >= 1.24).
+Outputs (run.py:29-51, 79-125): genetic-it-*.{jpg,txt} every --save-each generations,
+genetic_result (pickle: X, F, G, CV), F.jpg (Pareto scatter, two objectives), ls_result, output.{jpg,txt}.
 """
 import argparse
 import os
@@ -58,7 +58,8 @@ def main(argv=None, extra_config=None):
             ls = config.latent(config)
             ls.set_from_population(X)
             generated = algorithm.problem.generator.generate(ls, minibatch=config.batch_size)
-            name = "genetic-it-%d.jpg" % it if it < config.generations else "genetic-it-final.jpg"
+            ext = "txt" if config.task == "img2txt" else "jpg"                   # run.py:46-50
+            name = "genetic-it-%d.%s" % (it, ext) if it < config.generations else "genetic-it-final.%s" % ext
             algorithm.problem.generator.save(generated, os.path.join(config.tmp_folder, name))
 
     problem = GenerationProblem(config)
@@ -87,14 +88,16 @@ def main(argv=None, extra_config=None):
         X = np.stack([p.X for p in res.pop])
     ls = config.latent(config)
     ls.set_from_population(X)
-    np.savez(os.path.join(config.tmp_folder, "ls_result"), **ls.state_dict())   # run.py:101
+    with open(os.path.join(config.tmp_folder, "ls_result"), "wb") as f:        # run.py:101 (same file name, npz payload)
+        np.savez(f, **ls.state_dict())
     if config.problem_args["n_obj"] == 1:
         X = np.atleast_2d(res.X)
     else:
         X = np.atleast_2d(np.atleast_2d(res.X)[search.pseudo_weights_choice(np.atleast_2d(res.F), [0, 1])])  # run.py:103-113
     ls.set_from_population(X)
     generated = problem.generator.generate(ls)                                 # run.py:118
-    problem.generator.save(generated, os.path.join(config.tmp_folder, "output.jpg"))
+    ext = "txt" if config.task == "img2txt" else "jpg"                         # run.py:120-125
+    problem.generator.save(generated, os.path.join(config.tmp_folder, "output.%s" % ext))
     return res
 
 

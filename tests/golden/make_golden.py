@@ -121,8 +121,13 @@ def gpt2_case(seed=2, P=8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ffhq", action="store_true")
+    ap.add_argument("--only-ffhq", action="store_true")
     args = ap.parse_args()
     assert rh.available(), "needs /root/reference"
+    if args.only_ffhq:
+        np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 8, 4, 0, 11, 2))
+        print("ffhq_modules.npz")
+        return
     np.savez_compressed(os.path.join(HERE, "mini_problem.npz"), **problem_case())
     print("mini_problem.npz")
     np.savez_compressed(os.path.join(HERE, "gpt2_mini.npz"), **gpt2_case())
@@ -132,7 +137,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mini_modules.npz"), **modules_case("mini", 8, 4, 0, 11, 2))
     print("mini_modules.npz")
     if not args.skip_ffhq:
-        np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 4, 4, 0, 11, 2))
+        # P = 8: two minibatches = two shared noise planes per layer and two mbstd groups (SURVEY 8a notes 4-5)
+        np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 8, 4, 0, 11, 2))
         print("ffhq_modules.npz")
 
 

@@ -128,7 +128,7 @@ def test_biggan_generation_problem_and_cli(tmp_path):
     argv = ["--config", "DeepMindBigGAN512", "--generations", "3", "--save-each", "2", "--tmp-folder", str(tmp_path),
             "--pop-size", "8"]
     res = run.main(argv, extra_config=extra)
-    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result.npz", "output.jpg"):
+    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result", "output.jpg"):
         assert os.path.getsize(os.path.join(str(tmp_path), f)) > 0, f
     d = pickle.load(open(os.path.join(str(tmp_path), "genetic_result"), "rb"))
     assert np.atleast_2d(d["X"]).shape[1] == n_var

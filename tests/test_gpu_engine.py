@@ -179,7 +179,104 @@ def test_run_cli_end_to_end(tmp_path):
             "--weights", "synthetic:0", "--clip-weights", "synthetic:0", "--pop-size", "8", "--bpe-path", bpe]
     res = run.main(argv, extra_config=extra)
     assert np.atleast_2d(res.F).shape[1] == 2
-    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result.npz", "output.jpg"):
+    for f in ("genetic-it-2.jpg", "genetic-it-final.jpg", "genetic_result", "ls_result", "output.jpg"):
         assert os.path.getsize(os.path.join(str(tmp_path), f)) > 0, f
     d = pickle.load(open(os.path.join(str(tmp_path), "genetic_result"), "rb"))
     assert set(d) == {"X", "F", "G", "CV"}
+
+
+def test_offset_shards_equal_whole_population():
+    """SURVEY 8(e) / config C4 on one GPU: a population evaluated as two contiguous shards with first_minibatch offsets
+    (what ranks 0 and 1 of a 2-GPU job do, parallel.py) equals the single-call result — device noise is a pure function
+    of (seed, generation, GLOBAL minibatch, layer) and mbstd groups never straddle a shard (models.py:108-129)."""
+    from clip_glass_amd.parallel import shard_bounds
+    name, P, bs = "mini", 16, 4
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, 0)
+    x = synth.latents(7, P, c["latent"])
+    e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1, noise_seed=99)
+    e.set_target(np.ones(c["clip"][5], np.float32))
+    e.evaluate(x, generation=5)
+    target = M.make_target(e.details(P)["features"])
+    e.set_target(target)
+    F_whole = e.evaluate(x, generation=5)
+    for world in (2, 4):
+        parts = []
+        for lo, hi in shard_bounds(P, world, bs):
+            parts.append(e.evaluate(x[lo:hi], generation=5, first_minibatch=lo // bs))
+        F_shards = np.concatenate(parts)
+        np.testing.assert_allclose(F_shards, F_whole, rtol=0, atol=1e-6)
+    # an uneven split (3 ranks: 8 + 4 + 4) and a different generation both change nothing / something as expected
+    parts = [e.evaluate(x[lo:hi], generation=5, first_minibatch=lo // bs) for lo, hi in shard_bounds(P, 3, bs)]
+    np.testing.assert_allclose(np.concatenate(parts), F_whole, rtol=0, atol=1e-6)
+    assert np.abs(e.evaluate(x, generation=6) - F_whole).max() > 1e-5     # fresh noise per generation (modules.py:428-452)
+    e.close()
+
+
+def test_pop512_as_eight_shards_of_64():
+    """BASELINE.json configs[3] (StyleGAN2_ffhq_d pop=512, 64 per GPU x 8) exercised as offset shards on ONE GPU at the mid
+    architecture: the eight 64-row shard calls reproduce the whole-population call row for row."""
+    from clip_glass_amd.parallel import shard_bounds
+    name, P, bs = "mid", 512, 4
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, 0)
+    x = synth.latents(11, P, c["latent"])
+    e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1, noise_seed=3)
+    e.set_target(np.ones(c["clip"][5], np.float32))
+    e.evaluate(x[:64], generation=0)
+    e.set_target(M.make_target(e.details(64)["features"]))
+    F_whole = e.evaluate(x, generation=2)
+    parts = [e.evaluate(x[lo:hi], generation=2, first_minibatch=lo // bs) for lo, hi in shard_bounds(P, 8, bs)]
+    assert all(p.shape == (64, 2) for p in parts)
+    np.testing.assert_allclose(np.concatenate(parts), F_whole, rtol=0, atol=1e-6)
+    e.close()
+
+
+def test_bench_launcher_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must become the launcher (torch.distributed.run, one process per
+    rank) and print ONE JSON line with n_gpus = 2.  This box has one GPU: both ranks share it and rendezvous over gloo
+    (GLASS_BENCH_BACKEND / GLASS_BENCH_SHARE_GPU are test knobs; the driver's 8-GPU run uses RCCL, one GPU per rank)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GLASS_BENCH_BACKEND="gloo", GLASS_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--config", "mid", "--pop", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_pop"] == 16
+    assert out["scaling"] == "weak" and out["value"] > 0
+
+
+def test_full_size_ffhq_full_population():
+    """The exact code path bench.py times: ffhq-1024 G+D + CLIP ViT-B/32, P = 64, default chunk (64), device noise.
+    Rows 0-7 must equal the reference-generated fixture (tests/golden/ffhq_modules.npz, P = 8 = two minibatches), and the
+    whole F must equal a chunk = 4 run (one minibatch per launch group) of the same population."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ffhq_modules.npz"))
+    name, P, bs = "ffhq", 64, 4
+    c = M.CONFIGS[name]
+    Pg = int(g["P"])
+    sd = M.make_state(name, int(g["seed"]))
+    x = np.concatenate([synth.latents(int(g["seed"]) + 1, Pg, c["latent"]), synth.latents(1234, P - Pg, c["latent"])])
+    Fs = []
+    for chunk in (0, 4):
+        e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1,
+                          noise_seed=int(g["noise_seed"]), chunk=chunk)
+        e.set_target(g["target"])
+        Fs.append(e.evaluate(x, generation=int(g["generation"])))
+        if chunk == 0:
+            det = e.details(P)
+        e.close()
+    rel = np.abs(det["sim"][:Pg] - g["sim"]) / np.abs(g["sim"])
+    diag("[e2e] ffhq P=64 default chunk: rows 0-%d vs reference fixture: sim rel err %.3e, D abs err %.3e; chunk 64 vs 4 max |dF| %.3e"
+         % (Pg - 1, rel.max(), np.abs(det["dis"][:Pg] - g["dis"]).max(), np.abs(Fs[0] - Fs[1]).max()))
+    assert rel.max() < 1e-3
+    check("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], 5e-3, atol=2e-3)
+    assert np.isfinite(Fs[0]).all() and Fs[0].shape == (P, 2)
+    np.testing.assert_allclose(Fs[0], Fs[1], rtol=0, atol=1e-6)

@@ -2,6 +2,7 @@
 over a 2-process gloo group.  No GPU needed (`-m "not gpu"`)."""
 import os
 import re
+import sys
 import types
 
 import numpy as np
@@ -121,7 +122,7 @@ def test_generation_problem_contract_with_stub_generator(monkeypatch):
     from clip_glass_amd import problem
 
     class FakeGen:
-        def __init__(self, config):
+        def __init__(self, config, dist=None):
             self.config = config
 
         def evaluate(self, ls):
@@ -230,3 +231,21 @@ def test_clip_tokenizer_matches_reference_known_answers():
         np.testing.assert_array_equal(mine, ref_tok(texts).numpy())
     with pytest.raises(RuntimeError, match="too long"):
         tok.tokenize(["word " * 100])
+
+
+def test_bench_gpus_flag_becomes_a_launcher():
+    """`python bench.py --gpus 8` with no WORLD_SIZE must re-exec itself under torch.distributed.run with 8 ranks (the
+    driver's scaling run); with WORLD_SIZE set (already under a launcher) it must not."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["GLASS_BENCH_LAUNCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
