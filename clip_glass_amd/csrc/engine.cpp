@@ -942,6 +942,19 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         if (i == 0 && rgb_y && !fused_rgb) run_fromrgb(e, B, rgb_y, X);
         snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
         if (!fused_rgb) run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
+        {   // blur + blur-down + 1x1 skip + stride-2 conv + residual merge as ONE kernel where the block qualifies
+            snprintf(tag, sizeof tag, "D.down.r%d.%dx%d", r2, d.cin, d.cout);
+            const double px2 = (double)B * r2 * r2;
+            Prof pr(e, tag, 2.0 * px2 * (9.0 + 1.0) * d.cin * d.cout, 2.0 * (2.0 * B * (double)r * r * d.cin + px2 * d.cout));
+            const char* k = launch_conv_down(Hb, X, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur);
+            if (k) {
+                if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                if (e->profiling) e->tag_kernel[tag] = k;
+                std::swap(X, O);
+                continue;
+            }
+            pr.on = false;
+        }
         {
             snprintf(tag, sizeof tag, "D.blur.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);

@@ -187,6 +187,27 @@ extern "C" int glass_op_blur(int32_t device, int32_t mode, int32_t B, int32_t H,
     return down16(out, dy, (size_t)B * Ho * Ho * C);
 }
 
+extern "C" int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_t Cin, int32_t Cout, const float* h,
+                                    const float* x, const float* w1, const float* wskip, const float* b1, float* y) {
+    OPREQ(h && x && w1 && wskip && b1 && y, "bad argument");
+    GLASS_HIP(hipSetDevice(device));
+    Dev dv;
+    half_t* dh = dv.up16(h, (size_t)B * R * R * Cin);
+    half_t* dx = dv.up16(x, (size_t)B * R * R * Cin);
+    std::vector<_Float16> pk;
+    glass_pack_conv(w1, Cout, Cin, 3, Cin, pk);
+    half_t* dw1 = dv.up16v(pk);
+    glass_pack_conv(wskip, Cout, Cin, 1, Cin, pk);
+    half_t* dws = dv.up16v(pk);
+    float* db = dv.up32(b1, Cout);
+    const int Ro = R / 2;
+    half_t* dy = dv.alloc<half_t>((size_t)B * Ro * Ro * Cout);
+    OPREQ(launch_conv_down(dh, dx, dw1, dws, db, dy, B, R, Cin, Cout, 0) != nullptr, "conv_down: unsupported shape");
+    int rc = finish();
+    if (rc) return rc;
+    return down16(y, dy, (size_t)B * Ro * Ro * Cout);
+}
+
 extern "C" int glass_op_fromrgb(int32_t device, int32_t B, int32_t R, int32_t Cout, const float* y, const float* w,
                                 const float* bias, float* out) {
     OPREQ(y && w && bias && out && Cout % 8 == 0, "bad argument");

@@ -111,6 +111,19 @@ def blur(x, mode, device=0):
     return out
 
 
+def dblock_down(h, x, w1, wskip, b1, device=0):
+    """Fused second half of a D block (conv_down.hip).  h, x [B,R,R,Cin] NHWC; w1 [Cout,Cin,3,3]; wskip [Cout,Cin,1,1]."""
+    lib = load_library()
+    h, x, w1, wskip, b1 = _f32(h), _f32(x), _f32(w1), _f32(wskip), _f32(b1)
+    B, R, _, Cin = h.shape
+    Cout = w1.shape[0]
+    out = np.empty((B, R // 2, R // 2, Cout), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.glass_op_dblock_down.argtypes = [C.c_int32] * 5 + [fp] * 6
+    _check(lib, lib.glass_op_dblock_down(device, B, R, Cin, Cout, _fp(h), _fp(x), _fp(w1), _fp(wskip), _fp(b1), _fp(out)))
+    return out
+
+
 def fromrgb(y, w, bias, device=0):
     lib = load_library()
     y, w, bias = _f32(y), _f32(w), _f32(bias)

@@ -43,6 +43,11 @@ int glass_op_torgb(int32_t device, int32_t B, int32_t H, int32_t C, const float*
                    const float* bias, const float* sn, const float* smax, const float* yprev, float* yout);
 int glass_op_blur(int32_t device, int32_t mode /*0: pad2 stride1, 1: pad1 + ::2*/, int32_t B, int32_t H, int32_t C,
                   const float* x, float* out);
+/* second half of a discriminator block in one kernel (conv_down.hip; stylegan2/modules.py:1204-1254, 1587-1601):
+ * y = (lrelu(conv3x3 stride 2 (fir pad 2 (h)) + b1) * sqrt2 + conv1x1(fir pad 1 (x)[::2])) / sqrt2.
+ * h, x [B,R,R,Cin]; w1 [Cout,Cin,3,3], wskip [Cout,Cin,1,1] (reference layouts, un-scaled); y [B,R/2,R/2,Cout] */
+int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_t Cin, int32_t Cout, const float* h, const float* x,
+                         const float* w1, const float* wskip, const float* b1, float* y);
 int glass_op_fromrgb(int32_t device, int32_t B, int32_t R, int32_t Cout, const float* y /*[B,3,R,R]*/,
                      const float* w /*[Cout,3] scaled*/, const float* bias, float* out /*[B,R,R,Cout]*/);
 int glass_op_mbstd(int32_t device, int32_t B, int32_t hw, int32_t C, int32_t Cpad, int32_t batch_size, int32_t group,

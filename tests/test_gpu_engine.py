@@ -228,7 +228,15 @@ def test_pop512_as_eight_shards_of_64():
     F_whole = e.evaluate(x, generation=2)
     parts = [e.evaluate(x[lo:hi], generation=2, first_minibatch=lo // bs) for lo, hi in shard_bounds(P, 8, bs)]
     assert all(p.shape == (64, 2) for p in parts)
-    np.testing.assert_allclose(np.concatenate(parts), F_whole, rtol=0, atol=1e-6)
+    Fs = np.concatenate(parts)
+    # a 512-row launch and a 64-row launch may pick different kernel instances for the same layer (launch-size thresholds:
+    # streaming vs tiled conv, split-K depth), so rows agree to rounding, not bitwise: -sim to 1e-3 relative (the
+    # north-star bar), the D hinge to the D tolerance used everywhere else in this file
+    np.testing.assert_allclose(Fs[:, 0], F_whole[:, 0], rtol=1e-3, atol=0)
+    np.testing.assert_allclose(Fs[:, 1], F_whole[:, 1], rtol=5e-3, atol=2e-3)
+    # the SAME 64-row launch repeated with the same offsets is bitwise reproducible
+    again = e.evaluate(x[64:128], generation=2, first_minibatch=16)
+    np.testing.assert_array_equal(again, parts[1])
     e.close()
 
 
@@ -279,4 +287,6 @@ def test_full_size_ffhq_full_population():
     assert rel.max() < 1e-3
     check("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], 5e-3, atol=2e-3)
     assert np.isfinite(Fs[0]).all() and Fs[0].shape == (P, 2)
-    np.testing.assert_allclose(Fs[0], Fs[1], rtol=0, atol=1e-6)
+    # chunk 64 and chunk 4 launches may select different kernel instances per layer: equal to rounding
+    np.testing.assert_allclose(Fs[0][:, 0], Fs[1][:, 0], rtol=1e-3, atol=0)
+    np.testing.assert_allclose(Fs[0][:, 1], Fs[1][:, 1], rtol=5e-3, atol=2e-3)

@@ -169,6 +169,29 @@ def test_d_block_pieces(impl, H, Cin, Cout):
     check("D conv1 s2 + res", nchw(g_o), ref, 6e-3)
 
 
+@pytest.mark.parametrize("B,R,Cin,Cout", [
+    (2, 64, 32, 64),      # resident-weight instance (Cin 32, one n tile): the 1024^2 block's kernel, one tile column
+    (1, 128, 32, 64),     # two tile columns: interior window columns on both sides, edge columns inside the image
+    (3, 64, 64, 128),     # streamed weights: two chunks, two n tiles, odd item count per workgroup
+    (1, 64, 96, 64),      # three chunks
+])
+def test_d_block_down_fused(B, R, Cin, Cout):
+    """conv_down.hip: FIR pad 2 -> conv3x3 stride 2 + bias + lrelu*sqrt2, FIR pad 1 -> ::2 -> conv1x1 skip, (a + b)/sqrt2 in one
+    kernel (modules.py:1204-1254, 1587-1601) vs the oracle's ops on the same fp16-rounded inputs."""
+    h = rnd(14, "h", (B, Cin, R, R)); x = rnd(14, "x", (B, Cin, R, R))
+    w1 = rnd(14, "w1", (Cout, Cin, 3, 3)); b1 = rnd(14, "b1", (Cout,), 0.3); ws = rnd(14, "ws", (Cout, Cin, 1, 1))
+    ht, xt = torch.tensor(h16(h)), torch.tensor(h16(x))
+    hb = sg._filter(ht, sg._fir(), 2, 2)
+    h1 = sg._bias_act(sg._conv(hb, torch.tensor(w1), stride=2), torch.tensor(b1))
+    xs = sg._filter(xt, sg._fir(), 1, 1)[:, :, ::2, ::2]
+    ref = ((h1 + sg._conv(xs, torch.tensor(ws))) / math.sqrt(2)).numpy()
+    got = ops.dblock_down(nhwc(h), nhwc(x), w1, ws, b1)
+    check("D down fused B%d R%d %d->%d" % (B, R, Cin, Cout), nchw(got), ref, 6e-3)
+    # image borders carry the zero padding of both FIRs: check them on their own (a wrong mask hides in a global norm)
+    for name, sl in (("top", np.s_[:, :, :2, :]), ("bottom", np.s_[:, :, -2:, :]), ("left", np.s_[:, :, :, :2]), ("right", np.s_[:, :, :, -2:])):
+        check("D down fused border " + name, nchw(got)[sl], ref[sl], 8e-3)
+
+
 @pytest.mark.parametrize("impl,M,N,K", [(1, 150, 200, 96), (2, 150, 256, 192), (2, 400, 192, 64), (2, 128, 128, 128)])
 def test_gemm_modes(impl, M, N, K):
     a = rnd(5, "a", (M, K)); w = rnd(5, "w", (N, K), K ** -0.5); bias = rnd(5, "b", (N,), 0.2)

@@ -249,3 +249,29 @@ def test_bench_gpus_flag_becomes_a_launcher():
     assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
     assert tail == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+
+
+@pytest.mark.parametrize("B,R,Cin,Cout", [(1, 64, 32, 64), (1, 128, 32, 64), (1, 64, 64, 128)])
+def test_conv_down_index_emulation(B, R, Cin, Cout):
+    """tests/emu_ops.dblock_down replays conv_down.hip's thread mapping, LDS addressing (swizzles, edge parking, in-place
+    horizontal pass, de-interleaved operand slots) and MFMA fragment layout on the CPU; it must agree with the plain
+    formula of the fused D-block half (modules.py:1204-1254, 1587-1601)."""
+    import math
+    import torch
+    import emu_ops
+    from oracle import stylegan2_ref as sg
+    from util import nchw, nhwc
+    rs = np.random.RandomState(3)
+    h = rs.randn(B, Cin, R, R).astype(np.float32); x = rs.randn(B, Cin, R, R).astype(np.float32)
+    w1 = rs.randn(Cout, Cin, 3, 3).astype(np.float32); ws = rs.randn(Cout, Cin, 1, 1).astype(np.float32)
+    b1 = (0.3 * rs.randn(Cout)).astype(np.float32)
+    r16 = lambda a: torch.tensor(a.astype(np.float16).astype(np.float32))
+    hb = sg._filter(r16(h), sg._fir(), 2, 2)
+    h1 = sg._bias_act(sg._conv(hb, torch.tensor(w1), stride=2), torch.tensor(b1))
+    xs = sg._filter(r16(x), sg._fir(), 1, 1)[:, :, ::2, ::2]
+    ref = ((h1 + sg._conv(xs, torch.tensor(ws))) / math.sqrt(2)).numpy()
+    got = nchw(emu_ops.dblock_down(nhwc(h), nhwc(x), w1, ws, b1))
+    err = np.abs(got - ref)
+    assert err.max() < 8e-3 * np.abs(ref).max(), "max err %.3e at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
+    for sl in (np.s_[:, :, :2, :], np.s_[:, :, -2:, :], np.s_[:, :, :, :2], np.s_[:, :, :, -2:]):
+        assert np.abs(got[sl] - ref[sl]).max() < 8e-3 * np.abs(ref).max()
