@@ -60,7 +60,9 @@ struct ConvParams {
     const float* rgb_y;     // [B][3][H][W] fp32 (nullable: normal input x)
     const float* rgb_w;     // [32][3]
     const float* rgb_b;     // [32]
-    half_t* rgb_x_out;      // [B][H][W][32]: the fromRGB map, written as a side output (skip path input)
+    half_t* rgb_x_out;      // [B][H][W][32]: the fromRGB map, written as a side output (skip path input; nullable)
+    half_t* rgb_xs_out;     // [B][H/2][W/2][32]: FIR (pad 1) + ::2 of the fromRGB map — the D block's skip-branch input, taken
+                            // from the tile already staged in LDS (nullable)
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout

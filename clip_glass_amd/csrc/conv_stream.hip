@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
                         const h8 z = fw0 * h0 + fw1 * h1 + fw2 * h2 + fbv;          // v_pk_fma_f16
                         a = __builtin_elementwise_max(z, z * (half_t)0.2f);
                         const int pr = prc[k] >> 8, pc = prc[k] & 255;
-                        if (ok && pr >= 1 && pr <= TH && pc >= 1 && pc <= 32)      // tile interior: the map itself, for the skip path
+                        if (p.rgb_x_out && ok && pr >= 1 && pr <= TH && pc >= 1 && pc <= 32)      // tile interior: the map itself, for the skip path
                             *(h8*)(p.rgb_x_out + (((long long)b * p.H + ty0 - 1 + pr) * p.W + tx0 - 1 + pc) * 32 + part * 8) = a;
                         if (!ok) a = zero;
                     } else {
@@ -185,6 +185,21 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int t
                     }
                 }
 
+        if (FRGB && p.rgb_xs_out) {
+            // the D block's skip branch wants FIR 4x4 (pad 1) + ::2 of the fromRGB map (modules.py:1238-1254 via 1587-1601): the
+            // 8 x 32 tile (+ halo, zeros outside the image) sits in LDS, so its 4 x 16 down-sampled pixels are 16 reads + 5
+            // packed-fp16 FIRs per thread — and the 64-byte-per-pixel map itself never has to travel to HBM for the skip path
+            const int pix = t >> 2, ly = pix >> 4, lx = pix & 15;
+            h8 hr[4];
+#pragma unroll
+            for (int jy = 0; jy < 4; ++jy) {
+                const char* rowp = As + ((2 * ly + jy) * PW + 2 * lx) * ROWB + part * 16;
+                const h8 a0 = *(const h8*)rowp, a1 = *(const h8*)(rowp + ROWB), a2 = *(const h8*)(rowp + 2 * ROWB), a3 = *(const h8*)(rowp + 3 * ROWB);
+                hr[jy] = (a0 + a3) * (half_t)0.125f + (a1 + a2) * (half_t)0.375f;
+            }
+            const h8 o = (hr[0] + hr[3]) * (half_t)0.125f + (hr[1] + hr[2]) * (half_t)0.375f;
+            *(h8*)(p.rgb_xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + ly) * (p.W >> 1) + (tx0 >> 1) + lx) * 32 + part * 8) = o;
+        }
         // ---- epilogue: lane = pixel lr of tile row (wave*2 + i); quads of 4 consecutive channels -------------
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -239,7 +254,7 @@ const char* launch_conv_stream(const ConvParams& p, hipStream_t st) {
     static const bool off = getenv("GLASS_NO_STREAM") != nullptr;   // experiment knob
     if (off || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return nullptr;
     const bool frgb = p.rgb_y != nullptr;
-    if (frgb && (!p.rgb_w || !p.rgb_b || !p.rgb_x_out || p.sn)) return nullptr;
+    if (frgb && (!p.rgb_w || !p.rgb_b || (!p.rgb_x_out && !p.rgb_xs_out) || p.sn)) return nullptr;
     if (p.Cin != 32 || p.Neff != 32 || p.Cout != 32 || p.res || p.pre_shift || p.res_cs || p.res_up) return nullptr;
     if (frgb && (p.in_up || p.shift)) return nullptr;
     if (p.Wc % 32 != 0 || p.Hc % TH != 0 || p.W >= 256 * 32 || (!frgb && p.x_bstride == 0 && p.B > 1)) return nullptr;

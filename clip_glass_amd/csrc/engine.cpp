@@ -922,17 +922,21 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         p.x = X; p.x_bstride = (long long)r * r * d.cin; p.B = B; p.H = p.W = r; p.Cin = d.cin;
         p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
         p.bias = d.b0; p.act = 1; p.y = Hb;
-        bool fused_rgb = false;
+        bool fused_rgb = false, have_xs = false;
+        const bool fuse_down = conv_down_supported(r, d.cin, d.cout);   // blur + skip + stride-2 conv + merge as one kernel
         if (i == 0 && rgb_y) {
             static const bool no_fuse = getenv("GLASS_NO_FRGB_FUSE") != nullptr;   // A/B knob
             ConvParams q = p;
-            q.rgb_y = rgb_y; q.rgb_w = e->d_frgb_w; q.rgb_b = e->d_frgb_b; q.rgb_x_out = X;
+            q.rgb_y = rgb_y; q.rgb_w = e->d_frgb_w; q.rgb_b = e->d_frgb_b;
+            q.rgb_x_out = fuse_down ? nullptr : X;       // the fused second half reads the down-sampled skip input only
+            q.rgb_xs_out = fuse_down ? XS : nullptr;
             snprintf(tag, sizeof tag, "D.fromrgb+conv0.r%d.%dx%d", r, d.cin, d.cin);
             const double px = (double)B * r * r;
-            Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin), px * (12.0 + 4.0 * d.cin));
+            Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin), px * (12.0 + 2.0 * d.cin + (fuse_down ? 0.5 : 2.0) * d.cin));
             const char* k = no_fuse ? nullptr : launch_conv_stream(q, e->cur);
             if (k) {
                 fused_rgb = true;
+                have_xs = fuse_down;
                 if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
                 if (e->profiling) e->tag_kernel[tag] = k;
             } else {
@@ -942,11 +946,16 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         if (i == 0 && rgb_y && !fused_rgb) run_fromrgb(e, B, rgb_y, X);
         snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
         if (!fused_rgb) run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
-        {   // blur + blur-down + 1x1 skip + stride-2 conv + residual merge as ONE kernel where the block qualifies
+        if (!have_xs) {
+            snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
+            Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);
+            launch_blur_down(X, B, r, r, d.cin, XS, e->cur);
+        }
+        if (fuse_down) {
             snprintf(tag, sizeof tag, "D.down.r%d.%dx%d", r2, d.cin, d.cout);
             const double px2 = (double)B * r2 * r2;
-            Prof pr(e, tag, 2.0 * px2 * (9.0 + 1.0) * d.cin * d.cout, 2.0 * (2.0 * B * (double)r * r * d.cin + px2 * d.cout));
-            const char* k = launch_conv_down(Hb, X, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur);
+            Prof pr(e, tag, 2.0 * px2 * (9.0 + 1.0) * d.cin * d.cout, 2.0 * (B * (double)r * r * d.cin + px2 * (d.cin + d.cout)));
+            const char* k = launch_conv_down(Hb, XS, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur);
             if (k) {
                 if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
                 if (e->profiling) e->tag_kernel[tag] = k;
@@ -959,11 +968,6 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
             snprintf(tag, sizeof tag, "D.blur.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
             launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->cur);
-        }
-        {
-            snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
-            Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);
-            launch_blur_down(X, B, r, r, d.cin, XS, e->cur);
         }
         ConvParams s = conv_defaults();
         s.x = XS; s.x_bstride = (long long)r2 * r2 * d.cin; s.B = B; s.H = s.W = r2; s.Cin = d.cin;

@@ -12,10 +12,12 @@ const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
 const char* launch_conv_stream(const ConvParams& p, hipStream_t st);
 // LDS-DMA staged 3x3 conv for the MFMA-bound mid-resolution layers (conv_glds.hip); nullptr when unsupported / disabled
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force = false);
-// second half of a discriminator block in one kernel (conv_down.hip): y = (lrelu(conv3x3s2(fir_pad2(h)) + b1) * sqrt2 +
-// conv1x1(fir_pad1(x)[::2])) / sqrt2; nullptr when the shape does not qualify (caller runs the separate passes)
-const char* launch_conv_down(const half_t* h, const half_t* x, const half_t* w1, const half_t* ws, const float* b1, half_t* y,
+// second half of the full-resolution discriminator block in one kernel (conv_down.hip):
+//   y = (lrelu(conv3x3 stride 2 (fir_pad2(h)) + b1) * sqrt2 + conv1x1(xs)) / sqrt2, xs = fir_pad1(x)[::2] (32 -> 64 channels);
+// nullptr when the shape does not qualify (caller runs the separate passes)
+const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1, const half_t* ws, const float* b1, half_t* y,
                              int B, int R, int Cin, int Cout, hipStream_t st);
+bool conv_down_supported(int R, int Cin, int Cout);
 // fused transposed-conv + FIR + epilogue (upfir.hip); nullptr when unsupported
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);
 

@@ -201,8 +201,11 @@ extern "C" int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_
     half_t* dws = dv.up16v(pk);
     float* db = dv.up32(b1, Cout);
     const int Ro = R / 2;
+    half_t* dxs = dv.alloc<half_t>((size_t)B * Ro * Ro * Cin);
     half_t* dy = dv.alloc<half_t>((size_t)B * Ro * Ro * Cout);
-    OPREQ(launch_conv_down(dh, dx, dw1, dws, db, dy, B, R, Cin, Cout, 0) != nullptr, "conv_down: unsupported shape");
+    OPREQ(conv_down_supported(R, Cin, Cout), "conv_down: unsupported shape");
+    launch_blur_down(dx, B, R, R, Cin, dxs, 0);          // the skip branch's FIR (pad 1) + ::2 (conv_stream<fromrgb> emits it in the engine)
+    OPREQ(launch_conv_down(dh, dxs, dw1, dws, db, dy, B, R, Cin, Cout, 0) != nullptr, "conv_down: unsupported shape");
     int rc = finish();
     if (rc) return rc;
     return down16(y, dy, (size_t)B * Ro * Ro * Cout);

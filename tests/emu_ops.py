@@ -167,14 +167,13 @@ def noise(n_mb, hw, layer, mb0, generation, seed, device=0):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # conv_down.hip, emulated at the INDEX level: same thread -> window-column mapping, same LDS byte addresses (column
-# rotation / chunk XOR swizzles, edge-column parking, in-place horizontal pass, de-interleaved operand slots), same MFMA
-# fragment addressing and accumulator layout, packed-fp16 FIR arithmetic.  A wrong address term in the kernel's design
-# shows up here, on the CPU.
+# rotation / chunk XOR swizzles, edge-column parking, in-place horizontal pass, de-interleaved operand slots, per-wave
+# output transposition through the wave's private operand row), same MFMA fragment addressing and accumulator layout,
+# packed-fp16 FIR arithmetic.  A wrong address term in the kernel's design shows up here, on the CPU.
 # ---------------------------------------------------------------------------------------------------------------------
 _TH, _NT, _VP = 4, 64, 65
 _V_BYTES = 9 * _VP * 64
 _W_BYTES = 9 * _NT * 64
-_OFF_EX = 5 * _VP * 64
 _OFF_W, _OFF_EM = _V_BYTES, _V_BYTES + _W_BYTES
 _OFF_C = _OFF_EM + 12 * 4 * 64
 _OFF_WS = _OFF_C + _NT * 4
@@ -202,136 +201,110 @@ def _fir4(a, b, c, d):
 
 
 def dblock_down(h, x, w1, wskip, b1, device=0):
-    h = np.asarray(h, np.float32).astype(np.float16); x = np.asarray(x, np.float32).astype(np.float16)
+    h = np.asarray(h, np.float32).astype(np.float16)
+    xs = blur(x, 1).astype(np.float16)                                    # launch_blur_down / conv_stream<fromrgb>'s by-product
     B, R, _, Cin = h.shape
     Cout = w1.shape[0]
-    assert R % 64 == 0 and Cin % 32 == 0 and Cout % _NT == 0
-    pk1 = real_ops.host_pack_conv(w1, False).astype(np.float16)          # [9][Cout][Cin]
-    pks = real_ops.host_pack_conv(wskip, False).astype(np.float16)       # [1][Cout][Cin]
-    Ro, nc = R // 2, Cin // 32
-    tiles_x, tiles_y, NTn = Ro // 32, Ro // _TH, Cout // _NT
+    assert R % 64 == 0 and Cin == 32 and Cout == _NT
+    pk1 = real_ops.host_pack_conv(w1, False).astype(np.float16)          # [9][64][32]
+    pks = real_ops.host_pack_conv(wskip, False).astype(np.float16)       # [1][64][32]
+    Ro = R // 2
+    tiles_x, tiles_y = Ro // 32, Ro // _TH
     out = np.zeros((B, Ro, Ro, Cout), np.float16)
     t = np.arange(256); cg = t & 3; cs = t >> 2
     lane = np.arange(64)
     lds = np.zeros((_OFF_WS + _NT * 64) // 2, np.float16)
 
-    def wr(addr, vals):                     # addr: [n] byte addresses, vals [n, 8]
-        for a, v in zip(np.asarray(addr).ravel(), np.asarray(vals).reshape(-1, 8)):
-            lds[a // 2:a // 2 + 8] = v
+    def wr(addr, vals, n=8):                     # addr: byte addresses, vals [.., n] halfs
+        for a, v in zip(np.asarray(addr).ravel(), np.asarray(vals).reshape(-1, n)):
+            lds[a // 2:a // 2 + n] = v
 
     def rd(addr):
         addr = np.asarray(addr)
         return np.stack([lds[a // 2:a // 2 + 8] for a in addr.ravel()]).reshape(addr.shape + (8,))
 
-    def window(img, b, oy, ox, c, rows, col):
-        """clamped load + zero-padding mask, [len(rows), len(col), 8] for channel group cg of chunk c per thread"""
-        return img, b, oy, ox, c
+    # resident weights: swizzled source chunk, linear destination
+    for k in range(9):
+        v = k * 256 + t; row = v >> 2; lc = (v & 3) ^ ((row >> 2) & 3)
+        wr(_OFF_W + v * 16, np.stack([pk1[row[i] >> 6, row[i] & 63, lc[i] * 8:lc[i] * 8 + 8] for i in range(256)]))
+    row = t >> 2; lc = (t & 3) ^ ((row >> 2) & 3)
+    wr(_OFF_WS + t * 16, np.stack([pks[0, row[i], lc[i] * 8:lc[i] * 8 + 8] for i in range(256)]))
+    lr, kh = lane & 31, lane >> 5
+
+    def frag_to_mat(fr):          # lane l holds M[l & 31][(l >> 5) * 8 + e]
+        m = np.zeros((32, 16), np.float64)
+        m[lr[:, None], (kh * 8)[:, None] + np.arange(8)[None, :]] = fr.astype(np.float64)
+        return m
 
     for b in range(B):
         for tyi in range(tiles_y):
             for txi in range(tiles_x):
-                for nt in range(NTn):
-                    ty0, tx0, n0 = tyi * _TH, txi * 32, nt * _NT
-                    acc = np.zeros((4, 2, 32, 32), np.float64)           # [wave][j][channel][pixel]
-                    sk = None
-                    for kind in (0, 1):
-                        for c in range(nc):
-                            img = h if kind else x
-                            oy, ox = 2 * ty0 - (2 if kind else 1), 2 * tx0 - (2 if kind else 1)
-                            nrow = 12 if kind else 10
+                ty0, tx0 = tyi * _TH, txi * 32
+                oy, ox = 2 * ty0 - 2, 2 * tx0 - 2
 
-                            def load(iy, ix, g):     # per-thread vectors: clamped address, mask applied by the caller
-                                iyc = np.clip(iy, 0, R - 1); ixc = np.clip(ix, 0, R - 1)
-                                return np.stack([img[b, iyc[i], ixc[i], c * 32 + g[i] * 8:c * 32 + g[i] * 8 + 8] for i in range(len(g))])
-                            a = []
-                            colok = (ox + cs >= 0) & (ox + cs < R)
-                            for k in range(nrow):
-                                v = load(np.full(256, oy + k), ox + cs, cg)
-                                ok = colok & (0 <= oy + k < R)
-                                a.append(np.where(ok[:, None], v, np.float16(0)))
-                            if kind:
-                                for r in range(9):
-                                    wr(_vaddr(r, cs, cg), _fir4(a[r], a[r + 1], a[r + 2], a[r + 3]))
-                                te = t[t < 192]
-                                er, ecl = te >> 4, (te >> 2) & 3
-                                v = load(oy + er, ox + 64 + ecl, cg[te])
-                                ok = (oy + er >= 0) & (oy + er < R) & (ox + 64 + ecl >= 0) & (ox + 64 + ecl < R)
-                                wr(_OFF_EM + ((er * 4 + ecl) * 4 + cg[te]) * 16, np.where(ok[:, None], v, np.float16(0)))
-                            else:
-                                for q in range(4):
-                                    wr(_vaddr(q, cs, cg), _fir4(a[2 * q], a[2 * q + 1], a[2 * q + 2], a[2 * q + 3]))
-                                te = t[t < 80]
-                                er, ecl = te >> 3, (te >> 2) & 1
-                                v = load(oy + er, ox + 64 + ecl, cg[te])
-                                ok = (oy + er >= 0) & (oy + er < R) & (ox + 64 + ecl >= 0) & (ox + 64 + ecl < R)
-                                wr(_OFF_EX + ((er * 2 + ecl) * 4 + cg[te]) * 16, np.where(ok[:, None], v, np.float16(0)))
-                            # weights of the stage -> LDS image (swizzled source chunk, linear destination)
-                            if kind:
-                                for k in range(9):
-                                    v = k * 256 + t; row = v >> 2; lc = (v & 3) ^ ((row >> 2) & 3)
-                                    wr(_OFF_W + v * 16, np.stack([pk1[row[i] >> 6, n0 + (row[i] & 63), c * 32 + lc[i] * 8:c * 32 + lc[i] * 8 + 8] for i in range(256)]))
-                            else:
-                                row = t >> 2; lc = (t & 3) ^ ((row >> 2) & 3)
-                                wr(_OFF_W + t * 16, np.stack([pks[0, n0 + row[i], c * 32 + lc[i] * 8:c * 32 + lc[i] * 8 + 8] for i in range(256)]))
-                            # horizontal pass: wave-owned rows, in place
-                            j, cgl = lane >> 2, lane & 3
-                            for wave in range(4):
-                                if kind:
-                                    for ri in range(3):
-                                        rr = wave + 4 * ri
-                                        if rr >= 9:
-                                            continue
-                                        v = [rd(_vaddr(rr, 4 * j + k, cgl)) for k in range(4)]
-                                        for k in range(4, 8):
-                                            main = rd(_vaddr(rr, np.minimum(4 * j + k, 63), cgl)) if k < 7 else np.zeros((64, 8), np.float16)
-                                            e = _OFF_EM + ((rr * 4 + (k - 4)) * 4 + cgl) * 16
-                                            edge = _fir4(rd(e), rd(e + 256), rd(e + 512), rd(e + 768))
-                                            v.append(np.where((j < 15)[:, None], main, edge))
-                                        o = [_fir4(v[i], v[i + 1], v[i + 2], v[i + 3]) for i in range(5)]
-                                        for i in range(4):
-                                            cc = 4 * j + i
-                                            slot = np.where(cc & 1, 33 + (cc >> 1), cc >> 1)
-                                            wr(_aaddr(rr, slot, cgl), o[i])
-                                        m = j == 15
-                                        wr(_aaddr(rr, np.full(64, 32), cgl)[m], o[4][m])
-                                else:
-                                    q = wave
-                                    v = [rd(_vaddr(q, 4 * j + k, cgl)) for k in range(4)]
-                                    for k in range(4, 6):
-                                        main = rd(_vaddr(q, np.minimum(4 * j + k, 63), cgl))
-                                        e = _OFF_EX + ((2 * q * 2 + (k - 4)) * 4 + cgl) * 16
-                                        edge = _fir4(rd(e), rd(e + 128), rd(e + 256), rd(e + 384))
-                                        v.append(np.where((j < 15)[:, None], main, edge))
-                                    o0, o1 = _fir4(v[0], v[1], v[2], v[3]), _fir4(v[2], v[3], v[4], v[5])
-                                    wr(_aaddr(q, 2 * j, cgl), o0)
-                                    wr(_aaddr(q, 2 * j + 1, cgl), o1)
-                            # MFMA: A = weight fragments [32 ch x 16 k], B = pixel fragments [16 k x 32 px]
-                            lr, kh = lane & 31, lane >> 5
-
-                            def frag_to_mat(fr):          # lane l holds M[l & 31][(l >> 5) * 8 + e]
-                                m = np.zeros((32, 16), np.float64)
-                                m[lr[:, None], (kh * 8)[:, None] + np.arange(8)[None, :]] = fr.astype(np.float64)
-                                return m
-                            for wave in range(4):
-                                taps = [(ky, kx) for ky in range(3) for kx in range(3)] if kind else [(0, 0)]
-                                for ky, kx in taps:
-                                    for kk in range(2):
-                                        lc = kk * 2 + kh
-                                        if kind:
-                                            xf = rd(_aaddr(2 * wave + ky, (33 if kx == 1 else (kx >> 1)) + lr, lc))
-                                        else:
-                                            xf = rd(_aaddr(wave, lr, lc))
-                                        Bm = frag_to_mat(xf).T                                    # [16 k][32 px]
-                                        for jj in range(2):
-                                            row = ((ky * 3 + kx) * _NT if kind else 0) + jj * 32 + lr
-                                            Am = frag_to_mat(rd(_OFF_W + _waddr(row, lc)))        # [32 ch][16 k]
-                                            acc[wave, jj] += Am @ Bm
-                            if kind == 0 and c == nc - 1:
-                                sk = acc.astype(np.float32).astype(np.float16).astype(np.float64)
-                                acc[:] = 0
-                    v = acc.astype(np.float32) + np.asarray(b1, np.float32)[n0:n0 + 64].reshape(1, 2, 32, 1)
-                    v = (np.where(v > 0, v, np.float32(0.2) * v) * np.float32(math.sqrt(2))).astype(np.float32) + sk.astype(np.float32)
-                    res = (v * np.float32(0.70710678118654752440)).astype(np.float16)     # [wave][j][ch][px]
-                    for wave in range(4):
-                        out[b, ty0 + wave, tx0:tx0 + 32, n0:n0 + 64] = res[wave].reshape(64, 32).T
+                def load(iy, ix, g):     # per-thread vectors: clamped address, mask applied afterwards
+                    iyc = np.clip(iy, 0, R - 1); ixc = np.clip(ix, 0, R - 1)
+                    return np.stack([h[b, iyc[i], ixc[i], g[i] * 8:g[i] * 8 + 8] for i in range(len(g))])
+                a = []
+                colok = (ox + cs >= 0) & (ox + cs < R)
+                for k in range(12):
+                    v = load(np.full(256, oy + k), ox + cs, cg)
+                    a.append(np.where((colok & (0 <= oy + k < R))[:, None], v, np.float16(0)))
+                for r in range(9):
+                    wr(_vaddr(r, cs, cg), _fir4(a[r], a[r + 1], a[r + 2], a[r + 3]))
+                te = t[t < 192]
+                er, ecl = te >> 4, (te >> 2) & 3
+                v = load(oy + er, ox + 64 + ecl, cg[te])
+                ok = (oy + er >= 0) & (oy + er < R) & (ox + 64 + ecl >= 0) & (ox + 64 + ecl < R)
+                wr(_OFF_EM + ((er * 4 + ecl) * 4 + cg[te]) * 16, np.where(ok[:, None], v, np.float16(0)))
+                # horizontal pass: wave-owned rows, in place
+                j, cgl = lane >> 2, lane & 3
+                for wave in range(4):
+                    for ri in range(3):
+                        rr = wave + 4 * ri
+                        if rr >= 9:
+                            continue
+                        v = [rd(_vaddr(rr, 4 * j + k, cgl)) for k in range(4)]
+                        for k in range(4, 8):
+                            main = rd(_vaddr(rr, np.minimum(4 * j + k, 63), cgl)) if k < 7 else np.zeros((64, 8), np.float16)
+                            e = _OFF_EM + ((rr * 4 + (k - 4)) * 4 + cgl) * 16
+                            edge = _fir4(rd(e), rd(e + 256), rd(e + 512), rd(e + 768))
+                            v.append(np.where((j < 15)[:, None], main, edge))
+                        o = [_fir4(v[i], v[i + 1], v[i + 2], v[i + 3]) for i in range(5)]
+                        for i in range(4):
+                            cc = 4 * j + i
+                            wr(_aaddr(rr, np.where(cc & 1, 33 + (cc >> 1), cc >> 1), cgl), o[i])
+                        m = j == 15
+                        wr(_aaddr(rr, np.full(64, 32), cgl)[m], o[4][m])
+                # MFMA (A = weight fragments [32 ch x 16 k], B = pixel fragments [16 k x 32 px]), epilogue per wave
+                for wave in range(4):
+                    acc = np.zeros((2, 32, 32), np.float64)               # [j][channel][pixel]
+                    for ky in range(3):
+                        for kx in range(3):
+                            for kk in range(2):
+                                lc = kk * 2 + kh
+                                Bm = frag_to_mat(rd(_aaddr(2 * wave + ky, (33 if kx == 1 else (kx >> 1)) + lr, lc))).T
+                                for jj in range(2):
+                                    acc[jj] += frag_to_mat(rd(_OFF_W + _waddr((ky * 3 + kx) * _NT + jj * 32 + lr, lc))) @ Bm
+                    v = acc.astype(np.float32) + np.asarray(b1, np.float32).reshape(2, 32, 1)
+                    v = (np.where(v > 0, v, np.float32(0.2) * v) * np.float32(math.sqrt(2))).astype(np.float64)
+                    for kk in range(2):
+                        xf = np.stack([xs[b, ty0 + wave, tx0 + lr[i], kk * 16 + kh[i] * 8:kk * 16 + kh[i] * 8 + 8] for i in range(64)])
+                        Bm = frag_to_mat(xf).T
+                        for jj in range(2):
+                            v[jj] += frag_to_mat(rd(_OFF_WS + _waddr(jj * 32 + lr, kk * 2 + kh))) @ Bm
+                    res = (v.astype(np.float32) * np.float32(0.70710678118654752440)).astype(np.float16)    # [j][ch][px]
+                    # transposition through operand-image row 2 * wave + 1: lane (pixel lr, half kh) writes quads of 4 channels
+                    base = (2 * wave + 1) * (_VP * 64)
+                    for jj in range(2):
+                        for g in range(4):
+                            ch = jj * 32 + 8 * g + 4 * kh                                  # first of 4 consecutive channels, per lane
+                            quad = np.stack([res[jj, 8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)])
+                            wr(base + lr * 128 + (((jj * 4 + g) ^ (lr & 7)) << 4) + kh * 8, quad, n=4)
+                    for k in range(4):
+                        vv = lane + 64 * k
+                        pix, chv = vv >> 3, vv & 7
+                        data = rd(base + pix * 128 + ((chv ^ (pix & 7)) << 4))
+                        for i in range(64):
+                            out[b, ty0 + wave, tx0 + pix[i], chv[i] * 8:chv[i] * 8 + 8] = data[i]
     return out.astype(np.float32)

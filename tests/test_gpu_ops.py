@@ -170,14 +170,14 @@ def test_d_block_pieces(impl, H, Cin, Cout):
 
 
 @pytest.mark.parametrize("B,R,Cin,Cout", [
-    (2, 64, 32, 64),      # resident-weight instance (Cin 32, one n tile): the 1024^2 block's kernel, one tile column
-    (1, 128, 32, 64),     # two tile columns: interior window columns on both sides, edge columns inside the image
-    (3, 64, 64, 128),     # streamed weights: two chunks, two n tiles, odd item count per workgroup
-    (1, 64, 96, 64),      # three chunks
+    (2, 64, 32, 64),      # one tile column: both image borders in every window; one tile per workgroup (padded second step)
+    (1, 128, 32, 64),     # two tile columns: edge columns inside the image on the left tile
+    (3, 192, 32, 64),     # 3 x 3 x 24 tiles: interior tiles (no padding mask), odd counts
+    (20, 256, 32, 64),    # 2560 tiles: five tiles per persistent workgroup (odd: padded step), windows refilled two tiles ahead
 ])
 def test_d_block_down_fused(B, R, Cin, Cout):
-    """conv_down.hip: FIR pad 2 -> conv3x3 stride 2 + bias + lrelu*sqrt2, FIR pad 1 -> ::2 -> conv1x1 skip, (a + b)/sqrt2 in one
-    kernel (modules.py:1204-1254, 1587-1601) vs the oracle's ops on the same fp16-rounded inputs."""
+    """conv_down.hip (+ launch_blur_down for the skip input): FIR pad 2 -> conv3x3 stride 2 + bias + lrelu*sqrt2, FIR pad 1 -> ::2
+    -> conv1x1 skip, (a + b)/sqrt2 (modules.py:1204-1254, 1587-1601) vs the oracle's ops on the same fp16-rounded inputs."""
     h = rnd(14, "h", (B, Cin, R, R)); x = rnd(14, "x", (B, Cin, R, R))
     w1 = rnd(14, "w1", (Cout, Cin, 3, 3)); b1 = rnd(14, "b1", (Cout,), 0.3); ws = rnd(14, "ws", (Cout, Cin, 1, 1))
     ht, xt = torch.tensor(h16(h)), torch.tensor(h16(x))
