@@ -175,7 +175,7 @@ _TH, _NT, _VP = 4, 64, 65
 _V_BYTES = 9 * _VP * 64
 _W_BYTES = 9 * _NT * 64
 _OFF_W, _OFF_EM = _V_BYTES, _V_BYTES + _W_BYTES
-_OFF_C = _OFF_EM + 12 * 4 * 64
+_OFF_C = _OFF_EM + 9 * 4 * 64
 _OFF_WS = _OFF_C + _NT * 4
 
 
@@ -228,6 +228,7 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
         v = k * 256 + t; row = v >> 2; lc = (v & 3) ^ ((row >> 2) & 3)
         wr(_OFF_W + v * 16, np.stack([pk1[row[i] >> 6, row[i] & 63, lc[i] * 8:lc[i] * 8 + 8] for i in range(256)]))
     row = t >> 2; lc = (t & 3) ^ ((row >> 2) & 3)
+    pks = (pks.astype(np.float32) * np.float32(0.70710678118654752440)).astype(np.float16)    # the skip rows carry the merge's 1/sqrt2
     wr(_OFF_WS + t * 16, np.stack([pks[0, row[i], lc[i] * 8:lc[i] * 8 + 8] for i in range(256)]))
     lr, kh = lane & 31, lane >> 5
 
@@ -252,11 +253,14 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
                     a.append(np.where((colok & (0 <= oy + k < R))[:, None], v, np.float16(0)))
                 for r in range(9):
                     wr(_vaddr(r, cs, cg), _fir4(a[r], a[r + 1], a[r + 2], a[r + 3]))
-                te = t[t < 192]
+                te = t[t < 144]                           # thread (row r, edge column, cg) holds raw rows r .. r + 3 of an edge column
                 er, ecl = te >> 4, (te >> 2) & 3
-                v = load(oy + er, ox + 64 + ecl, cg[te])
-                ok = (oy + er >= 0) & (oy + er < R) & (ox + 64 + ecl >= 0) & (ox + 64 + ecl < R)
-                wr(_OFF_EM + ((er * 4 + ecl) * 4 + cg[te]) * 16, np.where(ok[:, None], v, np.float16(0)))
+                ecok = (ox + 64 + ecl >= 0) & (ox + 64 + ecl < R)
+                e4 = []
+                for k in range(4):
+                    v = load(oy + er + k, ox + 64 + ecl, cg[te])
+                    e4.append(np.where((ecok & (oy + er + k >= 0) & (oy + er + k < R))[:, None], v, np.float16(0)))
+                wr(_OFF_EM + te * 16, _fir4(*e4))
                 # horizontal pass: wave-owned rows, in place
                 j, cgl = lane >> 2, lane & 3
                 for wave in range(4):
@@ -267,8 +271,7 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
                         v = [rd(_vaddr(rr, 4 * j + k, cgl)) for k in range(4)]
                         for k in range(4, 8):
                             main = rd(_vaddr(rr, np.minimum(4 * j + k, 63), cgl)) if k < 7 else np.zeros((64, 8), np.float16)
-                            e = _OFF_EM + ((rr * 4 + (k - 4)) * 4 + cgl) * 16
-                            edge = _fir4(rd(e), rd(e + 256), rd(e + 512), rd(e + 768))
+                            edge = rd(_OFF_EM + ((rr * 4 + (k - 4)) * 4 + cgl) * 16)
                             v.append(np.where((j < 15)[:, None], main, edge))
                         o = [_fir4(v[i], v[i + 1], v[i + 2], v[i + 3]) for i in range(5)]
                         for i in range(4):
@@ -287,13 +290,13 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
                                 for jj in range(2):
                                     acc[jj] += frag_to_mat(rd(_OFF_W + _waddr((ky * 3 + kx) * _NT + jj * 32 + lr, lc))) @ Bm
                     v = acc.astype(np.float32) + np.asarray(b1, np.float32).reshape(2, 32, 1)
-                    v = (np.where(v > 0, v, np.float32(0.2) * v) * np.float32(math.sqrt(2))).astype(np.float64)
+                    v = np.maximum(v, np.float32(0.2) * v).astype(np.float64)
                     for kk in range(2):
                         xf = np.stack([xs[b, ty0 + wave, tx0 + lr[i], kk * 16 + kh[i] * 8:kk * 16 + kh[i] * 8 + 8] for i in range(64)])
                         Bm = frag_to_mat(xf).T
                         for jj in range(2):
                             v[jj] += frag_to_mat(rd(_OFF_WS + _waddr(jj * 32 + lr, kk * 2 + kh))) @ Bm
-                    res = (v.astype(np.float32) * np.float32(0.70710678118654752440)).astype(np.float16)    # [j][ch][px]
+                    res = v.astype(np.float32).astype(np.float16)    # [j][ch][px]
                     # transposition through operand-image row 2 * wave + 1: lane (pixel lr, half kh) writes quads of 4 channels
                     base = (2 * wave + 1) * (_VP * 64)
                     for jj in range(2):
