@@ -133,7 +133,7 @@ def test_conv_modulated_demod_noise(impl):
     check("modconv impl%d" % impl, nchw(got), ref, 5e-3)
 
 
-@pytest.mark.parametrize("impl", [1, 2, (3, 32, 32, 32), (3, 16, 64, 32), (3, 64, 32, 64), (3, 40, 32, 96)])
+@pytest.mark.parametrize("impl", [1, 2, (3, 32, 32, 32), (3, 16, 64, 32), (3, 64, 32, 64), (3, 40, 32, 96), (3, 128, 64, 32), (3, 16, 128, 128)])
 def test_conv_modulated_up(impl):
     got, ref = _modconv_case(True, impl)
     check("modconv-up impl%s" % (impl,), nchw(got), ref, 5e-3)
