@@ -58,6 +58,65 @@ def cpu_baseline(sd, cfg, target):
                        "the same workload, torch intra-op threads = cores, best of <=2 calls, %.2f s" % best)
 
 
+def bench_gpt2(args):
+    """BASELINE.json configs[4] (not the headline): GPT-2-small token-latent decode (20 latent + 3 prompt tokens, 30 greedy
+    steps, gpt2/sample.py:21-36) + CLIP text tower + cosine against an image feature, pop = 64, 1 GPU.  The host BPE
+    round trip between the two towers (detokenise / re-tokenise) needs the reference's vocabulary files, which are not on
+    the box: the decoded ids are mapped to CLIP ids by a fixed rule instead — same device work, said so in `config`."""
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    from clip_glass_amd import synth
+    from clip_glass_amd.engine import Engine, device_info
+    P = args.pop
+    clipg = (768, 12, 12, 32, 224, 512)
+    sd = synth.make_state(synth.gpt2_spec(), 5)
+    sd.update(synth.make_state(synth.clip_visual_spec(*[clipg[i] for i in (0, 1, 3, 4, 5)]), 0))
+    sd.update(synth.make_state(synth.clip_text_spec(), 0))
+    sd.pop("clip.logit_scale", None)
+    eng = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1, max_pop=P, clip=clipg, noise_mode=0)
+    eng.load_state(sd)
+    eng.finalize()
+    target = synth.normal(3, "imgfeat", (512,)).astype(np.float64)
+
+    def step(seed):
+        z = np.random.RandomState(seed).randint(0, 50257, size=(P, 20))
+        ctx = np.concatenate([z, np.tile([1169, 4286, 286], (P, 1))], axis=1)           # "the picture of" (config.py:25)
+        out = eng.gpt2_decode(ctx, 30)
+        dec_ms = eng.last_gpu_ms()
+        tok = np.zeros((P, 77), np.int64)
+        tok[:, 0] = 49406
+        tok[:, 1:31] = out[:, 23:] % 49406
+        tok[:, 31] = 49407
+        tf = eng.encode_text(tok).astype(np.float64)
+        sim = tf @ target / np.maximum(np.linalg.norm(tf, axis=1) * np.linalg.norm(target), 1e-8)
+        return -sim, dec_ms
+    for s in range(max(args.warmup, 1)):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec_ms = 0.0
+    for s in range(args.steps):
+        F, ms = step(100 + s)
+        dec_ms += ms
+    dt = time.perf_counter() - t0
+    assert F.shape == (P,) and np.isfinite(F).all()
+    # decode = weight streaming: every fp32 weight of the 12 blocks + the tied lm_head is read once per step
+    n_w = 12 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 50257 * 768
+    bytes_per_decode = 4.0 * n_w * 30
+    gbs = bytes_per_decode * args.steps / (dec_ms * 1e-3) / 1e9
+    out = dict(metric="candidate token-latents scored/sec (GPT2 decode -> CLIP text score), GPT2 pop=%d" % P, value=P * args.steps / dt,
+               unit="candidates/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="GPT2: GPT-2-small greedy decode (23-token context, 30 steps, fp32, KV cache, one hipGraph per single-"
+                                    "token step) + CLIP ViT-B/32 text tower + cosine, pop=%d; host BPE round trip replaced by a fixed id "
+                                    "mapping (no vocabulary files on the box)" % P, pop_per_gpu=P, device=device_info(0)["name"]),
+               roofline=dict(bound="hbm", kernel="gemm_f32_kernel<64,64> (weight streaming, 30 steps)", achieved=gbs, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None, decode_ms_per_population=dec_ms / args.steps,
+                             algorithmic_bytes_per_decode=bytes_per_decode))
+    print(json.dumps(out))
+    eng.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +142,9 @@ def main():
             print(json.dumps(cmd))
             sys.exit(0)
         sys.exit(subprocess.call(cmd))
+
+    if args.config == "gpt2":
+        return bench_gpt2(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

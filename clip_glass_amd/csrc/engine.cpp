@@ -172,11 +172,13 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     return GLASS_OK;
 }
 
+static void gpt2_work_free(glass_engine* e);
 extern "C" void glass_engine_destroy(glass_engine* e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_d) hipStreamSynchronize(e->stream_d);
+    gpt2_work_free(e);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -1322,6 +1324,15 @@ extern "C" int glass_engine_encode_image(glass_engine* e, const float* images, i
     return GLASS_OK;
 }
 
+static void gpt2_work_free(glass_engine* e) {
+    auto& w = e->gwork;
+    if (w.exec) hipGraphExecDestroy(w.exec);
+    if (w.graph) hipGraphDestroy(w.graph);
+    hipFree(w.d_tok); hipFree(w.d_gen); hipFree(w.d_state); hipFree(w.x); hipFree(w.ln); hipFree(w.qkv); hipFree(w.att); hipFree(w.hid);
+    hipFree(w.last); hipFree(w.logits); hipFree(w.kc); hipFree(w.vc); hipFree(w.part);
+    w = glass_engine::Gpt2Work();
+}
+
 extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context, int32_t P, int32_t nctx, int32_t length,
                                         int32_t* out_tokens) {
     REQUIRE(e && context && out_tokens && P > 0 && nctx > 0 && length > 0, GLASS_ERR_ARG, "bad argument");
@@ -1334,66 +1345,102 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
     GLASS_HIP(hipSetDevice(e->cfg.device));
     const int nl = (int)e->gblk.size();
     const size_t rows = (size_t)P * nctx;
-    int *d_tok = nullptr, *d_next = nullptr;
-    float *x = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *last = nullptr, *logits = nullptr, *kc = nullptr,
-          *vc = nullptr;
-    auto cleanup = [&]() {
-        hipFree(d_tok); hipFree(d_next); hipFree(x); hipFree(ln); hipFree(qkv); hipFree(att); hipFree(hid); hipFree(last);
-        hipFree(logits); hipFree(kc); hipFree(vc);
-    };
-    hipError_t err = hipMalloc(&d_tok, rows * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&d_next, (size_t)P * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&x, rows * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&ln, rows * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&qkv, rows * 3 * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&att, rows * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&hid, rows * 4 * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&last, (size_t)P * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&logits, (size_t)P * V * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&kc, (size_t)nl * P * Tmax * D * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&vc, (size_t)nl * P * Tmax * D * sizeof(float));
-    if (err != hipSuccess) {
-        cleanup();
-        glass_set_error(std::string("gpt2_decode: hipMalloc failed: ") + hipGetErrorString(err));
-        return GLASS_ERR_NOMEM;
-    }
+    auto& w = e->gwork;
     hipStream_t st = e->stream;
-    std::vector<int32_t> gen((size_t)P * length);
-    hipMemcpyAsync(d_tok, context, rows * sizeof(int), hipMemcpyHostToDevice, st);
-    int nd = nctx, past = 0;
-    for (int step = 0; step < length; ++step) {
+    if (w.P != P || w.nctx != nctx || w.length != length) {      // (re)build the workspace for this geometry
+        gpt2_work_free(e);
+        // split-K scratch for the single-token steps (M = P <= 64 rows: each weight is streamed once per step, so the number
+        // of workgroups pulling on HBM is what matters), device-resident tokens and step state {past length, step index}
+        w.part_elems = (size_t)16 * P * 4 * D;
+        hipError_t err = hipMalloc(&w.d_tok, rows * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&w.d_gen, (size_t)P * length * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&w.d_state, 2 * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&w.x, rows * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.ln, rows * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.qkv, rows * 3 * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.att, rows * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.hid, rows * 4 * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.last, (size_t)P * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.logits, (size_t)P * V * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.kc, (size_t)nl * P * Tmax * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.vc, (size_t)nl * P * Tmax * D * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.part, w.part_elems * sizeof(float));
+        if (err != hipSuccess) {
+            gpt2_work_free(e);
+            glass_set_error(std::string("gpt2_decode: hipMalloc failed: ") + hipGetErrorString(err));
+            return GLASS_ERR_NOMEM;
+        }
+        w.P = P; w.nctx = nctx; w.length = length;
+    }
+    // one transformer pass over `nd` new positions per sequence; step_state != nullptr: single-token step whose past length /
+    // step index are read from device memory (the form that is captured into a hipGraph and replayed)
+    auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
-        launch_gpt2_embed(step == 0 ? d_tok : d_next, e->g_wte, e->g_wpe, M, nd, past, D, x, st);
+        if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st);
+        else launch_gpt2_embed(w.d_tok, e->g_wte, e->g_wpe, M, nd, past, D, w.x, st);
         for (int l = 0; l < nl; ++l) {
             const auto& b = e->gblk[l];
-            float* kcl = kc + (size_t)l * P * Tmax * D;
-            float* vcl = vc + (size_t)l * P * Tmax * D;
-            launch_layernorm(x, D, M, D, b.ln1_g, b.ln1_b, nullptr, ln, st);
-            launch_gemm_f32(ln, b.w_qkv, b.b_qkv, qkv, M, 3 * D, D, D, 3 * D, 0, st);
-            launch_gpt2_attention(qkv, kcl, vcl, P, nd, past, Tmax, heads, att, st);
-            launch_gemm_f32(att, b.w_o, b.b_o, x, M, D, D, D, D, 2, st);
-            launch_layernorm(x, D, M, D, b.ln2_g, b.ln2_b, nullptr, ln, st);
-            launch_gemm_f32(ln, b.w_fc, b.b_fc, hid, M, 4 * D, D, D, 4 * D, 1, st);
-            launch_gemm_f32(hid, b.w_pr, b.b_pr, x, M, D, 4 * D, 4 * D, D, 2, st);
+            float* kcl = w.kc + (size_t)l * P * Tmax * D;
+            float* vcl = w.vc + (size_t)l * P * Tmax * D;
+            launch_layernorm(w.x, D, M, D, b.ln1_g, b.ln1_b, nullptr, w.ln, st);
+            launch_gemm_f32(w.ln, b.w_qkv, b.b_qkv, w.qkv, M, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems);
+            launch_gpt2_attention(w.qkv, kcl, vcl, P, nd, past, Tmax, heads, w.att, st, step_state);
+            launch_gemm_f32(w.att, b.w_o, b.b_o, w.x, M, D, D, D, D, 2, st, w.part, w.part_elems);
+            launch_layernorm(w.x, D, M, D, b.ln2_g, b.ln2_b, nullptr, w.ln, st);
+            launch_gemm_f32(w.ln, b.w_fc, b.b_fc, w.hid, M, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems);
+            launch_gemm_f32(w.hid, b.w_pr, b.b_pr, w.x, M, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems);
         }
-        // ln_f on the last position of each sequence, tied lm_head, greedy pick
-        launch_layernorm(x + (size_t)(nd - 1) * D, (long long)nd * D, P, D, e->g_lnf_g, e->g_lnf_b, nullptr, last, st);
-        launch_gemm_f32(last, e->g_wte, nullptr, logits, P, V, D, D, V, 0, st);
-        launch_argmax(logits, P, V, d_next, st);
-        hipMemcpyAsync(gen.data() + (size_t)step * P, d_next, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, st);
-        past += nd;
-        nd = 1;
+        // ln_f on the last position of each sequence, tied lm_head, greedy pick -> d_gen[step][P]
+        launch_layernorm(w.x + (size_t)(nd - 1) * D, (long long)nd * D, P, D, e->g_lnf_g, e->g_lnf_b, nullptr, w.last, st);
+        launch_gemm_f32(w.last, e->g_wte, nullptr, w.logits, P, V, D, D, V, 0, st, w.part, w.part_elems);
+        launch_argmax(w.logits, P, V, w.d_gen, st, w.d_state);
+        launch_gpt2_advance(w.d_state, st);
+    };
+    std::vector<int32_t> gen((size_t)P * length);
+    GLASS_HIP(hipEventRecord(e->ev0, st));
+    hipMemcpyAsync(w.d_tok, context, rows * sizeof(int), hipMemcpyHostToDevice, st);
+    const int state0[2] = {0, 0}, state1[2] = {nctx, 1};
+    hipMemcpyAsync(w.d_state, state0, sizeof state0, hipMemcpyHostToDevice, st);
+    pass(nctx, 0, nullptr);                                 // prefill = step 0 (writes d_gen[0 .. P))
+    hipMemcpyAsync(w.d_state, state1, sizeof state1, hipMemcpyHostToDevice, st);
+    hipError_t err = hipSuccess;
+    if (length > 1) {
+        // the 29 single-token steps are the same ~190 launches each: capture one step once, replay it (launch latency, not work,
+        // is what the un-graphed loop spent its time on)
+        static const bool no_graph = getenv("GLASS_GPT2_NO_GRAPH") != nullptr;   // A/B knob
+        if (!w.exec && !no_graph) {
+            err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (err == hipSuccess) {
+                pass(1, 0, w.d_state);
+                err = hipStreamEndCapture(st, &w.graph);
+                if (err == hipSuccess) err = hipGraphInstantiate(&w.exec, w.graph, nullptr, nullptr, 0);
+            }
+            if (err != hipSuccess) {       // capture unavailable: eager steps (same kernels, same device-side state)
+                (void)hipGetLastError();
+                if (w.exec) { hipGraphExecDestroy(w.exec); w.exec = nullptr; }
+                if (w.graph) { hipGraphDestroy(w.graph); w.graph = nullptr; }
+                err = hipSuccess;
+            }
+        }
+        for (int step = 1; step < length && err == hipSuccess; ++step) {
+            if (w.exec) err = hipGraphLaunch(w.exec, st);
+            else pass(1, 0, w.d_state);
+        }
     }
-    err = hipStreamSynchronize(st);
+    if (err == hipSuccess) err = hipEventRecord(e->ev1, st);
+    if (err == hipSuccess) err = hipMemcpyAsync(gen.data(), w.d_gen, (size_t)P * length * sizeof(int), hipMemcpyDeviceToHost, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err == hipSuccess) err = hipGetLastError();
-    cleanup();
     if (err != hipSuccess) {
+        gpt2_work_free(e);
         glass_set_error(std::string("gpt2_decode failed: ") + hipGetErrorString(err));
         return GLASS_ERR_HIP;
     }
+    (void)hipEventElapsedTime(&w.last_ms, e->ev0, e->ev1);
+    e->last_ms = w.last_ms;
     for (int p = 0; p < P; ++p) {
         for (int t = 0; t < nctx; ++t) out_tokens[(size_t)p * Tmax + t] = context[(size_t)p * nctx + t];
-        for (int s = 0; s < length; ++s) out_tokens[(size_t)p * Tmax + nctx + s] = gen[(size_t)s * P + p];
+        for (int s2 = 0; s2 < length; ++s2) out_tokens[(size_t)p * Tmax + nctx + s2] = gen[(size_t)s2 * P + p];
     }
     return GLASS_OK;
 }

@@ -134,6 +134,17 @@ struct glass_engine {
     std::vector<Gpt2Block> gblk;
     float *g_wte = nullptr, *g_wpe = nullptr, *g_lnf_g = nullptr, *g_lnf_b = nullptr;
     int g_vocab = 0, g_dim = 0, g_npos = 0;
+    // decode workspace, kept between calls (one geometry at a time): buffers + the captured single-token step
+    struct Gpt2Work {
+        int P = 0, nctx = 0, length = 0;
+        int *d_tok = nullptr, *d_gen = nullptr, *d_state = nullptr;
+        float *x = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *last = nullptr, *logits = nullptr,
+              *kc = nullptr, *vc = nullptr, *part = nullptr;
+        size_t part_elems = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        float last_ms = 0.f;      // device time of the last decode (hipEvents around the passes)
+    } gwork;
     // text tower (optional)
     std::vector<ClipBlock> tblk;
     float *t_tok = nullptr, *t_pos = nullptr, *t_lnf_g = nullptr, *t_lnf_b = nullptr, *t_proj = nullptr;

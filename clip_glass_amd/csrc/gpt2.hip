@@ -18,6 +18,24 @@ __global__ void gpt2_embed_kernel(const int* tok, const float* wte, const float*
     const float* pe = wpe + (long long)(pos0 + row % L) * D;
     for (int i = threadIdx.x; i < D; i += blockDim.x) x[(long long)row * D + i] = te[i] + pe[i];
 }
+// single-token decode step inside a hipGraph: the step's state lives in device memory (state[0] = past length, state[1] = step
+// index), so ONE captured graph serves every step.  Tokens of the previous step are read from gen[(step - 1) * P + row].
+__global__ void gpt2_embed_step_kernel(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x) {
+    const int row = blockIdx.x;
+    const int past = state[0], step = state[1];
+    const float* te = wte + (long long)gen[(long long)(step - 1) * P + row] * D;
+    const float* pe = wpe + (long long)past * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) x[(long long)row * D + i] = te[i] + pe[i];
+}
+void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(gpt2_embed_step_kernel, dim3(P), dim3(128), 0, st, gen, state, P, wte, wpe, D, x);
+}
+__global__ void gpt2_advance_kernel(int* state) {
+    state[0] += 1;
+    state[1] += 1;
+}
+void launch_gpt2_advance(int* state, hipStream_t st) { hipLaunchKernelGGL(gpt2_advance_kernel, dim3(1), dim3(1), 0, st, state); }
+
 void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
                        hipStream_t st) {
     hipLaunchKernelGGL(gpt2_embed_kernel, dim3(rows), dim3(128), 0, st, tok, wte, wpe, L, pos0, D, x);
@@ -30,9 +48,11 @@ void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int r
 // BM x BN block tile, 4 waves as 2 x 2, each wave (BM/2) x (BN/2) = TI x TJ tiles of 32 x 32.
 // <128,128> for the prefill (M = P * 23), <64,64> for the single-token decode steps (M = P): more, smaller
 // blocks — those GEMMs stream the weights once and are latency/launch-bound, not flop-bound.
+// blockIdx.z = K slice (split-K): with more than one slice the block writes its raw partial sums to part[z][M][N]
+// (mode / bias are applied by splitk_reduce_kernel, which adds the slices in a fixed order: deterministic).
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* A, const float* W, const float* bias, float* out,
-                                                       int M, int N, int K, int lda, int ldo, int mode) {
+                                                       int M, int N, int K, int lda, int ldo, int mode, float* part) {
     constexpr int TI = BM / 64, TJ = BN / 64;
     __shared__ float As[BM][F32_LD];
     __shared__ float Ws[BN][F32_LD];
@@ -47,18 +67,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* A, const flo
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += F32_BK) {
+    const int kc = gridDim.z > 1 ? ((K / F32_BK + gridDim.z - 1) / gridDim.z) * F32_BK : K;    // K slice of this block
+    const int k_lo = blockIdx.z * kc, k_hi = min(K, k_lo + kc);
+    for (int k0 = k_lo; k0 < k_hi; k0 += F32_BK) {
         for (int e = t; e < BM * 8; e += 256) {   // stage BM x 32 of A (coalesced along k), zero-filled outside
             const int row = e >> 3, c4 = (e & 7) * 4;
             f4 va = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < M && k0 + c4 < K) va = *(const f4*)(A + (long long)(m0 + row) * lda + k0 + c4);
+            if (m0 + row < M && k0 + c4 < k_hi) va = *(const f4*)(A + (long long)(m0 + row) * lda + k0 + c4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) As[row][c4 + j] = va[j];
         }
         for (int e = t; e < BN * 8; e += 256) {
             const int row = e >> 3, c4 = (e & 7) * 4;
             f4 vw = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + row < N && k0 + c4 < K) vw = *(const f4*)(W + (long long)(n0 + row) * K + k0 + c4);
+            if (n0 + row < N && k0 + c4 < k_hi) vw = *(const f4*)(W + (long long)(n0 + row) * K + k0 + c4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) Ws[row][c4 + j] = vw[j];
         }
@@ -88,6 +110,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* A, const flo
             for (int reg = 0; reg < 16; ++reg) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + mfma32_row(reg, lane);
                 if (n >= N) continue;
+                if (gridDim.z > 1) {
+                    part[((long long)blockIdx.z * M + m) * N + n] = acc[i][j][reg];
+                    continue;
+                }
                 float v = acc[i][j][reg] + (bias ? bias[n] : 0.f);
                 const long long oi = (long long)m * ldo + n;
                 if (mode == 1) {
@@ -101,23 +127,53 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* A, const flo
         }
     }
 }
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, int S, const float* bias, float* out, int M, int N,
+                                                            int ldo, int mode) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)M * N) return;
+    const int m = (int)(e / N), n = (int)(e - (long long)m * N);
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += part[((long long)z * M + m) * N + n];     // fixed order
+    v += bias ? bias[n] : 0.f;
+    const long long oi = (long long)m * ldo + n;
+    if (mode == 1) {
+        const float c = 0.7978845608028654f;  // sqrt(2/pi)
+        v = 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
+    } else if (mode == 2) {
+        v += out[oi];
+    }
+    out[oi] = v;
+}
+// `part`: scratch for split-K partial sums (nullable = never split); sized by the caller for GPT2_SPLITK_MAX slices of M x N.
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
-                     int mode, hipStream_t st) {
+                     int mode, hipStream_t st, float* part, size_t part_elems) {
     if (M <= 64) {
-        dim3 g((M + 63) / 64, (N + 63) / 64);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode);
+        // single-token steps stream each weight once: what matters is how many workgroups pull on HBM.  N / 64 column tiles
+        // alone are 12 workgroups at N = 768: split K until ~256 workgroups are live.
+        const int tiles = (N + 63) / 64;
+        int S = 1;
+        if (part) {
+            while (tiles * S < 192 && S < 16 && K / (2 * S) >= 2 * F32_BK && (size_t)(2 * S) * M * N <= part_elems) S *= 2;
+        }
+        dim3 g((M + 63) / 64, tiles, S);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
+        if (S > 1)
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out,
+                               M, N, ldo, mode);
     } else {
-        dim3 g((M + 127) / 128, (N + 127) / 128);
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode);
+        dim3 g((M + 127) / 128, (N + 127) / 128, 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
     }
 }
 
 // ---- attention with KV cache (model.py:59-95): one workgroup per (sequence, head) -----------------------
 // qkv: [P*nd][3*D] for the nd new positions past..past+nd-1; kc/vc: caches [P][Tmax][D] (this call appends).
 // w = q.k / sqrt(64); masked (key j > past + i) -> -1e10; softmax; a = w @ v.
+// past_dev != nullptr: the past length is read from device memory (graph replay), `past` is ignored.
 __global__ __launch_bounds__(256) void gpt2_attention_kernel(const float* qkv, float* kc, float* vc, int nd, int past,
-                                                             int Tmax, int heads, float* out) {
+                                                             int Tmax, int heads, float* out, const int* past_dev) {
     extern __shared__ float sm[];
+    if (past_dev) past = *past_dev;
     const int hd = 64, D = heads * hd;
     const int seq = blockIdx.x / heads, h = blockIdx.x % heads;
     const int ns = past + nd;
@@ -174,20 +230,21 @@ __global__ __launch_bounds__(256) void gpt2_attention_kernel(const float* qkv, f
     }
 }
 void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd, int past, int Tmax, int heads,
-                           float* out, hipStream_t st) {
-    const int ns = past + nd;
+                           float* out, hipStream_t st, const int* past_dev) {
+    const int ns = past_dev ? Tmax : past + nd;      // graph replay: LDS sized for the longest history
     const size_t lds = (size_t)(nd * 65 + 2 * ns * 65 + nd * (ns + 1)) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gpt2_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(gpt2_attention_kernel, dim3(P * heads), dim3(256), lds, st, qkv, kc, vc, nd, past, Tmax, heads, out);
+    hipLaunchKernelGGL(gpt2_attention_kernel, dim3(P * heads), dim3(256), lds, st, qkv, kc, vc, nd, past, Tmax, heads, out, past_dev);
 }
 
 // ---- greedy pick (sample.py:28-34 with sample=False): arg-max of softmax(top_k(logits / T)) == arg-max of the
 // logits, lowest index on exact ties (torch.topk returns the first maximum) ------------------------------------
-__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N, int* out) {
+// step_dev != nullptr: row r's pick goes to out[step * gridDim.x + r] with step = step_dev[1] (graph replay)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N, int* out, const int* step_dev) {
     __shared__ float bv[256];
     __shared__ int bi[256];
     const float* r = logits + (long long)blockIdx.x * N;
@@ -208,8 +265,8 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N,
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = bi[0];
+    if (threadIdx.x == 0) out[(step_dev ? (long long)step_dev[1] * gridDim.x : 0) + blockIdx.x] = bi[0];
 }
-void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, logits, N, out);
+void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, logits, N, out, step_dev);
 }

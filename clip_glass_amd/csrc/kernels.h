@@ -88,10 +88,14 @@ void launch_bg_rgb_tanh(const half_t* x, int B, long long hw, int C, float* y, h
 // --- GPT-2 (fp32, gpt2.hip) ----------------------------------------------------------
 void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
                        hipStream_t st);
+// part / part_elems: split-K scratch for the single-token (M <= 64) steps (nullptr = never split)
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
-                     int mode, hipStream_t st);
+                     int mode, hipStream_t st, float* part = nullptr, size_t part_elems = 0);
+// past_dev / step_dev: device-resident step state {past length, step index} for the captured single-token step
 void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd, int past, int Tmax, int heads,
-                           float* out, hipStream_t st);
-void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st);
+                           float* out, hipStream_t st, const int* past_dev = nullptr);
+void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr);
+void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st);
+void launch_gpt2_advance(int* state, hipStream_t st);
 // NCHW fp32 image [n][3][S][S] -> CLIP patch matrix [n*G*G][3*ps*ps] fp16
 void launch_image_patches(const float* img, int n, int S, int ps, half_t* patches, hipStream_t st);
