@@ -365,6 +365,16 @@ void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
 
 }  // namespace
 
+static int bg_take_tap(glass_engine* e, const half_t* x, int B, int res, int C) {
+    std::vector<_Float16> h((size_t)B * res * res * C);
+    GLASS_HIP(hipStreamSynchronize(e->cur));
+    GLASS_HIP(hipMemcpy(h.data(), x, h.size() * sizeof(_Float16), hipMemcpyDeviceToHost));
+    e->bg_tap_data.resize(h.size());
+    for (size_t i = 0; i < h.size(); ++i) e->bg_tap_data[i] = (float)h[i];
+    e->bg_tap_dims[0] = B; e->bg_tap_dims[1] = res; e->bg_tap_dims[2] = res; e->bg_tap_dims[3] = C;
+    return GLASS_OK;
+}
+
 int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
     BgState& g = e->bg;
     const int cd = 2 * g.zd;
@@ -380,6 +390,10 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
         if ((int)i == g.attn_before) {
             bg_attention(e, B, g.x[cur], g.x[cur ^ 1]);
             cur ^= 1;
+            if (e->bg_tap == -1 && c0 == 0) {
+                int rc = bg_take_tap(e, g.x[cur], B, g.blocks[i].res_in, g.blocks[i].cin);
+                if (rc) return rc;
+            }
         }
         const BgBlock& b = g.blocks[i];
         const int ri = b.res_in, ro = b.res_in << b.up;
@@ -414,6 +428,10 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
             bg_conv(e, tag, c0, B, q);
         }
         cur ^= 1;
+        if (e->bg_tap == (int)i && c0 == 0) {
+            int rc = bg_take_tap(e, g.x[cur], B, ro, b.cout);
+            if (rc) return rc;
+        }
     }
     {   // bn - relu (staging of the conv) - conv_to_rgb[:3] - tanh
         const int R = g.R, ch = e->cfg.bg_ch;

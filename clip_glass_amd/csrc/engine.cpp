@@ -1486,6 +1486,26 @@ extern "C" int glass_engine_set_overlap(glass_engine* e, int32_t on) {
     return GLASS_OK;
 }
 
+extern "C" int glass_engine_set_biggan_tap(glass_engine* e, int32_t block) {
+    REQUIRE(e, GLASS_ERR_ARG, "null engine");
+    REQUIRE(e->cfg.generator == GLASS_GEN_BIGGAN_DEEP, GLASS_ERR_STATE, "not a BigGAN-deep engine");
+    REQUIRE(block >= -2 && block < (int)e->bg.blocks.size(), GLASS_ERR_ARG, "no such GenBlock");
+    e->bg_tap = block;
+    e->bg_tap_data.clear();
+    return GLASS_OK;
+}
+
+extern "C" int glass_engine_get_biggan_tap(glass_engine* e, float* out, int64_t capacity, int32_t dims[4]) {
+    REQUIRE(e && dims, GLASS_ERR_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) dims[i] = e->bg_tap_dims[i];
+    REQUIRE(!e->bg_tap_data.empty(), GLASS_ERR_STATE, "no tap recorded (set_biggan_tap, then evaluate / generate)");
+    if (out) {
+        REQUIRE(capacity >= (int64_t)e->bg_tap_data.size(), GLASS_ERR_ARG, "tap buffer too small");
+        memcpy(out, e->bg_tap_data.data(), e->bg_tap_data.size() * sizeof(float));
+    }
+    return GLASS_OK;
+}
+
 extern "C" int glass_engine_set_profile_filter(glass_engine* e, const char* kernel_substr) {
     REQUIRE(e, GLASS_ERR_ARG, "null engine");
     e->prof_filter = kernel_substr ? kernel_substr : "";

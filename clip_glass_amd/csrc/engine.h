@@ -170,6 +170,10 @@ struct glass_engine {
     float* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
 
+    // ---- BigGAN per-block tap (diagnostic: localises a mismatch to the first wrong GenBlock) ----
+    int bg_tap = -2;                       // -2 off; -1 self-attention output; i >= 0: output of GenBlock i
+    std::vector<float> bg_tap_data;        // [B][R][R][C] NHWC of the first chunk
+    int bg_tap_dims[4] = {0, 0, 0, 0};
     // ---- profiling ----
     bool profiling = false;
     std::string prof_filter;                       // non-empty: only launches of kernels containing this substring

@@ -72,6 +72,7 @@ def load_library(path=None):
     lib.glass_engine_last_gpu_ms.argtypes = [C.c_void_p, fp]
     lib.glass_engine_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_overlap.argtypes = [C.c_void_p, C.c_int32]
+    lib.glass_engine_set_biggan_tap.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_profile_filter.argtypes = [C.c_void_p, C.c_char_p]
     lib.glass_engine_get_profile.argtypes = [C.c_void_p, C.POINTER(ProfRow), C.c_int32, C.POINTER(C.c_int32)]
     lib.glass_device_info.argtypes = [C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
@@ -240,6 +241,18 @@ class Engine:
 
     def set_profiling(self, on):
         _check(self.lib, self.lib.glass_engine_set_profiling(self._h, int(on)))
+
+    def biggan_tap(self, block):
+        """Record the activation after GenBlock `block` (-1: after self-attention) on the next pass; see biggan_tap_result."""
+        _check(self.lib, self.lib.glass_engine_set_biggan_tap(self._h, int(block)))
+
+    def biggan_tap_result(self):
+        dims = (C.c_int32 * 4)()
+        self.lib.glass_engine_get_biggan_tap.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_int32)]
+        _check(self.lib, self.lib.glass_engine_get_biggan_tap(self._h, None, 0, dims))
+        out = np.empty(tuple(int(d) for d in dims), dtype=np.float32)
+        _check(self.lib, self.lib.glass_engine_get_biggan_tap(self._h, _fp(out), out.size, dims))
+        return out
 
     def set_overlap(self, on):
         _check(self.lib, self.lib.glass_engine_set_overlap(self._h, int(on)))

@@ -161,6 +161,12 @@ int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_
  * (GLASS_OVERLAP=1 turns it on at creation).  Results are identical either way; it buys ~3 %
  * throughput and stretches co-running kernels, so per-kernel profiles are only clean with it off. */
 int glass_engine_set_overlap(glass_engine* e, int32_t on);
+/* BigGAN-deep diagnostic: record the activation after GenBlock `block` (-1: after the self-attention block, -2: off) of the first
+ * chunk of the next evaluate / generate; get_biggan_tap returns it as NHWC float32 [dims[0]][dims[1]][dims[2]][dims[3]] (out may
+ * be NULL to query dims).  The package behind models.py:64-86 is absent from the reference tree, so this path is checked
+ * block by block against the oracle's restatement: a real checkpoint that mismatches fails at the first wrong block. */
+int glass_engine_set_biggan_tap(glass_engine* e, int32_t block);
+int glass_engine_get_biggan_tap(glass_engine* e, float* out, int64_t capacity, int32_t dims[4]);
 
 /* Device info for bench.py (CU count, name, HBM bytes). */
 int glass_device_info(int32_t device, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes);

@@ -77,6 +77,35 @@ def test_biggan_512_eight_candidates_streaming_kernels():
     _run_case("bg512", 8, 8)
 
 
+@pytest.mark.parametrize("name", ["bg_mini", "bg512"])
+def test_biggan_per_block_taps(name):
+    """Every GenBlock output and the self-attention output of the engine against the oracle's taps (biggan_ref.generator(taps=)):
+    the path is parity-unpinned (package source absent), so a mismatch with a real checkpoint must be localisable to the first
+    wrong block."""
+    from oracle import biggan_ref
+    c = M.BIGGAN_CONFIGS[name]
+    P = 2
+    sd = M.make_biggan_state(name, 0)
+    x = synth.biggan_population(3, P, c["z_dim"], c["num_classes"])
+    z, probs = biggan_ref.latent_forward(x, c["z_dim"])                            # latent.py:16-24
+    taps = {}
+    with torch.no_grad():
+        biggan_ref.generator(_t(sd), z, probs, 1.0, c["layers"], attention_pos=c["attention_pos"], ch=c["ch"], taps=taps)
+    e = M.make_biggan_engine(name, sd, batch_size=P, max_pop=P)
+    worst = 0.0
+    for key in ["block%d" % i for i in range(len(c["layers"]))] + ["attn"]:
+        e.biggan_tap(-1 if key == "attn" else int(key[5:]))
+        e.generate(x)
+        got = e.biggan_tap_result().transpose(0, 3, 1, 2)                          # NHWC -> NCHW
+        ref = taps[key].numpy()
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        err = float(np.abs(got - ref).max() / np.abs(ref).max())
+        worst = max(worst, err)
+        assert err < 1e-2, "%s: first wrong block is %s (max err %.3e of max |ref|)" % (name, key, err)
+    diag("[biggan] %s per-block taps: %d blocks + attention, worst max-err / max|ref| = %.3e" % (name, len(c["layers"]), worst))
+    e.close()
+
+
 def test_biggan_error_paths():
     from clip_glass_amd.engine import Engine
     c = M.BIGGAN_CONFIGS["bg_mini"]
