@@ -93,11 +93,12 @@ def test_conv_stream_matches_tiled_and_direct():
     got = ops.conv(x, w, impl=4, **kw)
     ref_t = ops.conv(x, w, impl=2, **kw)
     ref_d = ops.conv(x, w, impl=1, **kw)
-    # same staging and MFMA order as the tiled kernel; the epilogue contracts v*d + noise into one fma, so a few
-    # outputs differ by one fp16 ulp
-    assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max())), float(np.abs(got - ref_t).max())
-    assert (got != ref_t).mean() < 1e-2
+    # same staging and MFMA order as the tiled kernel; the streaming epilogue rounds the activation INPUT to fp16 and applies
+    # lrelu * sqrt2 * scale in packed fp16 (the tiled kernel rounds once, after the activation): outputs differ by an fp16 ulp or two
     check("conv_stream vs direct", got, ref_d, 4e-3)
+    d = np.abs(got - ref_t)
+    diag("[conv_stream] vs tiled: max |diff| %.3e, %.1f %% of outputs differ" % (d.max(), 100 * (got != ref_t).mean()))
+    assert d.max() <= 2.0 ** -7 * max(1.0, float(np.abs(ref_t).max())), float(d.max())
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 64, 128, 128), (3, 16, 32, 256, 256), (1, 64, 64, 160, 128), (5, 16, 16, 256, 256),
