@@ -63,6 +63,17 @@ struct ConvParams {
     half_t* rgb_x_out;      // [B][H][W][32]: the fromRGB map, written as a side output (skip path input; nullable)
     half_t* rgb_xs_out;     // [B][H/2][W/2][32]: FIR (pad 1) + ::2 of the fromRGB map — the D block's skip-branch input, taken
                             // from the tile already staged in LDS (nullable)
+    // conv_stream only: the generator's LAST conv feeds nothing but toRGB (stylegan2/models.py:852-870, 1004-1013), so the
+    // kernel applies it to the activated tile in its accumulators and writes the skip image only — the feature map never
+    // reaches HBM.  trgb_yout != nullptr selects this mode (p.y is not written).
+    const float* trgb_w;    // [3][Cout] toRGB weights (runtime coefficient applied)
+    const float* trgb_b;    // [3]
+    const float* trgb_sn;   // [B][trgb_sn_stride] normalised style of the toRGB layer
+    int trgb_sn_stride;
+    const float* trgb_smax; // [B * trgb_smax_stride]: the style's normaliser (toRGB has no demod to cancel it)
+    int trgb_smax_stride;
+    const float* trgb_yprev;// [B][3][Ho/2][Wo/2] skip image of the previous block (nullable)
+    float* trgb_yout;       // [B][3][Ho][Wo]
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout

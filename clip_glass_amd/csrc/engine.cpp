@@ -841,8 +841,10 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     char tag[48];
     int gi = b_lo == 0 ? 0 : 1 + 2 * (b_lo - 1);
     int yi = 0;
+    static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knob
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
+        bool rgb_done = false;
         for (int l = 0; l < nl; ++l, ++gi) {
             const GConv& g = e->gconv[gi];
             ConvParams p = conv_defaults();
@@ -886,12 +888,33 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
                                  2.0 * 9 * g.cin * p.Neff;
             snprintf(tag, sizeof tag, "G.%s.r%d.%dx%d", g.up ? "upconv" : "conv", g.res_out, g.cin, g.cout);
+            if (b == c.n_blocks - 1 && l == nl - 1 && !g.up && !no_trgb_fuse) {
+                // the network's last conv feeds toRGB only: conv_stream<torgb> applies it to the tile in its accumulators and
+                // writes the skip image; the 64-byte-per-pixel feature map never goes to HBM
+                const GRgb& r = e->grgb[b];
+                ConvParams q = p;
+                q.y = nullptr;
+                q.trgb_w = r.w; q.trgb_b = r.bias;
+                q.trgb_sn = e->d_s + (size_t)c0 * e->S_total + r.style_off; q.trgb_sn_stride = e->S_total;
+                q.trgb_smax = e->d_smax + (size_t)c0 * e->n_style + r.style_idx; q.trgb_smax_stride = e->n_style;
+                q.trgb_yprev = yprev; q.trgb_yout = yb[yi];
+                if (conv_stream_applies(q)) {
+                    Prof pr(e, tag, flops + 2.0 * B * (double)r.res * r.res * 3 * r.cin,
+                            2.0 * B * (double)g.res_in * g.res_in * g.cin + B * (double)r.res * r.res * (12.0 + (b ? 3.0 : 0.0)));
+                    const char* k = launch_conv_stream(q, e->cur);
+                    if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                    if (e->profiling) e->tag_kernel[tag] = k;
+                    rgb_done = true;
+                    x = nullptr;   // not produced
+                }
+            }
+            if (rgb_done) { ++gi; break; }
             run_conv(e, p, tag, flops, bytes);
             x = out;
             xbs = (long long)g.res_out * g.res_out * g.cout;
         }
         const GRgb& r = e->grgb[b];
-        {
+        if (!rgb_done) {
             snprintf(tag, sizeof tag, "G.torgb.r%d", r.res);
             Prof pr(e, tag, 2.0 * B * (double)r.res * r.res * 3 * r.cin,
                     B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));

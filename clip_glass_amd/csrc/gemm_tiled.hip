@@ -6,6 +6,7 @@
 // consecutive output columns of one output row per accumulator quad (16/8-byte stores).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define GROWB 144
 
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     if (p.K % 64 != 0 || p.ldo % 4 != 0 || p.M < 64) return nullptr;
     const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
-    if (p.N % 128 == 0) {
+    // 128-wide n tiles under-fill the chip on the N = 768 CLIP linears (25 x 6 = 150 workgroups for 256 CUs): take 64-wide
+    // tiles whenever the 128-wide grid has fewer workgroups than CUs
+    static const bool wide_only = getenv("GLASS_GEMM_BN128") != nullptr;   // A/B knob
+    const bool fills = (long long)gx * (p.N / 128) * gz >= 256;
+    if (p.N % 128 == 0 && (fills || wide_only)) {
         hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<128>";
     }

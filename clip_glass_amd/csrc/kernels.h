@@ -10,6 +10,7 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st);
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
 // persistent streaming 3x3 conv for the 32 -> 32 channel 1024^2 layers (conv_stream.hip); nullptr when unsupported
 const char* launch_conv_stream(const ConvParams& p, hipStream_t st);
+bool conv_stream_applies(const ConvParams& p);   // trgb_yout set: the fused conv + toRGB form
 // LDS-DMA staged 3x3 conv for the MFMA-bound mid-resolution layers (conv_glds.hip); nullptr when unsupported / disabled
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force = false);
 // second half of the full-resolution discriminator block in one kernel (conv_down.hip):

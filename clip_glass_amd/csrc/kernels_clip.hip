@@ -5,6 +5,7 @@
 // :218-235 (VisualTransformer.forward), generator.py:51 (cosine), problem.py:21-27.
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -141,9 +142,129 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* qkv, int L
         out[((long long)img * L + i) * D + h * hd + d] = (half_t)a;
     }
 }
+// MFMA form for L <= 64 (the visual tower's 50 tokens; the scalar kernel above spends 49 us per layer on LDS-fed fp32 FMAs).
+// TWO waves per (image, head): wave qb owns 32 queries and all 64 key slots.
+//   S^T[key][query] = K Q^T: both operands are 16-byte global loads of a token's 8 consecutive head dims — no staging;
+//   the softmax runs in the accumulator registers (a query's keys live in one lane pair: 32 registers + one xor-32 shuffle);
+//   O^T[d][query] = V^T P: the MFMA's K order is free, so P stays where the softmax left it (lane half kh, registers 8g+4kh+q)
+//   and V^T goes to LDS once per pair with its keys permuted to match (144-byte rows: conflict-free 16-byte reads);
+//   P is split hi + lo * 2^-11 in fp16 so the product keeps the fp32 softmax (fp16 x fp16 products are exact in the fp32
+//   accumulator: the scores themselves are the scalar kernel's up to summation order).
+__global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t* qkv, int L, int heads, int n_pairs, int causal,
+                                                             half_t* out) {
+    constexpr int VROW = 144;
+    __shared__ __attribute__((aligned(16))) char vts[2][64 * VROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+    const int pair = blockIdx.x * 2 + (wave >> 1), qb = wave & 1;
+    const int pc = min(pair, n_pairs - 1);
+    const int img = pc / heads, h = pc - img * heads, D = heads * 64;
+    const half_t* base = qkv + (long long)img * L * 3 * D + h * 64;
+    const long long ts = 3LL * D;                       // token stride
+    const int query = qb * 32 + lr;
+    h8 qf[4], kf[2][4], vv[4];
+    {
+        const half_t* qp = base + min(query, L - 1) * ts + kh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const h8*)(qp + kk * 16);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const half_t* kp = base + min(kb * 32 + lr, L - 1) * ts + D + kh * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kf[kb][kk] = *(const h8*)(kp + kk * 16);
+        }
+    }
+    const int pt = t & 127;                             // thread within the pair
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = pt + 128 * u, tok = e >> 3, d8 = e & 7;
+        vv[u] = *(const h8*)(base + min(tok, L - 1) * ts + 2 * D + d8 * 8);
+    }
+    char* vt = vts[wave >> 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = pt + 128 * u, tok = e >> 3, d8 = e & 7;
+        // key tok = kb*32 + 8g + 4kh' + q sits at K position (kb*2 + (g>>1))*16 + kh'*8 + (g&1)*4 + q of its row
+        const int r = tok & 31, g = r >> 3;
+        const int pos = ((tok >> 5) * 2 + (g >> 1)) * 16 + ((r >> 2) & 1) * 8 + (g & 1) * 4 + (r & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *(half_t*)(vt + (d8 * 8 + j) * VROW + pos * 2) = tok < L ? vv[u][j] : (half_t)0.f;
+    }
+    f16x s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s[kb] = mfma32(kf[kb][kk], qf[kk], s[kb]);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            float v = s[kb][r] * 0.125f;                // hd^-0.5, hd = 64
+            if (key >= L || (causal && key > query)) v = -INFINITY;
+            s[kb][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float z = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e2 = __expf(s[kb][r] - m);
+            s[kb][r] = e2;
+            z += e2;
+        }
+    z += __shfl_xor(z, 32);
+    const float inv = 1.f / z;
+    __syncthreads();                                    // V^T of both pairs is in place
+    f16x o[2], ol[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[db][r] = 0.f; ol[db][r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        h8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pv = s[ks >> 1][(2 * (ks & 1) + (e >> 2)) * 4 + (e & 3)] * inv;
+            ph[e] = (half_t)pv;
+            pl[e] = (half_t)((pv - (float)ph[e]) * 2048.f);
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const h8 vf = *(const h8*)(vt + (db * 32 + lr) * VROW + (ks * 16 + kh * 8) * 2);
+            o[db] = mfma32(vf, ph, o[db]);
+            ol[db] = mfma32(vf, pl, ol[db]);
+        }
+    }
+    if (pair < n_pairs && query < L) {
+        half_t* op = out + ((long long)img * L + query) * D + h * 64 + 4 * kh;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = (half_t)(o[db][g * 4 + q] + ol[db][g * 4 + q] * (1.f / 2048.f));
+                *(h4*)(op + db * 32 + 8 * g) = w;
+            }
+    }
+}
+
 void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,
                       hipStream_t st) {
     (void)hd;  // 64 (asserted by the engine)
+    static const bool no_mfma = getenv("GLASS_NO_ATTN_MFMA") != nullptr;   // A/B knob
+    if (L <= 64 && !no_mfma) {
+        const int n_pairs = n_img * heads;
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3((n_pairs + 1) / 2), dim3(256), 0, st, qkv, L, heads, n_pairs, causal, out);
+        return;
+    }
     const size_t lds = (size_t)(3 * L * 65 + L * (L + 1)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS

@@ -104,6 +104,18 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     half_t* y = dv.alloc<half_t>(nout);
     p.y = y;
     OPREQ(p.x && p.w && y, "device allocation failed");
+    float* yrgb = nullptr;
+    const size_t nrgb = (size_t)d->B * 3 * d->Ho * d->Wo;
+    if (d->trgb_yout) {
+        OPREQ(d->impl == 4 && d->trgb_w && d->trgb_b && d->trgb_sn && d->trgb_smax, "fused toRGB: impl 4 and all of w / b / sn / smax");
+        p.trgb_w = dv.up32(d->trgb_w, 3 * (size_t)d->Cout); p.trgb_b = dv.up32(d->trgb_b, 3);
+        p.trgb_sn = dv.up32(d->trgb_sn, (size_t)d->B * d->Cout); p.trgb_sn_stride = d->Cout;
+        p.trgb_smax = dv.up32(d->trgb_smax, d->B); p.trgb_smax_stride = 1;
+        p.trgb_yprev = dv.up32(d->trgb_yprev, (size_t)d->B * 3 * (d->Ho / 2) * (d->Wo / 2));
+        yrgb = dv.alloc<float>(nrgb);
+        p.trgb_yout = yrgb;
+        p.y = nullptr;
+    }
     if (d->impl == 1) launch_conv_direct(p, 0);
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
@@ -116,6 +128,10 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
     int rc = finish();
     if (rc) return rc;
+    if (yrgb) {
+        GLASS_HIP(hipMemcpy(d->trgb_yout, yrgb, nrgb * sizeof(float), hipMemcpyDeviceToHost));
+        return GLASS_OK;
+    }
     return down16(d->y, y, nout);
 }
 

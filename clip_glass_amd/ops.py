@@ -19,7 +19,10 @@ class ConvDesc(C.Structure):
                 ("noise_strength", C.c_float), ("out_scale", C.c_float),
                 ("x", C.POINTER(C.c_float)), ("w", C.POINTER(C.c_float)), ("sn", C.POINTER(C.c_float)),
                 ("dscale", C.POINTER(C.c_float)), ("noise", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
-                ("res", C.POINTER(C.c_float)), ("y", C.POINTER(C.c_float))]
+                ("res", C.POINTER(C.c_float)), ("y", C.POINTER(C.c_float)),
+                ("trgb_w", C.POINTER(C.c_float)), ("trgb_b", C.POINTER(C.c_float)), ("trgb_sn", C.POINTER(C.c_float)),
+                ("trgb_smax", C.POINTER(C.c_float)), ("trgb_yprev", C.POINTER(C.c_float)),
+                ("trgb_yout", C.POINTER(C.c_float))]
 
 
 def _opt(a):
@@ -30,8 +33,11 @@ def _opt(a):
 
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
-         batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0):
-    """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout]."""
+         batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
+         torgb=None):
+    """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout].
+    torgb = dict(w [3,Cout], b [3], sn [B,Cout], smax [B], yprev [B,3,Ho/2,Wo/2] or None) with impl=4: the fused conv + toRGB
+    form of the streaming kernel — returns the skip image [B,3,Ho,Wo] instead of y."""
     lib = load_library()
     x = _f32(x); w = _f32(w)
     Bx, H, W, Cin = x.shape
@@ -55,9 +61,18 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
         keep.append(a)
         if p is not None:
             setattr(d, name, p)
+    yrgb = None
+    if torgb is not None:
+        yrgb = np.empty((B, 3, Ho, Wo), dtype=np.float32)
+        for name in ("w", "b", "sn", "smax", "yprev"):
+            a, p = _opt(torgb.get(name))
+            keep.append(a)
+            if p is not None:
+                setattr(d, "trgb_" + name, p)
+        d.trgb_yout = _fp(yrgb)
     lib.glass_op_conv.argtypes = [C.c_int32, C.POINTER(ConvDesc)]
     _check(lib, lib.glass_op_conv(device, C.byref(d)))
-    return y
+    return yrgb if yrgb is not None else y
 
 
 def gemm(a, w, bias=None, mode=3, impl=0, acc=None, device=0):

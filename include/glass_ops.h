@@ -31,6 +31,13 @@ typedef struct glass_conv_desc {
     const float* bias;     /* [Cout] or NULL */
     const float* res;      /* [B,Ho,Wo,Cout] or NULL */
     float* y;              /* [B,Ho,Wo,Cout] */
+    /* impl 4 only, all or none: toRGB fused into the conv (the generator's last layer) — y is NOT written, trgb_yout is */
+    const float* trgb_w;     /* [3,Cout] scaled */
+    const float* trgb_b;     /* [3] */
+    const float* trgb_sn;    /* [B,Cout] normalised toRGB style */
+    const float* trgb_smax;  /* [B] */
+    const float* trgb_yprev; /* [B,3,Ho/2,Wo/2] or NULL */
+    float* trgb_yout;        /* [B,3,Ho,Wo] */
 } glass_conv_desc;
 
 int glass_op_conv(int32_t device, const glass_conv_desc* d);

@@ -101,6 +101,43 @@ def test_conv_stream_matches_tiled_and_direct():
     assert d.max() <= 2.0 ** -7 * max(1.0, float(np.abs(ref_t).max())), float(d.max())
 
 
+@pytest.mark.parametrize("with_skip", [True, False])
+def test_conv_stream_fused_torgb(with_skip):
+    """conv_stream<torgb>: the generator's last conv with toRGB (stylegan2/models.py:852-870) + the FIR-upsampled skip image
+    (models.py:1004-1013, modules.py:580-602) applied to the tile in the accumulators — against the same conv's stored fp16
+    output pushed through a float64 toRGB."""
+    rng = np.random.default_rng(11)
+    B, H, W, C = 5, 256, 1024 + 32, 32       # uneven tile ranges, sample switches inside a workgroup's range, all four borders
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    sn = rng.uniform(0.5, 1.0, (B, C)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, C)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32) * 0.2
+    kw = dict(sn=sn, dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True)
+    wrgb = (rng.standard_normal((3, C)) / math.sqrt(C)).astype(np.float32)
+    brgb = rng.standard_normal(3).astype(np.float32) * 0.1
+    srgb = rng.uniform(0.2, 1.0, (B, C)).astype(np.float32)
+    smax = rng.uniform(0.5, 3.0, B).astype(np.float32)
+    yprev = rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32) if with_skip else None
+    got = ops.conv(x, w, impl=4, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw)
+    feat = ops.conv(x, w, impl=4, **kw).astype(np.float64)                 # [B,H,W,C], fp16-rounded as the fused kernel sees it
+    wm = wrgb[None].astype(np.float64) * (srgb.astype(np.float64) * smax[:, None])[:, None, :]    # [B,3,C]
+    ref = np.einsum("bhwc,boc->bohw", feat, wm) + brgb[None, :, None, None]
+    if with_skip:
+        yp = np.pad(yprev.astype(np.float64), ((0, 0), (0, 0), (1, 0), (1, 0)))       # x[m-1] with zero at m = 0
+        a, bq = yp[:, :, :-1], yp[:, :, 1:]                                          # rows m-1, m
+        rows = np.empty((B, 3, H, W // 2 + 1))
+        rows[:, :, 0::2] = 0.75 * a + 0.25 * bq
+        rows[:, :, 1::2] = 0.25 * a + 0.75 * bq
+        a, bq = rows[..., :-1], rows[..., 1:]
+        up = np.empty((B, 3, H, W))
+        up[..., 0::2] = 0.75 * a + 0.25 * bq
+        up[..., 1::2] = 0.25 * a + 0.75 * bq
+        ref = ref + up
+    check("conv_stream<torgb>", got, ref, 2e-5)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 64, 128, 128), (3, 16, 32, 256, 256), (1, 64, 64, 160, 128), (5, 16, 16, 256, 256),
                                              (2, 32, 16, 128, 384)])
 def test_conv_glds_matches_tiled(B, H, W, Cin, Cout):
@@ -269,7 +306,7 @@ def test_layernorm_attention():
     x = rnd(11, "x", (M, D), 2.0) + 0.5; g = rnd(11, "g", (D,), 0.1) + 1; b = rnd(11, "b", (D,), 0.1)
     ref = F.layer_norm(torch.tensor(x), (D,), torch.tensor(g), torch.tensor(b), 1e-5).numpy()
     check("layernorm", ops.layernorm(x, g, b), ref, 1e-5)
-    for L, causal in ((50, False), (17, False), (77, True)):
+    for L, causal in ((50, False), (17, False), (77, True), (64, True), (33, True)):   # L <= 64: the MFMA kernel
         n_img, heads = 3, 2
         qkv = h16(rnd(12, "qkv%d" % L, (n_img * L, 3 * heads * 64)))
         t = torch.tensor(qkv).view(n_img, L, 3, heads, 64)
