@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     const int lr = lane & 31, kh = lane >> 5;
     const int part = t & 3;
 
+    // Loads are UNCONDITIONAL (out-of-image / out-of-range vectors read a valid address instead) and masked when they are
+    // written to LDS, on border tiles only: a conditional load costs a saveexec + branch + zero-fill each, every stage.
     int a_goff[NA];
+    int okm = 0;                                 // bit k: vector k is inside the image
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int v = t + 256 * k;
@@ -54,11 +57,19 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
         const int pr = pix / PW, pc = pix - pr * PW;
         const int iy = my0 - 1 + pr, ix = mx0 - 1 + pc;
         const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : -1;
+        a_goff[k] = ok ? (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
+        okm |= (ok ? 1 : 0) << k;
     }
+    const bool border = my0 < 1 || mx0 < 1 || my0 + 7 >= p.H || mx0 + 31 >= p.W;     // uniform
     const half_t* xb = p.x + (long long)b * p.x_bstride;
     const half_t* wb = p.w_up + (long long)b * p.w_bstride;
     const half_t* snb = p.sn16 ? p.sn16 + (long long)b * p.sn_stride + part * 8 : nullptr;
+    long long b_goff[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int u = min(t + 256 * k, NVB - 1);
+        b_goff[k] = ((long long)(u >> 7) * p.Cout + n0 + ((u >> 2) & 31)) * p.Cin + part * 8;
+    }
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
@@ -66,32 +77,29 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     for (int j = 0; j < 8; ++j) sh[j] = (half_t)1.f;
     auto load_a = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
-            if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
-        }
-        if (snb) sh = *(const h8*)(snb + c0);
+        for (int k = 0; k < NA; ++k) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
+        if (p.sn16) sh = *(const h8*)(snb + c0);
     };
     auto load_b = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int u = t + 256 * k;
-            if (u < NVB) {
-                const int tap = u >> 7;           // / (32 * 4)
-                const int n = (u >> 2) & 31;
-                rb[k] = *(const h8*)(wb + ((long long)tap * p.Cout + n0 + n) * p.Cin + c0 + part * 8);
-            }
-        }
+        for (int k = 0; k < NB; ++k) rb[k] = *(const h8*)(wb + b_goff[k] + c0);
     };
     auto store_a = [&]() {
+        if (!border && !p.sn16) {                // interior tile of a layer whose weights carry the style: registers -> LDS
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const int v = t + 256 * k;
-            if (v < NVA) {
-                h8 a = ra[k];
-                if (snb) a = a * sh;   // 4 x v_pk_mul_f16
-                *(h8*)(As + (v >> 2) * ROWB + part * 16) = a;
+            for (int k = 0; k < NA; ++k) {
+                const int v = t + 256 * k;
+                if (k < NA - 1 || v < NVA) *(h8*)(As + (v >> 2) * ROWB + part * 16) = ra[k];
+            }
+        } else {
+            const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                const int v = t + 256 * k;
+                if (k < NA - 1 || v < NVA) {
+                    h8 a = ((okm >> k) & 1) ? ra[k] : zero;
+                    *(h8*)(As + (v >> 2) * ROWB + part * 16) = a * sh;   // 4 x v_pk_mul_f16 (1.0 without a style)
+                }
             }
         }
     };
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int u = t + 256 * k;
-            if (u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
+            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
         }
     };
 
@@ -160,10 +168,9 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
     const int px = min(txi * 60 + oxl, p.Wo - 1);
     f4 dq[4];
+    if (p.dscale) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        dq[g] = f4{1.f, 1.f, 1.f, 1.f};
-        if (p.dscale) dq[g] = *(const f4*)(p.dscale + (long long)b * p.ds_stride + n0 + 8 * g + 4 * kh);
+        for (int g = 0; g < 4; ++g) dq[g] = *(const f4*)(p.dscale + (long long)b * p.ds_stride + n0 + 8 * g + 4 * kh);
     }
     f4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -171,6 +178,8 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
         bq1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
     }
     float nzv[12];
+#pragma unroll
+    for (int r = 0; r < 12; ++r) nzv[r] = 0.f;
     if (p.noise) {
         const float* nzp = p.noise + (long long)(b / p.batch_size) * p.Ho * p.Wo + px;
 #pragma unroll
@@ -178,22 +187,31 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     }
 
     // ---- t tile -> LDS (demod applied; it commutes with the FIR) ---------------------------------
+    // Pixel (lty, ltx) is a 64-byte row of four 16-byte channel pairs (8g .. 8g+7: the quads of lane halves kh = 0 | 1);
+    // the pair slot is XOR-swizzled by (ltx >> 1) & 3 (4-way instead of 16-way conflicts for the 8-byte writes, and the
+    // FIR's 16-byte reads need no fix-up).  Round 2 instruction diet: the epilogue was ~2500 instructions per thread per
+    // tile (a phase trace: 17000 cycles, more than the K loop of every layer below 256 input channels) — 16 v_cndmask per
+    // FIR row to un-swap an 8-byte swizzle, an element-wise activation, 64-bit store addressing per row.
+    {
+        char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+        int so[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int g = 0; g < 4; ++g) so[g] = (g ^ (lr & 3)) * 16;
+        auto put = [&](bool scaled) {
 #pragma unroll
-        for (int ph = 0; ph < 4; ++ph) {
-            const int lty = 2 * (wave * 2 + i) + (ph >> 1), ltx = 2 * lr + (ph & 1);
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4 d = dq[g];
-                h4 o;
+                for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][g * 4 + q] * d[q]);
-                // quad position XOR-swizzled by the pixel (2-way instead of 16-way write conflicts)
-                const int qp = (2 * g + kh) ^ (lr & 7);
-                *(h4*)(T + ((lty * 64 + ltx) * 32 + qp * 4)) = o;
-            }
-        }
+                    for (int g = 0; g < 4; ++g) {
+                        h4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (half_t)(scaled ? acc[i][ph][g * 4 + q] * dq[g][q] : acc[i][ph][g * 4 + q]);
+                        *(h4*)(tw + so[g] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                    }
+        };
+        if (p.dscale) put(true);
+        else put(false);          // weights carry the demodulation already
     }
     __syncthreads();
 
@@ -205,40 +223,29 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     h8 bias8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)bq0[j]; bias8[j + 4] = (half_t)bq1[j]; }
-    const half_t k1 = (half_t)(GLASS_SQRT2 * p.out_scale), k2 = (half_t)(0.2f * GLASS_SQRT2 * p.out_scale);
+    // activation as max(v * k1, v * k2): lrelu * sqrt2 * scale -> (sqrt2 s, 0.2 sqrt2 s); none -> (s, s)
+    const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+    const char* tr[4];
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+        const int ltx = oxl + 1 + jx;
+        tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+    }
+    const long long rowpitch = (long long)p.Wo * p.Cout;
+    half_t* yp = p.y + (((long long)b * p.Ho + tyi * 12) * p.Wo + px) * p.Cout + n0 + cg * 8;
     h8 hs[4];
 #pragma unroll
     for (int r = 1; r < 16; ++r) {
-        h8 hv[4];
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) {
-            const int ltx = oxl + 1 + jx;
-            const int sw = (ltx >> 1) & 7;           // writer's lr & 7 for this t column
-            const h8 v = *(const h8*)(T + ((r * 64 + ltx) * 32 + ((cg ^ (sw >> 1)) * 8)));
-            if (sw & 1) {                            // the two quads of the pair sit swapped
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { hv[jx][j] = v[j + 4]; hv[jx][j + 4] = v[j]; }
-            } else {
-                hv[jx] = v;
-            }
-        }
-        hs[r & 3] = (hv[0] + hv[3]) * fq + (hv[1] + hv[2]) * ft;
+        const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
+                 v3 = *(const h8*)(tr[3] + r * 4096);
+        hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
         if (r >= 4) {
-            const int py = tyi * 12 + (r - 4);
-            if (py < p.Ho) {
-                h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + (hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft;
-                half_t nv = (half_t)0.f;
-                if (p.noise) nv = (half_t)(p.noise_strength * nzv[r - 4]);
-                v = v + bias8 + nv;
-                if (p.act) {
-                    const h8 a = v * k1, c2 = v * k2;     // lrelu(v)*sqrt2*scale = max(v*k1, v*k2) for k1 > k2 > 0
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = a[j] > c2[j] ? a[j] : c2[j];
-                } else {
-                    v = v * (half_t)p.out_scale;
-                }
-                *(h8*)(p.y + (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + n0 + cg * 8) = v;
+            if (tyi * 12 + (r - 4) < p.Ho) {
+                const h8 bn = bias8 + (half_t)(p.noise_strength * nzv[r - 4]);
+                h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
+                *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2);
             }
+            yp += rowpitch;
         }
     }
 }
