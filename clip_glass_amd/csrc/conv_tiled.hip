@@ -67,29 +67,47 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         return w;
     };
 
-    // staging state of the tile being LOADED (may be one tile ahead of the tile being computed)
-    int a_goff[NA];   // element offset into the image (without chunk offset), -1 = zero fill
+    // staging state of the tile being LOADED (may be one tile ahead of the tile being computed).
+    // Loads are UNCONDITIONAL (vectors outside the image / past the patch read a valid address) and masked when they are
+    // written to LDS, on border tiles only; the per-vector LDS offsets are computed once per tile; every option of the input
+    // transform is tested on the (uniform) launch parameters, not on per-thread pointers — round 2's instruction diet: the
+    // compiler had turned this staging into ~25 exec-mask / zero-fill instructions per vector per chunk.
+    int a_goff[NA];   // element offset into the image (without chunk offset)
+    int a_loff[(NA + 1) / 2];   // LDS byte offsets, two 16-bit values per register
+    int okm = 0;      // bit k: vector k is a pixel of the image
+    bool border = false;        // uniform: the patch reaches outside the image
     const half_t* xb = p.x;
     const half_t* wb = p.w;
     const half_t* snb = nullptr;
     const half_t* psb = nullptr;
     int ld_n0 = 0;
     auto aim = [&](const Tile& w) {
+        okm = 0;
+#pragma unroll
+        for (int k = 0; k < (NA + 1) / 2; ++k) a_loff[k] = 0;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             const int v = t + 256 * k;
             const int pix = v >> 2;
             const int pr = pix / PW, pc = pix - pr * PW;
             const int iy = w.ty0 * S - p.pad + pr, ix = w.tx0 * S - p.pad + pc;
-            const bool ok = (v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_goff[k] = ok ? ((iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + part * 8 : -1;
+            const bool ok = (k < NA - 1 || v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            a_goff[k] = ok ? ((iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + part * 8 : part * 8;
+            okm |= (ok ? 1 : 0) << k;
+            int lrow = pix;
+            if (S == 2)     // de-interleave the patch columns (even | odd): a stride-2 fragment read then walks CONSECUTIVE LDS rows
+                lrow = pr * PW + ((pc & 1) ? (PW + 1) / 2 + (pc >> 1) : (pc >> 1));   // (pixel order is 2-way bank-conflicted for any 16-byte-aligned pitch)
+            a_loff[k >> 1] |= (lrow * ROWB + part * 16) << ((k & 1) * 16);
         }
+        const int y_lo = w.ty0 * S - p.pad, x_lo = w.tx0 * S - p.pad;
+        border = y_lo < 0 || x_lo < 0 || y_lo + PH > p.H || x_lo + PW > p.W;
         xb = p.x + (long long)w.b * p.x_bstride;
         wb = p.w + (long long)w.b * p.w_bstride;
         snb = p.sn16 ? p.sn16 + (long long)w.b * p.sn_stride + part * 8 : nullptr;
         psb = p.pre_shift16 ? p.pre_shift16 + (long long)w.b * p.sn_stride + part * 8 : nullptr;
         ld_n0 = w.n0;
     };
+    static_assert(PH * PW * ROWB + 64 < 65536, "LDS offsets are packed in 16 bits");
 
     h8 ra[NA], rb[NB];
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
@@ -99,51 +117,46 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 
     auto load_a = [&](int c0) {
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
-            if (a_goff[k] >= 0) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
-        }
-        if (snb) sh = *(const h8*)(snb + c0);
+        for (int k = 0; k < NA; ++k) ra[k] = *(const h8*)(xb + a_goff[k] + c0);
+        if (p.sn16) sh = *(const h8*)(snb + c0);
         ld_c0 = c0;
     };
     auto load_b = [&](int c0, int ty) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int u = t + 256 * k;
-            if (NVB % 256 == 0 || u < NVB) {
-                const int tx = u / (NT * 4);
-                const int n = (u >> 2) % NT;
-                rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
-            }
+            const int u = min(t + 256 * k, NVB - 1);
+            const int tx = u / (NT * 4);
+            const int n = (u >> 2) % NT;
+            rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
         }
     };
+    auto a_lds = [&](int k) { return As + ((a_loff[k >> 1] >> ((k & 1) * 16)) & 0xffff); };
     auto store_a = [&]() {
-        h8 shf;   // pre-activation shift (BigGAN: relu(x * sh + shf)); fetched here to keep it out of the K-loop registers
-        if (psb) shf = *(const h8*)(psb + ld_c0);
+        if (!border && !p.sn16 && !p.pre_shift16) {      // interior tile, no input transform: registers -> LDS
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const int v = t + 256 * k;
-            if (NVA % 256 == 0 || v < NVA) {
-                h8 a = ra[k];
-                if (psb) {              // 4 x v_pk_fma_f16 + 4 x v_pk_max_f16; padding pixels stay zero
-                    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-                    a = a_goff[k] >= 0 ? __builtin_elementwise_max(a * sh + shf, zero) : zero;
-                } else if (snb) a = a * sh;    // 4 x v_pk_mul_f16
-                int lrow = v >> 2;
-                if (S == 2) {   // de-interleave the patch columns (even | odd): a stride-2 fragment read then walks CONSECUTIVE
-                    const int pr = lrow / PW, pc = lrow - pr * PW;       // LDS rows (with pixel order it is 2-way bank-conflicted
-                    lrow = pr * PW + ((pc & 1) ? (PW + 1) / 2 + (pc >> 1) : (pc >> 1));   // for any 16-byte-aligned row pitch)
-                }
-                *(h8*)(As + lrow * ROWB + part * 16) = a;
-            }
+            for (int k = 0; k < NA; ++k)
+                if (k < NA - 1 || t + 256 * k < NVA) *(h8*)a_lds(k) = ra[k];
+            return;
+        }
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p.pre_shift16) {   // BigGAN: relu(x * sh + shf), 4 x v_pk_fma_f16 + 4 x v_pk_max_f16; padding pixels stay zero
+            const h8 shf = *(const h8*)(psb + ld_c0);    // fetched here to keep it out of the K-loop registers
+#pragma unroll
+            for (int k = 0; k < NA; ++k)
+                if (k < NA - 1 || t + 256 * k < NVA)
+                    *(h8*)a_lds(k) = ((okm >> k) & 1) ? __builtin_elementwise_max(ra[k] * sh + shf, zero) : zero;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NA; ++k)
+                if (k < NA - 1 || t + 256 * k < NVA)
+                    *(h8*)a_lds(k) = (((okm >> k) & 1) ? ra[k] : zero) * sh;    // 4 x v_pk_mul_f16 (1.0 without a style)
         }
     };
     auto store_b = [&]() {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int u = t + 256 * k;
-            if (NVB % 256 == 0 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
+            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
         }
     };
 

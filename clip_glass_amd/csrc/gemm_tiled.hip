@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
     auto load = [&](int k0) {
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int row = (t >> 3) + 32 * k;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ra[k][j] = (half_t)0.f;
-            if (m0 + row < p.M) ra[k] = *(const h8*)(p.a + (long long)(m0 + row) * p.K + k0 + part * 8);
+            // unconditional (rows past M read row M - 1; their outputs are never stored): a conditional load costs a
+            // saveexec + branch + zero-fill per vector per stage
+            const int row = min(m0 + (t >> 3) + 32 * k, p.M - 1);
+            ra[k] = *(const h8*)(p.a + (long long)row * p.K + k0 + part * 8);
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {

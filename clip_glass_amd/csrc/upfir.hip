@@ -119,21 +119,10 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    const int n_stages = p.Cin >> 5;
-    load_a(0);
-    load_b(0);
-    for (int s = 0; s < n_stages; ++s) {
-        if (s > 0) __syncthreads();
-        store_a();
-        store_b();
-        __syncthreads();
-        if (s + 1 < n_stages) {
-            load_a((s + 1) * 32);
-            load_b((s + 1) * 32);
-        }
-        // tap (ky,kx) feeds parity class (ky&1, kx&1) and reads x[m - (ky>>1), n - (kx>>1)]: the 9 taps
-        // use only 4 distinct input shifts, so each x fragment is loaded once per shift and re-used
-        // by every tap of that shift (17 LDS fragment reads per 18 MFMAs instead of 27).
+    // tap (ky,kx) feeds parity class (ky&1, kx&1) and reads x[m - (ky>>1), n - (kx>>1)]: the 9 taps
+    // use only 4 distinct input shifts, so each x fragment is loaded once per shift and re-used
+    // by every tap of that shift (17 LDS fragment reads per 18 MFMAs instead of 27).
+    auto mfma_block = [&]() {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -159,12 +148,27 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
                 }
             }
         }
+    };
+    const int n_stages = p.Cin >> 5;
+    load_a(0);
+    load_b(0);
+    for (int s = 0; s + 1 < n_stages; ++s) {
+        if (s > 0) __syncthreads();
+        store_a();
+        store_b();
+        __syncthreads();
+        load_a((s + 1) * 32);
+        load_b((s + 1) * 32);
+        mfma_block();
     }
-    __syncthreads();   // everyone is done with the staging area: overlay T
-
-    // Everything the epilogue needs from global memory is fetched HERE, unconditionally and in one batch (a load
-    // under a branch, consumed at once, costs a full round trip each: 32 serial demod loads + 12 serial noise
-    // loads per block before): 4 demod quads, 2 bias quads, this thread's 12 noise values.
+    // last stage, peeled: in place of a next stage's operands, everything the epilogue needs from global memory is fetched
+    // HERE (4 demod quads, 2 bias quads, this thread's 12 noise values), unconditionally and in one batch, so that it lands
+    // under the last MFMA block instead of costing the epilogue a round trip of its own (~1.5 us of a ~7 us tile on the
+    // two-stage 1024^2 layer).  Peeled because as loop-carried values these 36 registers would be live through every stage.
+    if (n_stages > 1) __syncthreads();
+    store_a();
+    store_b();
+    __syncthreads();
     const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
     const int px = min(txi * 60 + oxl, p.Wo - 1);
     f4 dq[4];
@@ -185,6 +189,8 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
 #pragma unroll
         for (int r = 0; r < 12; ++r) nzv[r] = nzp[(long long)min(tyi * 12 + r, p.Ho - 1) * p.Wo];
     }
+    mfma_block();
+    __syncthreads();   // everyone is done with the staging area: overlay T
 
     // ---- t tile -> LDS (demod applied; it commutes with the FIR) ---------------------------------
     // Pixel (lty, ltx) is a 64-byte row of four 16-byte channel pairs (8g .. 8g+7: the quads of lane halves kh = 0 | 1);
