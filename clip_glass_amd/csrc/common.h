@@ -20,6 +20,34 @@ __device__ __forceinline__ f16x mfma32(h8 a, h8 b, f16x c) {
 }
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
+// ---- toRGB applied to a wave's output tile while it is still in registers (conv_stream / conv_tiled / conv_glds) -------------
+// The activated fp16 quads a lane holds after the epilogue math (lane (px, kh): channels j*32 + 8g + 4kh + q of pixel px) are a
+// valid MFMA B operand as they stand — the K order of an MFMA is free as long as A uses the same one.  A = 16-row weight table
+// per image row i of the wave: rows 0-2 (i = 0) / 4-6 (i = 1) the fp16 hi part of w[c][.] * style, rows 8-10 / 12-14 the lo part
+// * 2^11; after the MFMAs lane half kh holds image row kh: registers 0-2 hi, 4-6 lo.
+// Table element (tab, n, hidx), hidx = ((j*2 + gp)*2 + kh)*8 + e  <->  channel j*32 + 8*(2gp + (e>>2)) + 4kh + (e&3).
+__device__ __forceinline__ int trgb_channel(int hidx) {
+    const int chunk = hidx >> 3, e = hidx & 7;
+    return (chunk >> 2) * 32 + 8 * (2 * ((chunk >> 1) & 1) + (e >> 2)) + 4 * (chunk & 1) + (e & 3);
+}
+__device__ __forceinline__ half_t trgb_table_value(int tab, int n, float w) {
+    if ((n & 3) == 3 || ((n >> 2) & 1) != tab) return (half_t)0.f;
+    const half_t hv = (half_t)w;
+    return (n & 8) ? (half_t)((w - (float)hv) * 2048.f) : hv;
+}
+// FIR-upsampled skip image (modules.py:580-602; zero-insert, pad [3,1], 4x4 FIR * 4): out[2m] = .75 x[m-1] + .25 x[m],
+// out[2m+1] = .25 x[m-1] + .75 x[m]; taps t[dy*2+dx] = yprev[my-1+dy][mx-1+dx] (clamped loads, zero weight outside)
+__device__ __forceinline__ float trgb_skip(const float t[4], int oy, int ox) {
+    const int my = oy >> 1, mx = ox >> 1;
+    const float wy0 = (oy & 1) ? 0.25f : 0.75f, wx0 = (ox & 1) ? 0.25f : 0.75f;
+    float s = 0.f;
+    s += ((my >= 1 && mx >= 1) ? wy0 * wx0 : 0.f) * t[0];
+    s += (my >= 1 ? wy0 * (1.f - wx0) : 0.f) * t[1];
+    s += (mx >= 1 ? (1.f - wy0) * wx0 : 0.f) * t[2];
+    s += (1.f - wy0) * (1.f - wx0) * t[3];
+    return s;
+}
+
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * GLASS_SQRT2; }
 
 // Parameters of one convolution launch (implicit GEMM, NHWC fp16 activations).
@@ -74,6 +102,9 @@ struct ConvParams {
     int trgb_smax_stride;
     const float* trgb_yprev;// [B][3][Ho/2][Wo/2] skip image of the previous block (nullable)
     float* trgb_yout;       // [B][3][Ho][Wo]
+    const half_t* trgb_tab; // conv_tiled / conv_glds (their output map IS stored too): [B][2][16][Neff] fp16 weight tables from
+                            // launch_trgb_tables (the MFMA A operand of the 1x1 conv in accumulator-lane channel order)
+    int dry_run;            // conv_tiled / conv_glds launchers: report the kernel that would run, launch nothing
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout

@@ -34,7 +34,8 @@ struct Geo {
     static constexpr int OFF_B = 2 * A_BYTES;
     static constexpr int OFF_C = OFF_B + 3 * (3 * NT * 64);      // epilogue constants [3][NT] floats
     static constexpr int OFF_S = OFF_C + 3 * NT * 4;             // this sample's style row, Cin <= 1024 halfs
-    static constexpr int LDS_BYTES = OFF_S + 2048;
+    static constexpr int OFF_T = OFF_S + 2048;                   // TRGB: compact toRGB weight rows [hi r,g,b | lo r,g,b][NT] fp16
+    static constexpr int LDS_BYTES = OFF_T + 6 * NT * 2;
 };
 constexpr int NB = 3 * NT * 4 / NTHR;                    // 3 DMA loads per thread per stage
 constexpr int B_BYTES = 3 * NT * 64;                     // 24576
@@ -59,7 +60,8 @@ __device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8}: the que
 }
 }  // namespace
 
-template <int TW>
+// TRGB (TW = 32, one n tile = all output channels): toRGB + skip-image sum applied to the finished tile in registers (common.h).
+template <int TW, bool TRGB = false>
 __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     using G = Geo<TW>;
     constexpr int RW = G::RW, TH = G::TH, PW = G::PW, NVA = G::NVA, NA = G::NA, A_BYTES = G::A_BYTES, OFF_B = G::OFF_B,
@@ -201,11 +203,39 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
         nzr[i] = 0.f;
         if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i * RPL) * p.Wo + ox];
     }
+    float ytap[3][4];                      // TRGB: skip-image taps of this lane's pixel (row kh of the wave's pair, column lr)
+    if (TRGB) {
+        static_assert(!TRGB || (RW == 2 && TW == 32), "lane half kh owns tile row kh of the wave");
+        // the six non-zero rows of the weight table (hi / lo of r, g, b for tile row 0); lanes pick theirs by row below
+        if (t < 6 * (NT / 8)) {
+            const int row6 = t / (NT / 8), piece = t % (NT / 8);
+            const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
+            *(h8*)(smem + G::OFF_T + row6 * (NT * 2) + piece * 16) = *(const h8*)(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8);
+        }
+        if (p.trgb_yprev) {
+            const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+            const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ytap[c][q] = yp[(c * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
+        }
+    }
     if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }
     __syncthreads();                       // every wave is done with the patch / weight images (Os overlays them)
     const int rcs = p.res_cs ? p.res_cs : p.Cout;
+    f16x rgb;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rgb[q] = 0.f;
+    // A-operand row of this lane: n = lr & 15 -> colour n & 3, tile row (n >> 2) & 1, lo part n & 8
+    const int tn = lr & 15;
+    const char* Trow = smem + G::OFF_T + (((tn >> 3) & 1) * 3 + min(tn & 3, 2)) * (NT * 2) + kh * 16;
+    const bool trow_ok = (tn & 3) < 3;
+    const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        h4 va[RW][4];                      // TRGB: the finished quads of this slice, the 1x1 conv's B operand
         h4 rq[4][RW];
         if (p.res) {
 #pragma unroll
@@ -246,7 +276,29 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 #pragma unroll
                 for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
                 *(h4*)(Os + (i * 32 + lr) * OROW + nl * 2) = out;
+                if (TRGB) va[i][g] = out;
             }
+        }
+        if (TRGB) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const h8 wt = *(const h8*)(Trow + ((j * 2 + gp) * 2) * 16);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const h8 wi = (trow_ok && ((tn >> 2) & 1) == i) ? wt : hzero;
+                    rgb = mfma32(wi, __builtin_shufflevector(va[i][2 * gp], va[i][2 * gp + 1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
+                }
+            }
+        }
+    }
+    if (TRGB) {
+        const long long hw = (long long)p.Ho * p.Wo;
+        float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float r = p.trgb_b[c] + (rgb[c] + rgb[4 + c] * (1.f / 2048.f));
+            if (p.trgb_yprev) r += trgb_skip(ytap[c], oyb + kh, ox);
+            yo[c * hw] = r;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -263,19 +315,20 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
     }
 }
 
-template <int TW>
+template <int TW, bool TRGB = false>
 static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const char* name) {
     using G = Geo<TW>;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv_glds_kernel<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_glds_kernel<TW, TRGB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         attr = true;
     }
     const int tiles_x = p.Wc / TW, tiles_y = p.Hc / G::TH;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
-    hipLaunchKernelGGL(conv_glds_kernel<TW>, dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+    if (p.dry_run) return name;
+    hipLaunchKernelGGL((conv_glds_kernel<TW, TRGB>), dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -285,6 +338,10 @@ const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
+    if (p.trgb_yout) {   // fused toRGB: only where one workgroup holds every output channel of its pixels
+        if (!p.trgb_tab || !p.trgb_b || p.Neff != NT || p.Cout != NT || p.Wc % 32 != 0) return nullptr;
+        return launch_glds_inst<32, true>(p, st, "conv_glds_kernel<torgb>");
+    }
     if (p.Wc % 32 == 0) return launch_glds_inst<32>(p, st, "conv_glds_kernel");
     if (p.Wc % 16 == 0) return launch_glds_inst<16>(p, st, "conv_glds_kernel<w16>");
     return nullptr;

@@ -25,7 +25,10 @@
 // PERSIST: the block walks several work items and prefetches the first stage of the next tile during
 // the last MFMA block + store epilogue of the current one (memory-bound small-K layers); otherwise
 // one work item per block (MFMA-bound layers: fewer live registers).
-template <int KS, int S, int TH, int NT, bool PERSIST = false>
+// TRGB (fast path, TH = 8, one n tile = all output channels): toRGB + skip-image sum of the block (stylegan2/models.py:852-870,
+// 1004-1013) applied to the finished tile while it is in registers (common.h: 2 MFMAs per 32 channels per tile row) — the
+// separate toRGB pass would re-read the whole map.
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = TH / 4;                 // tile rows per wave
     constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     if (id >= n_work) return;
     // per-channel epilogue constants of this block's n tile (demod scale, bias, shift) are parked in LDS by the epilogue
     // prologue: one batched round trip instead of one per accumulator quad
-    const bool fast = !PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore;
+    const bool fast = TRGB || (!PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore);
     float* Cc = (float*)(smem + CC_OFF);   // [3][NT]
+    char* Tt = smem + CC_OFF + 3 * NT * 4;  // TRGB: this sample's weight tables [2][16][NT] fp16
     aim(cur);
     load_a(0);
     load_b(0, 0);
@@ -253,11 +257,32 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                 nzr[i] = 0.f;
                 if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oy0 + i) * p.Wo + ox];
             }
+            float ytap[3][4];                             // TRGB: skip-image taps of this lane's pixel (tile row kh, column lr)
+            if (TRGB) {
+                static_assert(!TRGB || RW == 2, "lane half kh owns tile row kh of the wave");
+#pragma unroll
+                for (int u = 0; u < (4 * NT + 255) / 256; ++u)
+                    if (t + 256 * u < 4 * NT)
+                        *(h8*)(Tt + (t + 256 * u) * 16) = *(const h8*)(p.trgb_tab + (long long)b * 32 * NT + (t + 256 * u) * 8);
+                if (p.trgb_yprev) {
+                    const int my = (oy0 + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+                    const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ytap[c][q] = yp[(c * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
+                }
+            }
             if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }   // Cc sits behind As / Bs / Os
             __syncthreads();                              // every wave is done reading As / Bs; constants visible
+            f16x rgb;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rgb[q] = 0.f;
             const int rcs = p.res_cs ? p.res_cs : p.Cout;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                h4 va[RW][4];                             // TRGB: the finished quads of this slice, the 1x1 conv's B operand
                 h4 rq[4][RW];                             // residual quads of this 32-channel slice: one batch of loads
                 if (p.res) {
 #pragma unroll
@@ -298,9 +323,29 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
                         for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
                         *(h4*)(Os + (i * 32 + lr) * OROW + nl * 2) = out;
+                        if (TRGB) va[i][g] = out;
                     }
                     __builtin_amdgcn_sched_barrier(0);    // keep one quad's constants live at a time (no hoisting of all
                 }                                         // 16 quads' LDS reads to the top: that spills)
+                if (TRGB) {
+#pragma unroll
+                    for (int i = 0; i < RW; ++i)
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const h8 wt = *(const h8*)(Tt + (i * 16 + (lr & 15)) * (NT * 2) + ((j * 2 + gp) * 2 + kh) * 16);
+                            rgb = mfma32(wt, __builtin_shufflevector(va[i][2 * gp], va[i][2 * gp + 1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
+                        }
+                }
+            }
+            if (TRGB) {
+                const long long hw = (long long)p.Ho * p.Wo;
+                float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oy0 + kh) * p.Wo + ox;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float r = p.trgb_b[c] + (rgb[c] + rgb[4 + c] * (1.f / 2048.f));
+                    if (p.trgb_yprev) r += trgb_skip(ytap[c], oy0 + kh, ox);
+                    yo[c * hw] = r;
+                }
             }
             __builtin_amdgcn_wave_barrier();              // LDS is in-order per wave: only pin the compiler's order
 #pragma unroll
@@ -383,16 +428,16 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
     constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = TH * 32 * (NT * 2 + 16);   // K-loop images | epilogue image
-    constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4;
+    constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST>,
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
@@ -405,7 +450,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static int resident = 0;
     if (!resident) {
         int per_cu = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST>, 256, LDS);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>, 256, LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         hipDeviceProp_t prop;
         int dev = 0;
@@ -417,7 +462,8 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     }
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    if (p.dry_run) return name;
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -426,6 +472,13 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     static const bool no_ts = getenv("GLASS_NO_TSTORE") != nullptr;   // experiment knob
     if (no_ts) p.no_tstore = 1;
     if (p.y32 || !p.y) return nullptr;
+    if (p.trgb_yout) {   // fused toRGB: only where one workgroup holds every output channel of its pixels
+        if (!p.trgb_tab || !p.trgb_b || p.up || p.KS != 3 || p.stride != 1 || p.pad != 1 || p.no_tstore || p.Neff != 64 || p.Cout != 64 ||
+            p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || (p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16) ||
+            (p.x_bstride == 0 && p.B > 1) || (long long)p.H * p.W * p.Cin >= (1LL << 31))
+            return nullptr;
+        return launch_inst<3, 1, 8, 64, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,torgb>");
+    }
     if ((p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16)) return nullptr;   // fp16 tables not provided: direct path
     if (p.x_bstride == 0 && p.B > 1) return nullptr;  // broadcast input (4x4 const): direct path
     if (p.Cin % 32 != 0 || p.Wc % 32 != 0 || p.Cout % 4 != 0) return nullptr;

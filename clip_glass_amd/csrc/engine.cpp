@@ -536,6 +536,7 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_s, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_s16, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
+    if ((rc = dev_alloc(e, &e->d_trgb_tab, (size_t)P * 32 * 128))) return rc;
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
     for (auto& g : e->gconv) {
@@ -841,7 +842,8 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     char tag[48];
     int gi = b_lo == 0 ? 0 : 1 + 2 * (b_lo - 1);
     int yi = 0;
-    static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knob
+    static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
+    static const bool no_trgb_mid = getenv("GLASS_NO_TRGB_MID") != nullptr;
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
         bool rgb_done = false;
@@ -888,24 +890,48 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
                                  2.0 * 9 * g.cin * p.Neff;
             snprintf(tag, sizeof tag, "G.%s.r%d.%dx%d", g.up ? "upconv" : "conv", g.res_out, g.cin, g.cout);
-            if (b == c.n_blocks - 1 && l == nl - 1 && !g.up && !no_trgb_fuse) {
-                // the network's last conv feeds toRGB only: conv_stream<torgb> applies it to the tile in its accumulators and
-                // writes the skip image; the 64-byte-per-pixel feature map never goes to HBM
+            if (l == nl - 1 && !g.up && !no_trgb_fuse) {
+                // toRGB of the block fused into its last conv (common.h).  The network's LAST conv feeds toRGB only:
+                // conv_stream<torgb> writes just the skip image and the 64-byte-per-pixel feature map never goes to HBM;
+                // the mid-resolution blocks still store their map (the next block reads it) but toRGB no longer re-reads it.
                 const GRgb& r = e->grgb[b];
                 ConvParams q = p;
-                q.y = nullptr;
                 q.trgb_w = r.w; q.trgb_b = r.bias;
                 q.trgb_sn = e->d_s + (size_t)c0 * e->S_total + r.style_off; q.trgb_sn_stride = e->S_total;
                 q.trgb_smax = e->d_smax + (size_t)c0 * e->n_style + r.style_idx; q.trgb_smax_stride = e->n_style;
                 q.trgb_yprev = yprev; q.trgb_yout = yb[yi];
-                if (conv_stream_applies(q)) {
-                    Prof pr(e, tag, flops + 2.0 * B * (double)r.res * r.res * 3 * r.cin,
-                            2.0 * B * (double)g.res_in * g.res_in * g.cin + B * (double)r.res * r.res * (12.0 + (b ? 3.0 : 0.0)));
-                    const char* k = launch_conv_stream(q, e->cur);
-                    if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
-                    if (e->profiling) e->tag_kernel[tag] = k;
-                    rgb_done = true;
-                    x = nullptr;   // not produced
+                const double tflops = flops + 2.0 * B * (double)r.res * r.res * 3 * r.cin;
+                const double ybytes = B * (double)r.res * r.res * (12.0 + (b ? 3.0 : 0.0));
+                if (b == c.n_blocks - 1) {
+                    q.y = nullptr;
+                    if (conv_stream_applies(q)) {
+                        Prof pr(e, tag, tflops, 2.0 * B * (double)g.res_in * g.res_in * g.cin + ybytes);
+                        const char* k = launch_conv_stream(q, e->cur);
+                        if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                        if (e->profiling) e->tag_kernel[tag] = k;
+                        rgb_done = true;
+                        x = nullptr;   // not produced
+                    }
+                }
+                if (!rgb_done && !no_trgb_mid && r.cin <= 128) {
+                    q.y = out;
+                    q.trgb_tab = e->d_trgb_tab + (size_t)c0 * 32 * 128;
+                    q.dry_run = 1;
+                    const char* k = launch_conv_glds(q, e->cur);
+                    if (!k) k = launch_conv_tiled(q, e->cur);
+                    if (k) {
+                        q.dry_run = 0;
+                        Prof pr(e, tag, tflops, bytes + ybytes);
+                        launch_trgb_tables(q.trgb_w, q.trgb_sn, q.trgb_sn_stride, q.trgb_smax, q.trgb_smax_stride, B, r.cin,
+                                           e->d_trgb_tab + (size_t)c0 * 32 * 128, e->cur);
+                        k = launch_conv_glds(q, e->cur);
+                        if (!k) k = launch_conv_tiled(q, e->cur);
+                        if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                        if (e->profiling) e->tag_kernel[tag] = k;
+                        rgb_done = true;
+                        x = out;
+                        xbs = (long long)g.res_out * g.res_out * g.cout;
+                    }
                 }
             }
             if (rgb_done) { ++gi; break; }

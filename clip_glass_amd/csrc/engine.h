@@ -153,6 +153,7 @@ struct glass_engine {
 
     // ---- activations / scratch ----
     half_t* d_s16 = nullptr;   // fp16 copy of d_s (normalised styles)
+    half_t* d_trgb_tab = nullptr;   // [P][2][16][128] fp16: toRGB weight tables of the fused conv epilogues
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;
     std::vector<float*> d_noise;  // per noise layer: [n_mb_max][res*res]

@@ -354,6 +354,23 @@ void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb
 #undef TORGB_CASE
 }
 
+// toRGB weight tables for the fused conv epilogues (common.h: trgb_channel / trgb_table_value): [B][2][16][NT] fp16
+__global__ __launch_bounds__(256) void trgb_tables_kernel(const float* wrgb, const float* sn, int sn_stride, const float* smax,
+                                                          int smax_stride, int NT, half_t* tab) {
+    const int b = blockIdx.x;
+    const float sm = smax[(long long)b * smax_stride];
+    for (int e = threadIdx.x; e < 32 * NT; e += 256) {
+        const int tsel = e / (16 * NT), n = (e / NT) & 15, hidx = e % NT;
+        const int ch = trgb_channel(hidx), c = n & 3;
+        const float w = c < 3 ? wrgb[c * NT + ch] * sn[(long long)b * sn_stride + ch] * sm : 0.f;
+        tab[(long long)b * 32 * NT + e] = trgb_table_value(tsel, n, w);
+    }
+}
+void launch_trgb_tables(const float* wrgb, const float* sn, int sn_stride, const float* smax, int smax_stride, int B, int NT,
+                        half_t* tab, hipStream_t st) {
+    hipLaunchKernelGGL(trgb_tables_kernel, dim3(B), dim3(256), 0, st, wrgb, sn, sn_stride, smax, smax_stride, NT, tab);
+}
+
 // ---- biggan_norm: utils.py:14-17 ---------------------------------------------------
 __global__ void finalize_image_kernel(const float* y, float* img, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

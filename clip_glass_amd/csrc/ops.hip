@@ -107,14 +107,21 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     float* yrgb = nullptr;
     const size_t nrgb = (size_t)d->B * 3 * d->Ho * d->Wo;
     if (d->trgb_yout) {
-        OPREQ(d->impl == 4 && d->trgb_w && d->trgb_b && d->trgb_sn && d->trgb_smax, "fused toRGB: impl 4 and all of w / b / sn / smax");
+        OPREQ((d->impl == 4 || d->impl == 2 || d->impl == 5) && d->trgb_w && d->trgb_b && d->trgb_sn && d->trgb_smax,
+              "fused toRGB: impl 2 / 4 / 5 and all of w / b / sn / smax");
         p.trgb_w = dv.up32(d->trgb_w, 3 * (size_t)d->Cout); p.trgb_b = dv.up32(d->trgb_b, 3);
         p.trgb_sn = dv.up32(d->trgb_sn, (size_t)d->B * d->Cout); p.trgb_sn_stride = d->Cout;
         p.trgb_smax = dv.up32(d->trgb_smax, d->B); p.trgb_smax_stride = 1;
         p.trgb_yprev = dv.up32(d->trgb_yprev, (size_t)d->B * 3 * (d->Ho / 2) * (d->Wo / 2));
         yrgb = dv.alloc<float>(nrgb);
         p.trgb_yout = yrgb;
-        p.y = nullptr;
+        if (d->impl == 4) {
+            p.y = nullptr;                       // the streaming form never stores the map
+        } else {                                 // tiled / LDS-DMA forms: weight tables from the table kernel
+            half_t* tab = dv.alloc<half_t>((size_t)d->B * 32 * d->Cout);
+            launch_trgb_tables(p.trgb_w, p.trgb_sn, p.trgb_sn_stride, p.trgb_smax, p.trgb_smax_stride, d->B, d->Cout, tab, 0);
+            p.trgb_tab = tab;
+        }
     }
     if (d->impl == 1) launch_conv_direct(p, 0);
     else if (d->impl == 3) {

@@ -31,7 +31,7 @@ typedef struct glass_conv_desc {
     const float* bias;     /* [Cout] or NULL */
     const float* res;      /* [B,Ho,Wo,Cout] or NULL */
     float* y;              /* [B,Ho,Wo,Cout] */
-    /* impl 4 only, all or none: toRGB fused into the conv (the generator's last layer) — y is NOT written, trgb_yout is */
+    /* impl 2 / 4 / 5, all or none: toRGB fused into the conv epilogue — y is NOT returned, trgb_yout is */
     const float* trgb_w;     /* [3,Cout] scaled */
     const float* trgb_b;     /* [3] */
     const float* trgb_sn;    /* [B,Cout] normalised toRGB style */

@@ -121,10 +121,17 @@ def test_conv_stream_fused_torgb(with_skip):
     smax = rng.uniform(0.5, 3.0, B).astype(np.float32)
     yprev = rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32) if with_skip else None
     got = ops.conv(x, w, impl=4, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw)
-    feat = ops.conv(x, w, impl=4, **kw).astype(np.float64)                 # [B,H,W,C], fp16-rounded as the fused kernel sees it
+    feat = ops.conv(x, w, impl=4, **kw)                 # [B,H,W,C], fp16-rounded as the fused kernel sees it
+    ref = _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev)
+    check("conv_stream<torgb>", got, ref, 2e-5)
+
+
+def _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev):
+    """float64 toRGB (stylegan2/models.py:852-870) + FIR-upsampled skip image (modules.py:580-602) of an NHWC map."""
+    B, H, W, _ = feat.shape
     wm = wrgb[None].astype(np.float64) * (srgb.astype(np.float64) * smax[:, None])[:, None, :]    # [B,3,C]
-    ref = np.einsum("bhwc,boc->bohw", feat, wm) + brgb[None, :, None, None]
-    if with_skip:
+    ref = np.einsum("bhwc,boc->bohw", feat.astype(np.float64), wm) + brgb[None, :, None, None]
+    if yprev is not None:
         yp = np.pad(yprev.astype(np.float64), ((0, 0), (0, 0), (1, 0), (1, 0)))       # x[m-1] with zero at m = 0
         a, bq = yp[:, :, :-1], yp[:, :, 1:]                                          # rows m-1, m
         rows = np.empty((B, 3, H, W // 2 + 1))
@@ -135,7 +142,30 @@ def test_conv_stream_fused_torgb(with_skip):
         up[..., 0::2] = 0.75 * a + 0.25 * bq
         up[..., 1::2] = 0.25 * a + 0.75 * bq
         ref = ref + up
-    check("conv_stream<torgb>", got, ref, 2e-5)
+    return ref
+
+
+@pytest.mark.parametrize("impl,C,with_skip", [(2, 64, True), (2, 64, False), (5, 128, True), (5, 128, False)])
+def test_conv_epilogue_fused_torgb(impl, C, with_skip):
+    """conv_tiled<3,1,8,64,torgb> / conv_glds<torgb>: a mid-resolution block's last conv with toRGB + skip sum applied to the
+    tile in registers — against the same kernel's stored fp16 map pushed through a float64 toRGB."""
+    rng = np.random.default_rng(13)
+    B, H, W = 3, 32, 96
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    sn = rng.uniform(0.5, 1.0, (B, C)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, C)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32) * 0.2
+    kw = dict(sn=sn, dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True)
+    wrgb = (rng.standard_normal((3, C)) / math.sqrt(C)).astype(np.float32)
+    brgb = rng.standard_normal(3).astype(np.float32) * 0.1
+    srgb = rng.uniform(0.2, 1.0, (B, C)).astype(np.float32)
+    smax = rng.uniform(0.5, 3.0, B).astype(np.float32)
+    yprev = rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32) if with_skip else None
+    got = ops.conv(x, w, impl=impl, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw)
+    feat = ops.conv(x, w, impl=impl, **kw)
+    check("fused toRGB impl %d" % impl, got, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 64, 128, 128), (3, 16, 32, 256, 256), (1, 64, 64, 160, 128), (5, 16, 16, 256, 256),
