@@ -28,7 +28,9 @@
 // TRGB (fast path, TH = 8, one n tile = all output channels): toRGB + skip-image sum of the block (stylegan2/models.py:852-870,
 // 1004-1013) applied to the finished tile while it is in registers (common.h: 2 MFMAs per 32 channels per tile row) — the
 // separate toRGB pass would re-read the whole map.
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false>
+// SKIP (stride 2, fast path): ConvParams::skip_x / skip_w — the residual branch's 1x1 conv as extra K stages after an in-register
+// activation.
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = TH / 4;                 // tile rows per wave
     constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     if (id >= n_work) return;
     // per-channel epilogue constants of this block's n tile (demod scale, bias, shift) are parked in LDS by the epilogue
     // prologue: one batched round trip instead of one per accumulator quad
-    const bool fast = TRGB || (!PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore);
+    const bool fast = TRGB || SKIP || (!PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore);
     float* Cc = (float*)(smem + CC_OFF);   // [3][NT]
     char* Tt = smem + CC_OFF + 3 * NT * 4;  // TRGB: this sample's weight tables [2][16][NT] fp16
     aim(cur);
@@ -233,8 +235,64 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             ty = nty;
         }
 
-        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ------------------
         const int b = cur.b;
+        if (SKIP) {
+            static_assert(!SKIP || (TH * 32 * 4 <= 2 * 256 && NT * 4 <= NB * 256), "skip stage operands fit the staging registers");
+            // operands of skip stage 0 first (their latency hides under the activation math)
+            const int sv0 = t >> 2;                         // vector k: pixel (sv0 >> 5) + 2k of the tile... TH*32 px, 4 parts
+            auto load_s = [&](int c0) {
+#pragma unroll
+                for (int k = 0; k < TH / 2; ++k) {
+                    const int px = sv0 + 64 * k, row = px >> 5, col = px & 31;
+                    ra[k] = *(const h8*)(p.skip_x + (((long long)b * p.Ho + cur.ty0 + row) * p.Wo + cur.tx0 + col) * p.Cin + c0 + part * 8);
+                }
+#pragma unroll
+                for (int k = 0; k < NT / 64; ++k)
+                    rb[k] = *(const h8*)(p.skip_w + (long long)(cur.n0 + sv0 + 64 * k) * p.Cin + c0 + part * 8);
+            };
+            load_s(0);
+            // activation in the accumulators: lrelu(acc + bias) * sqrt2 (the D path has no demodulation, noise or shift)
+            f4 bq[NJ][4];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bq[j][g] = f4{0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) bq[j][g] = *(const f4*)(p.bias + cur.n0 + j * 32 + 8 * g + 4 * kh);
+                }
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const float v = acc[i][j][q] + bq[j][q >> 2][q & 3];
+                        acc[i][j][q] = p.act == 1 ? lrelu_sqrt2(v) : v;
+                    }
+            for (int cs = 0; cs < n_chunks; ++cs) {
+                __syncthreads();                             // previous stage's fragment reads are done
+#pragma unroll
+                for (int k = 0; k < TH / 2; ++k) *(h8*)(As + (sv0 + 64 * k) * ROWB + part * 16) = ra[k];
+#pragma unroll
+                for (int k = 0; k < NT / 64; ++k) *(h8*)(Bs + (sv0 + 64 * k) * ROWB + part * 16) = rb[k];
+                __syncthreads();
+                if (cs + 1 < n_chunks) load_s((cs + 1) * 32);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    h8 wf[NJ];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) wf[j] = *(const h8*)(Bs + (j * 32 + lr) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        const h8 xf = *(const h8*)(As + ((wave * RW + i) * 32 + lr) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue: lane = one pixel (col lr of tile row), 4 consecutive channels per quad ------------------
         if (fast) {
             // Fast path.  Nothing here waits on a global load it has just issued: the per-channel constants were staged
             // in LDS at kernel start, the noise values and residual quads of a tile row are fetched as one batch, and
@@ -245,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             const int oy0 = cur.ty0 + wave * RW, ox = cur.tx0 + lr;
             // ONE batch of global loads: this thread's per-channel constants (threads < NT) and its pixels' noise values
             float c_d = 1.f, c_b = 0.f, c_s = 0.f;
-            if (t < NT) {
+            if (t < NT && !SKIP) {                         // (SKIP: bias and activation were applied before the skip stages)
                 const int o = cur.n0 + t;
                 if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
                 if (p.bias) c_b = p.bias[o];
@@ -308,10 +366,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                             v[q] += bb[q];
                             v[q] += sh4[q];
                         }
-                        if (p.act == 1) {
+                        if (!SKIP && p.act == 1) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
-                        } else if (p.act == 2) {
+                        } else if (!SKIP && p.act == 2) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
                         }
@@ -428,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
@@ -437,7 +495,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>,
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
@@ -450,7 +508,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static int resident = 0;
     if (!resident) {
         int per_cu = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>, 256, LDS);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>, 256, LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         hipDeviceProp_t prop;
         int dev = 0;
@@ -463,7 +521,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
     if (p.dry_run) return name;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -496,6 +554,14 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
         if ((th4 & 1) && p.Neff % 32 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 32>(p, st, "conv_tiled_kernel<3,1,4,32>");
         if (persist && p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32, true>(p, st, "conv_tiled_kernel<3,1,8,32,persist>");
         if (p.Neff % 32 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 32>(p, st, "conv_tiled_kernel<3,1,8,32>");
+        return nullptr;
+    }
+    if (p.skip_x) {   // skip branch as extra K stages: stride-2 fast path without demodulation / noise / shift / residual
+        if (KS != 3 || S != 2 || p.pad != 0 || !p.skip_w || p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.up ||
+            (p.Cout & 7) || p.no_tstore || p.Hc % 4 != 0)
+            return nullptr;
+        if (p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip>");
+        if (p.Neff % 64 == 0) return launch_inst<3, 2, 4, 64, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,64,skip>");
         return nullptr;
     }
     if (KS == 3 && S == 2 && p.pad == 0) {

@@ -1020,18 +1020,34 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
             Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
             launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->cur);
         }
-        ConvParams s = conv_defaults();
-        s.x = XS; s.x_bstride = (long long)r2 * r2 * d.cin; s.B = B; s.H = s.W = r2; s.Cin = d.cin;
-        s.Hc = s.Wc = r2; s.KS = 1; s.pad = 0; s.w = d.wskip; s.Cout = s.Neff = d.cout; s.Ho = s.Wo = r2; s.y = S;
-        snprintf(tag, sizeof tag, "D.skip.r%d.%dx%d", r2, d.cin, d.cout);
-        run_conv(e, s, tag, 2.0 * B * (double)r2 * r2 * d.cin * d.cout, 2.0 * B * (double)r2 * r2 * (d.cin + d.cout));
         ConvParams q = conv_defaults();
         q.x = HB; q.x_bstride = (long long)(r + 1) * (r + 1) * d.cin; q.B = B; q.H = q.W = r + 1; q.Cin = d.cin;
         q.Hc = q.Wc = r2; q.KS = 3; q.stride = 2; q.pad = 0; q.w = d.w1; q.Cout = q.Neff = d.cout; q.Ho = q.Wo = r2;
-        q.bias = d.b1; q.act = 1; q.res = S; q.out_scale = 0.70710678118654752440f; q.y = O;
+        q.bias = d.b1; q.act = 1; q.out_scale = 0.70710678118654752440f; q.y = O;
         snprintf(tag, sizeof tag, "D.conv1.r%d.%dx%d", r2, d.cin, d.cout);
-        run_conv(e, q, tag, 2.0 * B * (double)r2 * r2 * 9 * d.cin * d.cout,
-                 2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + 2.0 * r2 * r2 * d.cout));
+        const double f1 = 2.0 * B * (double)r2 * r2 * 9 * d.cin * d.cout, fs = 2.0 * B * (double)r2 * r2 * d.cin * d.cout;
+        {   // skip branch as extra K stages of the stride-2 conv (conv_tiled<3,2,4,N,skip>) where that kernel applies
+            static const bool no_skip_fuse = getenv("GLASS_NO_SKIP_FUSE") != nullptr;   // A/B knob
+            ConvParams qs = q;
+            qs.skip_x = XS; qs.skip_w = d.wskip; qs.dry_run = 1;
+            if (!no_skip_fuse && launch_conv_tiled(qs, e->cur)) {
+                qs.dry_run = 0;
+                Prof pr(e, tag, f1 + fs, 2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + (double)r2 * r2 * (d.cin + d.cout)));
+                const char* k = launch_conv_tiled(qs, e->cur);
+                if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                if (e->profiling) e->tag_kernel[tag] = k;
+                std::swap(X, O);
+                continue;
+            }
+        }
+        ConvParams s = conv_defaults();
+        s.x = XS; s.x_bstride = (long long)r2 * r2 * d.cin; s.B = B; s.H = s.W = r2; s.Cin = d.cin;
+        s.Hc = s.Wc = r2; s.KS = 1; s.pad = 0; s.w = d.wskip; s.Cout = s.Neff = d.cout; s.Ho = s.Wo = r2; s.y = S;
+        char stag[64];
+        snprintf(stag, sizeof stag, "D.skip.r%d.%dx%d", r2, d.cin, d.cout);
+        run_conv(e, s, stag, fs, 2.0 * B * (double)r2 * r2 * (d.cin + d.cout));
+        q.res = S;
+        run_conv(e, q, tag, f1, 2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + 2.0 * r2 * r2 * d.cout));
         std::swap(X, O);
     }
     return X;

@@ -13,10 +13,34 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// One wave per row; two-pass mean/variance in fp32 (clip/model.py:152-158, eps 1e-5).
+// One wave per row; two-pass mean/variance in fp32 (clip/model.py:152-158, eps 1e-5).  Rows up to 1024 wide are read from
+// global memory ONCE and held in registers (16 values per lane) for the three passes.
 template <typename LoadF>
 __device__ __forceinline__ void ln_row(LoadF load, int D, const float* g, const float* b, half_t* o16, float* o32) {
     const int lane = threadIdx.x & 63;
+    if (D <= 1024) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = lane + 64 * k < D ? load(lane + 64 * k) : 0.f;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += v[k];
+        const float mean = wsum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float d = lane + 64 * k < D ? v[k] - mean : 0.f; q += d * d; }
+        const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = lane + 64 * k;
+            if (i < D) {
+                const float o = (v[k] - mean) * rstd * g[i] + b[i];
+                if (o16) o16[i] = (half_t)o;
+                if (o32) o32[i] = o;
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int i = lane; i < D; i += 64) s += load(i);
     const float mean = wsum(s) / (float)D;

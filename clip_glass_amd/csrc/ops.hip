@@ -104,6 +104,13 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     half_t* y = dv.alloc<half_t>(nout);
     p.y = y;
     OPREQ(p.x && p.w && y, "device allocation failed");
+    if (d->skip_x) {
+        OPREQ(d->skip_w && d->impl == 2, "fused skip branch: impl 2 with skip_x and skip_w");
+        std::vector<_Float16> pks;
+        glass_pack_conv(d->skip_w, d->Cout, d->Cin, 1, d->Cin, pks);
+        p.skip_w = dv.up16v(pks);
+        p.skip_x = dv.up16(d->skip_x, (size_t)d->B * d->Ho * d->Wo * d->Cin);
+    }
     float* yrgb = nullptr;
     const size_t nrgb = (size_t)d->B * 3 * d->Ho * d->Wo;
     if (d->trgb_yout) {

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
                 ("res", C.POINTER(C.c_float)), ("y", C.POINTER(C.c_float)),
                 ("trgb_w", C.POINTER(C.c_float)), ("trgb_b", C.POINTER(C.c_float)), ("trgb_sn", C.POINTER(C.c_float)),
                 ("trgb_smax", C.POINTER(C.c_float)), ("trgb_yprev", C.POINTER(C.c_float)),
-                ("trgb_yout", C.POINTER(C.c_float))]
+                ("trgb_yout", C.POINTER(C.c_float)),
+                ("skip_x", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float))]
 
 
 def _opt(a):
@@ -34,7 +35,7 @@ def _opt(a):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None):
+         torgb=None, skip=None):
     """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout].
     torgb = dict(w [3,Cout], b [3], sn [B,Cout], smax [B], yprev [B,3,Ho/2,Wo/2] or None) with impl=4: the fused conv + toRGB
     form of the streaming kernel — returns the skip image [B,3,Ho,Wo] instead of y."""
@@ -60,6 +61,11 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
         a, p = _opt(val)
         keep.append(a)
         if p is not None:
+            setattr(d, name, p)
+    if skip is not None:      # (skip_x [B,Ho,Wo,Cin], skip_w [Cout,Cin,1,1]): the D block's 1x1 skip conv fused as extra K stages
+        for name, val in zip(("skip_x", "skip_w"), skip):
+            a, p = _opt(val)
+            keep.append(a)
             setattr(d, name, p)
     yrgb = None
     if torgb is not None:

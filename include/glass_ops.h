@@ -38,6 +38,9 @@ typedef struct glass_conv_desc {
     const float* trgb_smax;  /* [B] */
     const float* trgb_yprev; /* [B,3,Ho/2,Wo/2] or NULL */
     float* trgb_yout;        /* [B,3,Ho,Wo] */
+    /* impl 2, stride 2, both or none: the D block's skip branch as extra K stages — y = (act(conv + bias) + conv1x1(skip_x)) * out_scale */
+    const float* skip_x;     /* [B,Ho,Wo,Cin] */
+    const float* skip_w;     /* [Cout,Cin,1,1] reference layout, un-scaled */
 } glass_conv_desc;
 
 int glass_op_conv(int32_t device, const glass_conv_desc* d);
