@@ -104,6 +104,10 @@ struct ConvParams {
     float* trgb_yout;       // [B][3][Ho][Wo]
     const half_t* trgb_tab; // conv_tiled / conv_glds (their output map IS stored too): [B][2][16][Neff] fp16 weight tables from
                             // launch_trgb_tables (the MFMA A operand of the 1x1 conv in accumulator-lane channel order)
+    // upfir only: per-(sample, channel) factor applied to the finished output — the NEXT layer's style, so that the consumer runs
+    // without its activation-side modulation (x * s is the same product wherever it is formed)
+    const half_t* post_scale16;   // [B][post_stride] (nullable)
+    int post_stride;
     // conv_tiled stride 2 only: the D block's skip branch (1x1 conv of the down-sampled block input, modules.py:1238-1254) as extra
     // K stages of the same kernel — after the 3x3 stages the activation is applied IN the accumulators and the skip MFMAs land on
     // top of it (no separate 1x1 pass, no fp16 round trip of its result)

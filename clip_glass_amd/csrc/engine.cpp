@@ -844,9 +844,10 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     int yi = 0;
     static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
     static const bool no_trgb_mid = getenv("GLASS_NO_TRGB_MID") != nullptr;
+    static const bool no_pre_style = getenv("GLASS_NO_PRE_STYLE") != nullptr;
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
-        bool rgb_done = false;
+        bool rgb_done = false, pre_styled = false;
         for (int l = 0; l < nl; ++l, ++gi) {
             const GConv& g = e->gconv[gi];
             ConvParams p = conv_defaults();
@@ -883,6 +884,20 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
                 p.w_bstride = g.welems;
                 if (g.up) { p.w_up = g.wm + (size_t)c0 * g.welems; p.w = nullptr; }
                 else p.w = g.wm + (size_t)c0 * g.welems;
+            }
+            // upconv -> conv link: the up-conv's only consumer is the block's second conv, so (where the fused up-conv kernel
+            // runs and that conv modulates on the activation side) its style is applied once, to the up-conv's output
+            if (pre_styled) { p.sn = nullptr; p.sn16 = nullptr; pre_styled = false; }
+            if (g.up && l == 0 && nl == 2 && !no_pre_style && !e->gconv[gi + 1].premod && !e->gconv[gi + 1].up) {
+                ConvParams dq = p;
+                dq.dry_run = 1;
+                dq.y = pp[0];
+                if (launch_upconv_fused(dq, e->cur)) {
+                    const GConv& g2 = e->gconv[gi + 1];
+                    p.post_scale16 = e->d_s16 + (size_t)c0 * e->S_total + g2.style_off;
+                    p.post_stride = e->S_total;
+                    pre_styled = true;
+                }
             }
             half_t* out = pp[(x == pp[0]) ? 1 : 0];
             p.y = out;

@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
         bq0 = *(const f4*)(p.bias + n0 + cg * 8);
         bq1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
     }
+    h8 ps8;                                           // the consumer's style for this thread's 8 channels (or 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ps8[j] = (half_t)1.f;
+    if (p.post_scale16) ps8 = *(const h8*)(p.post_scale16 + (long long)b * p.post_stride + n0 + cg * 8);
     float nzv[12];
 #pragma unroll
     for (int r = 0; r < 12; ++r) nzv[r] = 0.f;
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
             if (tyi * 12 + (r - 4) < p.Ho) {
                 const h8 bn = bias8 + (half_t)(p.noise_strength * nzv[r - 4]);
                 h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
-                *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2);
+                *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * ps8;
             }
             yp += rowpitch;
         }
@@ -271,6 +275,7 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Cout / 32;
     const int PT8 = (PT + 7) / 8 * 8;
+    if (p.dry_run) return "upfir_kernel";
     hipLaunchKernelGGL(upfir_kernel, dim3(PT8 * NTn), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return "upfir_kernel";
 }
