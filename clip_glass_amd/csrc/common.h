@@ -128,6 +128,8 @@ struct GemmParams {
     half_t* out16;
     float* out32;
     int ldo;
+    int kpt;                // 0: w rows are K long.  > 0: w is a packed conv weight [K / kpt][N][kpt] (K steps never straddle a tap)
+    long long w_tap_stride; // elements between the taps of such a weight
     int batch;              // 0/1: single problem; >1: blockIdx.z walks problems a_bs / w_bs / o_bs elements apart
     long long a_bs, w_bs, o_bs;
 };

@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     const half_t* ap = p.a + (long long)m * p.K + kh * 8;
-    const half_t* wp = p.w + (long long)(n0 + r) * p.K + kh * 8;
+    const int rs = p.kpt ? p.kpt : p.K;
     for (int k0 = 0; k0 < p.K; k0 += 16) {
+        const half_t* wp = (p.kpt ? p.w + (long long)(k0 / p.kpt) * p.w_tap_stride + (k0 % p.kpt) - k0 : p.w) + (long long)(n0 + r) * rs + kh * 8;
         h8 a;
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = (half_t)0.f;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_direct_kernel(GemmParams p) {
             h8 bf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) bf[j] = (half_t)0.f;
-            if (n0 + nw * 32 + r < p.N) bf = *(const h8*)(wp + (long long)nw * 32 * p.K + k0);
+            if (n0 + nw * 32 + r < p.N) bf = *(const h8*)(wp + (long long)nw * 32 * rs + k0);
             acc[nw] = mfma32(a, bf, acc[nw]);
         }
     }

@@ -1,0 +1,98 @@
+// conv_gemm.hip — the low-resolution layers (conv grid <= 16 x 16: 4x4 .. 16x16 maps of 512 channels) as im2col + the LDS-tiled
+// GEMM + a finishing pass.
+//
+// These layers are 3 % of the FLOPs but cost 5 % of the pass on conv_direct.hip, whose lanes fetch every operand fragment from
+// global memory themselves (1.25 loads per MFMA, no LDS re-use: 24 - 200 TFLOP/s).  With 64 candidates the whole population's
+// conv grid is only M = 1024 .. 4096 rows, so the patch matrix A[M][9 Cin] is a 9 - 38 MB scratch buffer (written and read once,
+// ~20 us of HBM time) and the product runs on gemm_tiled.hip's 128-row tiles straight from the conv weights in their packed
+// [tap][n][Cin] layout (GemmParams::kpt).  The epilogue (demodulation, noise, bias, activation, residual, depth-to-space of the
+// folded up-conv) is the same arithmetic as conv_direct's, applied to the fp32 product.
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+#include <string.h>
+
+// A[m][tap][ci] = x[b][oy * stride + ty - pad][ox * stride + tx - pad][ci] * style[b][ci]   (zero outside the image)
+__global__ __launch_bounds__(256) void conv_im2col_kernel(ConvParams p, half_t* A, long long n_vec) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;      // one 8-channel vector of A
+    if (idx >= n_vec) return;
+    const int c8n = p.Cin >> 3, taps = p.KS * p.KS;
+    const int c8 = (int)(idx % c8n);
+    const long long mt = idx / c8n;
+    const int tap = (int)(mt % taps);
+    const long long m = mt / taps;
+    const int hw = p.Hc * p.Wc;
+    const int b = (int)(m / hw), rem = (int)(m - (long long)b * hw);
+    const int oy = rem / p.Wc, ox = rem - oy * p.Wc;
+    const int ty = tap / p.KS, tx = tap - ty * p.KS;
+    const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
+    h8 a = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        a = *(const h8*)(p.x + (long long)b * p.x_bstride + ((long long)iy * p.W + ix) * p.Cin + c8 * 8);
+        if (p.sn) {      // (half)(x * s): conv_direct's rounding
+            const float* s = p.sn + (long long)b * p.sn_stride + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (half_t)((float)a[j] * s[j]);
+        }
+    }
+    *(h8*)(A + idx * 8) = a;
+}
+
+// y = epilogue(C[m][n]) for 4 consecutive n per thread — conv_direct.hip's epilogue contract
+__global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const float* C, long long n_quad) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_quad) return;
+    const int nq = p.Neff >> 2;
+    const int n = (int)(idx % nq) * 4;
+    const long long m = idx / nq;
+    const int hw = p.Hc * p.Wc;
+    const int b = (int)(m / hw), rem = (int)(m - (long long)b * hw);
+    int py = rem / p.Wc, px = rem - py * p.Wc, o = n;
+    if (p.up) {
+        const int ph = n / p.Cout;
+        o = n - ph * p.Cout;
+        py = 2 * py + (ph >> 1);
+        px = 2 * px + (ph & 1);
+    }
+    const f4 c = *(const f4*)(C + m * p.Neff + n);
+    const float nz = p.noise ? p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px] : 0.f;
+    const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
+    h4 r = {0, 0, 0, 0};
+    if (p.res) {
+        const int rcs = p.res_cs ? p.res_cs : p.Cout;
+        r = *(const h4*)(p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (py >> 1)) * (p.Wo >> 1) + (px >> 1)) * rcs + o
+                                           : (((long long)b * p.Ho + py) * p.Wo + px) * rcs + o));
+    }
+    h4 out;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = c[q];
+        if (p.dscale) v *= p.dscale[(long long)b * p.ds_stride + o + q];
+        v += nz;
+        if (p.bias) v += p.bias[o + q];
+        if (p.shift) v += p.shift[(long long)b * p.ds_stride + o + q];
+        if (p.act == 1) v = lrelu_sqrt2(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (p.res) v += (float)r[q];
+        out[q] = (half_t)(v * p.out_scale);
+    }
+    *(h4*)(p.y + oidx) = out;
+}
+
+const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
+    static const bool off = getenv("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
+    if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.pre_shift || p.in_up || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
+    if ((p.KS != 1 && p.KS != 3) || p.Cin % 64 != 0 || p.Neff % 64 != 0 || (p.Cout & 3) || (p.res_cs & 3)) return nullptr;
+    const long long M = (long long)p.B * p.Hc * p.Wc, K = (long long)p.KS * p.KS * p.Cin;
+    if (M < 64 || M * K > cap_a || M * p.Neff > cap_c || M * K >= (1LL << 31)) return nullptr;
+    const long long n_vec = M * K / 8, n_quad = M * p.Neff / 4;
+    hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
+    GemmParams g;
+    memset(&g, 0, sizeof g);
+    g.a = ws_a; g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
+    g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]
+    g.mode = 3; g.out32 = ws_c; g.ldo = p.Neff;
+    if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+    hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n_quad + 255) / 256)), dim3(256), 0, st, p, ws_c, n_quad);
+    return "conv_gemm(im2col+gemm_tiled+finish)";
+}

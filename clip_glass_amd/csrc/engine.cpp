@@ -537,6 +537,14 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_s16, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_trgb_tab, (size_t)P * 32 * 128))) return rc;
+    {   // low-resolution layers as im2col + GEMM: conv grids up to 8 x 8 per candidate (4x4 .. 16x16 maps), widest channel count
+        int cmax = 16;
+        for (int i = 0; i < e->cfg.n_blocks; ++i) cmax = std::max(cmax, (int)e->cfg.channels[i]);
+        e->cap_a = (long long)P * 64 * 9 * cmax;
+        e->cap_c = (long long)P * 64 * 4 * cmax;
+        if ((rc = dev_alloc(e, &e->ws_a, (size_t)e->cap_a))) return rc;
+        if ((rc = dev_alloc(e, &e->ws_c, (size_t)e->cap_c))) return rc;
+    }
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
     for (auto& g : e->gconv) {
@@ -741,6 +749,7 @@ void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flop
     if (!k) k = launch_conv_stream(p, e->cur);
     if (!k) k = launch_conv_glds(p, e->cur);
     if (!k) k = launch_conv_tiled(p, e->cur);
+    if (!k) k = launch_conv_gemm(p, e->ws_a, e->cap_a, e->ws_c, e->cap_c, e->cur);
     if (!k) k = launch_conv_direct(p, e->cur);
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
     if (e->profiling) e->tag_kernel[tag] = k;

@@ -153,6 +153,9 @@ struct glass_engine {
 
     // ---- activations / scratch ----
     half_t* d_s16 = nullptr;   // fp16 copy of d_s (normalised styles)
+    half_t* ws_a = nullptr;   // conv_gemm.hip scratch: patch matrix of a low-resolution layer (cap_a halfs) and its fp32 product (cap_c)
+    float* ws_c = nullptr;
+    long long cap_a = 0, cap_c = 0;
     half_t* d_trgb_tab = nullptr;   // [P][2][16][128] fp16: toRGB weight tables of the fused conv epilogues
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;

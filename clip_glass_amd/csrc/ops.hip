@@ -137,6 +137,11 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         if (!launch_conv_tiled(p, 0)) { glass_set_error("tiled conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 4) {
         if (!launch_conv_stream(p, 0)) { glass_set_error("streaming conv: unsupported shape"); return GLASS_ERR_ARG; }
+    } else if (d->impl == 6) {
+        const long long M = (long long)p.B * p.Hc * p.Wc, cap_a = M * p.KS * p.KS * p.Cin, cap_c = M * p.Neff;
+        half_t* wa = dv.alloc<half_t>((size_t)cap_a);
+        float* wc = dv.alloc<float>((size_t)cap_c);
+        if (!launch_conv_gemm(p, wa, cap_a, wc, cap_c, 0)) { glass_set_error("im2col + GEMM conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 5) {
         if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);

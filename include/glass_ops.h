@@ -21,7 +21,7 @@ typedef struct glass_conv_desc {
     int32_t broadcast_x;   /* x is [1,H,W,Cin], shared by all B (the learned const) */
     int32_t act;           /* leaky-relu 0.2 * sqrt(2) */
     int32_t batch_size;    /* candidates per noise plane */
-    int32_t impl;          /* 0 auto, 1 direct, 2 tiled, 3 fused up-conv, 4 streaming 32->32 (error if unsupported) */
+    int32_t impl;          /* 0 auto, 1 direct, 2 tiled, 3 fused up-conv, 4 streaming 32->32, 5 LDS-DMA, 6 im2col + GEMM (error if unsupported) */
     float noise_strength, out_scale;
     const float* x;        /* [B,H,W,Cin] */
     const float* w;        /* reference layout [Cout,Cin,KS,KS], un-scaled (coef applied inside) */

@@ -148,6 +148,39 @@ def test_conv_stride2_fused_skip(B, R, Cin, Cout):
     check("stride-2 conv + fused skip vs two passes", got, ref2, 3e-3)
 
 
+@pytest.mark.parametrize("case", ["conv8", "up8", "down17", "skip1x1", "const4"])
+def test_conv_gemm_matches_direct(case):
+    """conv_gemm.hip (im2col + gemm_tiled + finishing pass) for the low-resolution layers against conv_direct: modulated 3x3,
+    folded up-conv with depth-to-space, stride-2 with residual, 1x1, broadcast (learned const) input."""
+    rng = np.random.default_rng(23)
+    B, C = 6, 128
+    kw = {}
+    if case == "conv8":
+        x = rng.standard_normal((B, 8, 8, C)); w = rng.standard_normal((C, C, 3, 3))
+        kw = dict(sn=rng.uniform(0.3, 1.0, (B, C)), dscale=rng.uniform(0.5, 2.0, (B, C)), noise=rng.standard_normal((B // 2, 8, 8)),
+                  noise_strength=0.4, batch_size=2, bias=rng.standard_normal(C) * 0.2, act=True)
+    elif case == "up8":
+        x = rng.standard_normal((B, 8, 8, C)); w = rng.standard_normal((64, C, 3, 3))
+        kw = dict(up=True, sn=rng.uniform(0.3, 1.0, (B, C)), dscale=rng.uniform(0.5, 2.0, (B, 64)), noise=rng.standard_normal((B, 16, 16)),
+                  noise_strength=0.4, batch_size=1, bias=rng.standard_normal(64) * 0.2, act=True)
+    elif case == "down17":
+        x = rng.standard_normal((B, 17, 17, C)); w = rng.standard_normal((2 * C, C, 3, 3))
+        kw = dict(stride=2, pad=0, bias=rng.standard_normal(2 * C) * 0.2, act=True, res=rng.standard_normal((B, 8, 8, 2 * C)), out_scale=2.0 ** -0.5)
+    elif case == "skip1x1":
+        x = rng.standard_normal((B, 8, 8, C)); w = rng.standard_normal((2 * C, C, 1, 1))
+        kw = dict(pad=0)
+    else:
+        x = rng.standard_normal((1, 4, 4, C)); w = rng.standard_normal((C, C, 3, 3))
+        kw = dict(broadcast_x=True, B=16, sn=rng.uniform(0.3, 1.0, (16, C)), dscale=rng.uniform(0.5, 2.0, (16, C)), bias=rng.standard_normal(C) * 0.2, act=True)
+    kw = {k: (np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    if "res" in kw:
+        kw["res"] = kw["res"].astype(np.float16).astype(np.float32)
+    x = x.astype(np.float16).astype(np.float32); w = w.astype(np.float32)
+    got = ops.conv(x, w, impl=6, **kw)
+    ref = ops.conv(x, w, impl=1, **kw)
+    check("conv_gemm %s vs direct" % case, got, ref, 2e-3)
+
+
 def _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev):
     """float64 toRGB (stylegan2/models.py:852-870) + FIR-upsampled skip image (modules.py:580-602) of an NHWC map."""
     B, H, W, _ = feat.shape
