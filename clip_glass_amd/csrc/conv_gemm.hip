@@ -79,18 +79,20 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
     *(h4*)(p.y + oidx) = out;
 }
 
+// cap_a / cap_c: scratch capacity PER CANDIDATE (halfs of A, floats of C); the buffers hold p.B candidates
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
     static const bool off = getenv("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
     if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.pre_shift || p.in_up || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
     if ((p.KS != 1 && p.KS != 3) || p.Cin % 64 != 0 || p.Neff % 64 != 0 || (p.Cout & 3) || (p.res_cs & 3)) return nullptr;
     const long long M = (long long)p.B * p.Hc * p.Wc, K = (long long)p.KS * p.KS * p.Cin;
-    if (M < 64 || M * K > cap_a || M * p.Neff > cap_c || M * K >= (1LL << 31)) return nullptr;
+    if ((long long)p.Hc * p.Wc * K > cap_a || (long long)p.Hc * p.Wc * p.Neff > cap_c || M * K >= (1LL << 31)) return nullptr;
     const long long n_vec = M * K / 8, n_quad = M * p.Neff / 4;
     hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
     GemmParams g;
     memset(&g, 0, sizeof g);
     g.a = ws_a; g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
-    g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]
+    g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]; (kpt: any M is accepted —
+                                                                      // the kernel choice must not depend on the candidate count)
     g.mode = 3; g.out32 = ws_c; g.ldo = p.Neff;
     if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
     hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n_quad + 255) / 256)), dim3(256), 0, st, p, ws_c, n_quad);

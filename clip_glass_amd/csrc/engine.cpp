@@ -158,6 +158,10 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     // two-stream overlap is worth +3 % throughput but stretches every co-running kernel ~2x, which makes
     // per-kernel profiles (rocprof, roofline) meaningless: opt-in (GLASS_OVERLAP=1 / glass_engine_set_overlap)
     e->overlap = getenv("GLASS_OVERLAP") != nullptr;
+    // CLIP's image tower (short, latency-bound launches: 2.2 ms of a mostly idle GPU) on the second stream next to the
+    // discriminator, which only shares the finished image with it
+    // (default; GLASS_NO_CLIP_OVERLAP=1 / glass_engine_set_overlap(e, 0) put everything on one stream)
+    e->clip_overlap = getenv("GLASS_NO_CLIP_OVERLAP") == nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream_d, hipStreamNonBlocking);
     e->cur = e->stream;
@@ -537,13 +541,16 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_s16, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_trgb_tab, (size_t)P * 32 * 128))) return rc;
-    {   // low-resolution layers as im2col + GEMM: conv grids up to 8 x 8 per candidate (4x4 .. 16x16 maps), widest channel count
+    if (e->cfg.generator != GLASS_GEN_BIGGAN_DEEP && e->cfg.n_blocks > 0) {
+        // StyleGAN2's low-resolution layers as im2col + GEMM (conv_gemm.hip): conv grids up to 16 x 16 per candidate, widest
+        // channel count (151 + 134 MB at P = 64).  The capacities are per candidate: whether a layer takes this path must not
+        // depend on how many candidates a launch carries (results are chunking- and sharding-invariant to the bit).
         int cmax = 16;
         for (int i = 0; i < e->cfg.n_blocks; ++i) cmax = std::max(cmax, (int)e->cfg.channels[i]);
-        e->cap_a = (long long)P * 64 * 9 * cmax;
-        e->cap_c = (long long)P * 64 * 4 * cmax;
-        if ((rc = dev_alloc(e, &e->ws_a, (size_t)e->cap_a))) return rc;
-        if ((rc = dev_alloc(e, &e->ws_c, (size_t)e->cap_c))) return rc;
+        e->cap_a = 256LL * 9 * cmax;
+        e->cap_c = 256LL * 4 * cmax;
+        if ((rc = dev_alloc(e, &e->ws_a, (size_t)(e->cap_a * P)))) return rc;
+        if ((rc = dev_alloc(e, &e->ws_c, (size_t)(e->cap_c * P)))) return rc;
     }
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
@@ -1240,6 +1247,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
         e->ev_d.push_back(b2);
     }
     const bool overlap = e->overlap && out_F;
+    const bool clip_ov = e->clip_overlap && !overlap && out_F && want_d;
     hipStream_t sd = overlap ? e->stream_d : e->stream;
     for (int c0 = 0, k = 0; c0 < P; c0 += e->chunk, ++k) {
         const int B = std::min(e->chunk, P - c0);
@@ -1269,6 +1277,14 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
                 launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
                                       e->cur);
             }
+            if (clip_ov && c0 + e->chunk >= P) {   // last chunk's patches are in place: CLIP starts now on the second stream
+                GLASS_HIP(hipEventRecord(e->ev_g[0], e->stream));
+                GLASS_HIP(hipStreamWaitEvent(e->stream_d, e->ev_g[0], 0));
+                e->cur = e->stream_d;
+                run_clip(e, P);
+                GLASS_HIP(hipEventRecord(e->ev_d[0], e->stream_d));
+                e->cur = e->stream;
+            }
             if (want_d) {
                 if (d_hi > 0) {
                     half_t* const bufs[5] = {e->act[1], e->act[2], e->act[3], e->act[4], e->act[5]};
@@ -1294,7 +1310,8 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
             GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_d[n_chunks - 1], 0));
         }
         e->cur = e->stream;
-        run_clip(e, P);
+        if (clip_ov) GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_d[0], 0));   // join: CLIP finished on the second stream
+        else run_clip(e, P);
         if (overlap) {   // join: D head finished
             GLASS_HIP(hipEventRecord(e->ev_g[0], sd));
             GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_g[0], 0));
@@ -1571,7 +1588,9 @@ extern "C" int glass_engine_set_profiling(glass_engine* e, int32_t on) {
 
 extern "C" int glass_engine_set_overlap(glass_engine* e, int32_t on) {
     REQUIRE(e, GLASS_ERR_ARG, "null engine");
-    e->overlap = on != 0;
+    // 0: one stream; 1: D + CLIP of chunk k under the synthesis of chunk k + 1; 2: CLIP on the second stream next to D (default)
+    e->overlap = on == 1;
+    e->clip_overlap = on == 2;
     return GLASS_OK;
 }
 

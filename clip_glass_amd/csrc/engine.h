@@ -96,7 +96,7 @@ struct glass_engine {
     int chunk = 0;
     bool finalized = false, has_target = false;
     hipStream_t stream = nullptr, stream_d = nullptr, cur = nullptr;  // main, second (D/resize), current target
-    bool overlap = false;
+    bool overlap = false, clip_overlap = false;
     std::vector<hipEvent_t> ev_g, ev_d;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float last_ms = 0.f;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
 }
 
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
-    if (p.K % 64 != 0 || p.ldo % 4 != 0 || p.M < 64 || (p.kpt && p.kpt % 64 != 0)) return nullptr;
+    if (p.K % 64 != 0 || p.ldo % 4 != 0 || (p.M < 64 && !p.kpt) || (p.kpt && p.kpt % 64 != 0)) return nullptr;
     const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
     // 128-wide n tiles under-fill the chip on the N = 768 CLIP linears (25 x 6 = 150 workgroups for 256 CUs): take 64-wide
     // tiles whenever the 128-wide grid has fewer workgroups than CUs

@@ -10,7 +10,7 @@ const char* launch_conv_tiled(const ConvParams& p, hipStream_t st);
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st);
 // persistent streaming 3x3 conv for the 32 -> 32 channel 1024^2 layers (conv_stream.hip); nullptr when unsupported
 const char* launch_conv_stream(const ConvParams& p, hipStream_t st);
-// the low-resolution layers as im2col + gemm_tiled + finishing pass (conv_gemm.hip); ws_a / ws_c: scratch of cap_a halfs / cap_c floats
+// the low-resolution layers as im2col + gemm_tiled + finishing pass (conv_gemm.hip); ws_a / ws_c: scratch of cap_a halfs / cap_c floats PER CANDIDATE
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st);
 bool conv_stream_applies(const ConvParams& p);   // trgb_yout set: the fused conv + toRGB form
 // LDS-DMA staged 3x3 conv for the MFMA-bound mid-resolution layers (conv_glds.hip); nullptr when unsupported / disabled

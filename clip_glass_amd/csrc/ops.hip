@@ -138,9 +138,9 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     } else if (d->impl == 4) {
         if (!launch_conv_stream(p, 0)) { glass_set_error("streaming conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 6) {
-        const long long M = (long long)p.B * p.Hc * p.Wc, cap_a = M * p.KS * p.KS * p.Cin, cap_c = M * p.Neff;
-        half_t* wa = dv.alloc<half_t>((size_t)cap_a);
-        float* wc = dv.alloc<float>((size_t)cap_c);
+        const long long cap_a = (long long)p.Hc * p.Wc * p.KS * p.KS * p.Cin, cap_c = (long long)p.Hc * p.Wc * p.Neff;   // per candidate
+        half_t* wa = dv.alloc<half_t>((size_t)(cap_a * p.B));
+        float* wc = dv.alloc<float>((size_t)(cap_c * p.B));
         if (!launch_conv_gemm(p, wa, cap_a, wc, cap_c, 0)) { glass_set_error("im2col + GEMM conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 5) {
         if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 # single stream + one step: every launch is counted exactly once per kernel instance
-export GLASS_NO_OVERLAP=1 GLASS_BENCH_NOPROF=1
+export GLASS_NO_CLIP_OVERLAP=1 GLASS_BENCH_NOPROF=1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/write.err
 python tools/traffic_table.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv > $OUT/traffic.json
