@@ -816,7 +816,8 @@ static void run_styles(glass_engine* e, int P) {
         launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->cur);
         float *a = e->d_w0, *b = e->d_w1;
         for (int i = 0; i < c.mapping_layers; ++i) {
-            launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->cur);
+            if (L % 64 == 0 && L <= 768) launch_dense_splitk(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 1, e->cur);
+            else launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->cur);
             std::swap(a, b);
         }
         if (a != e->d_w0)  // result must end in d_w0

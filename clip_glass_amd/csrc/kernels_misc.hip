@@ -97,6 +97,56 @@ void launch_dense_multi(const DenseDesc* d_desc, int n_desc, int max_N, int P, i
     dim3 g((max_N + 63) / 64, (P + DENSE_PB - 1) / DENSE_PB, n_desc);
     hipLaunchKernelGGL(dense_multi_kernel, g, dim3(256), 0, st, d_desc, P, in_sq, mode);
 }
+// Mapping-network layers (K = N = latent size, 16 candidates per workgroup): dense_body walks K in ONE chain per thread — 32
+// batches of L2 round trips, 37 us per layer for 34 MFLOP.  Here the four waves of a workgroup each take a quarter of K for all
+// 16 candidates (8 batches) and the partial sums meet in LDS: fixed order (q0 + q1) + (q2 + q3), independent of P.
+__global__ __launch_bounds__(256) void dense_splitk_kernel(const float* x, int ldx, int P, int K, const float* wt, int N,
+                                                           const float* bias, float* out, int ldo, int mode) {
+    extern __shared__ float dsm[];
+    float* xs = dsm;                          // [16][K]
+    float* red = dsm + 16 * K;                // [4][16][64]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = blockIdx.x * 64 + lane, p0 = blockIdx.y * DENSE_PB;
+    for (int e = t; e < DENSE_PB * K; e += 256) {
+        const int pr = e / K, kk = e - pr * K;
+        xs[e] = p0 + pr < P ? x[(long long)(p0 + pr) * ldx + kk] : 0.f;
+    }
+    __syncthreads();
+    float acc[DENSE_PB];
+#pragma unroll
+    for (int j = 0; j < DENSE_PB; ++j) acc[j] = 0.f;
+    const int kq = K >> 2, kb = wave * kq;
+    const int nc = min(n, N - 1);
+    for (int kk = 0; kk < kq; kk += 16) {
+        float w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = wt[(long long)(kb + kk + u) * N + nc];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+#pragma unroll
+            for (int j = 0; j < DENSE_PB; ++j) acc[j] += w[u] * xs[j * K + kb + kk + u];
+    }
+#pragma unroll
+    for (int j = 0; j < DENSE_PB; ++j) red[(wave * DENSE_PB + j) * 64 + lane] = acc[j];
+    __syncthreads();
+    // 16 x 64 outputs, 4 per thread
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = wave * 4 + u, p = p0 + j;
+        float v = (red[(0 * DENSE_PB + j) * 64 + lane] + red[(1 * DENSE_PB + j) * 64 + lane]) +
+                  (red[(2 * DENSE_PB + j) * 64 + lane] + red[(3 * DENSE_PB + j) * 64 + lane]);
+        if (p >= P || n >= N) continue;
+        v += bias ? bias[n] : 0.f;
+        if (mode == 1) v = lrelu_sqrt2(v);
+        out[(long long)p * ldo + n] = v;
+    }
+}
+void launch_dense_splitk(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias, float* out, int ldo,
+                         int mode, hipStream_t st) {
+    const size_t lds = (size_t)(16 * K + 4 * 16 * 64) * sizeof(float);
+    dim3 g((N + 63) / 64, (P + DENSE_PB - 1) / DENSE_PB);
+    hipLaunchKernelGGL(dense_splitk_kernel, g, dim3(256), lds, st, x, ldx, P, K, wt, N, bias, out, ldo, mode);
+}
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
                   hipStream_t st) {
