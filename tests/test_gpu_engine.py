@@ -213,6 +213,28 @@ def test_offset_shards_equal_whole_population():
     e.close()
 
 
+def test_stream_modes_give_identical_results():
+    """glass_engine_set_overlap: 0 = one stream, 1 = chunk pipelining, 2 = CLIP's image tower on a second stream next to the
+    discriminator (the default).  The stream mode only moves launches between streams: fitness values are bit-identical."""
+    name, P, bs = "mini", 16, 4
+    c = M.CONFIGS[name]
+    sd = M.make_state(name, 0)
+    x = synth.latents(11, P, c["latent"])
+    e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1, noise_seed=5, chunk=8)
+    e.set_target(np.ones(c["clip"][5], np.float32))
+    e.evaluate(x, generation=1)
+    e.set_target(M.make_target(e.details(P)["features"]))
+    ref = None
+    for mode in (0, 2, 1, 2, 0):
+        e.set_overlap(mode)
+        for _ in range(2):
+            F = e.evaluate(x, generation=3)
+            if ref is None:
+                ref = F
+            np.testing.assert_array_equal(F, ref)
+    e.close()
+
+
 def test_pop512_as_eight_shards_of_64():
     """BASELINE.json configs[3] (StyleGAN2_ffhq_d pop=512, 64 per GPU x 8) exercised as offset shards on ONE GPU at the mid
     architecture: the eight 64-row shard calls reproduce the whole-population call row for row."""
