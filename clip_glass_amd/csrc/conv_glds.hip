@@ -51,6 +51,8 @@ __device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 __device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8}: the queue depths this pipeline produces
     if (n >= 8) WAIT_VM(8);
@@ -315,6 +317,308 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
     }
 }
 
+// ---- persistent form (TW = 32, an even number of 32-channel chunks) -------------------------------------------------------------
+// One 512-thread workgroup per CU means nothing covers a tile's pipeline fill (first DMA round trip), its epilogue and the
+// dispatch of the next workgroup: 48 S + B = 134.7 us, 24 S + B = 72.9 us and 12 S + B = 43 us per tile on the 512 / 256 / 128
+// channel layers give S = 2.6 us per stage and B = 11 us per tile — a quarter of the 128-channel layers' time.  Here a workgroup
+// walks work items id, id + gridDim.x, ... and the DMA ring never drains: with 3 * n_chunks stages per tile (slot rotation period 3)
+// and an even chunk count (patch buffer parity), stages 0 and 1 and chunk 0 of the NEXT tile are exactly what "two stages ahead" /
+// "one chunk ahead" mean at the end of a tile.  The epilogue therefore runs while those loads are in flight, in the one patch
+// buffer and nowhere else: the output transposition goes through it in four 32-channel slices (4 KB + pad per wave).
+template <bool TRGB>
+__global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
+    constexpr int TW = 32;
+    using G = Geo<TW>;
+    constexpr int RW = G::RW, TH = G::TH, PW = G::PW, NVA = G::NVA, NA = G::NA, A_BYTES = G::A_BYTES, OFF_B = G::OFF_B,
+                  OFF_C = G::OFF_C, OFF_S = G::OFF_S;
+    static_assert(RW == 2 && 8 * RW * 32 * 80 <= A_BYTES, "the sliced output image fits one patch buffer");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (lane geometry is re-derived per phase from an opaque copy of the thread id: as invariants of the item loop these values and
+    // every address built from them are hoisted above the K loop, where the register file is full, and spilled)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tpi = tiles_x * tiles_y;
+    const int n_work = ((PT + 7) & ~7) * NTn;
+    struct Item { int b, ty0, tx0, n0; bool valid; };
+    auto decode = [&](int id) {   // work item -> (pixel tile, n tile): the n tiles of one pixel tile sit on one XCD (id % 8)
+        Item w;
+        const int lo = id & 7, rest = id >> 3;
+        const int nt = rest % NTn, pt = (rest / NTn) * 8 + lo;
+        w.valid = id < n_work && pt < PT;
+        const int ptc = w.valid ? pt : 0;
+        w.b = ptc / tpi;
+        const int trem = ptc - w.b * tpi;
+        w.ty0 = (trem / tiles_x) * TH;
+        w.tx0 = (trem % tiles_x) * TW;
+        w.n0 = nt * NT;
+        return w;
+    };
+    int id = blockIdx.x;
+    Item cur = decode(id);
+    while (id < n_work && !cur.valid) { id += gridDim.x; cur = decode(id); }
+    if (id >= n_work) return;
+
+    // ---- DMA sources of the item being LOADED (the current item, or the next one near the end of a tile) ----------------
+    const half_t* xb = p.x;
+    const half_t* wb = p.w;
+    long long a_src[NA];      // element offset into the image, or -1 = zero page
+    long long b_src[NB];      // element offset of (tap-in-row tx, n, chunk) within one tap row, without ty / c0
+    auto aim_a = [&](const Item& w) {
+        const int t = opaque(threadIdx.x);
+        xb = p.x + (long long)w.b * p.x_bstride;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int v = k * NTHR + t, pix = v >> 2;
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int iy = w.ty0 - 1 + pr, ix = w.tx0 - 1 + pc;
+            const int lc = (v & 3) ^ ((pix >> 2) & 3);
+            const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            a_src[k] = ok ? ((long long)iy * p.W + ix) * p.Cin + lc * 8 : -1;
+        }
+    };
+    auto aim_b = [&](const Item& w) {
+        const int t = opaque(threadIdx.x);
+        wb = p.w + (long long)w.b * p.w_bstride;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int v = k * NTHR + t, row = v >> 2;          // row = tx * 128 + n
+            const int tx = row >> 7, n = row & 127;
+            const int lc = (v & 3) ^ ((row >> 2) & 3);
+            b_src[k] = ((long long)tx * p.Neff + w.n0 + n) * p.Cin + lc * 8;
+        }
+    };
+    auto issue_a = [&](int c, int buf) {
+        char* dst = smem + buf * A_BYTES + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+            dma16(a_src[k] >= 0 ? xb + a_src[k] + c * 32 : g_zero_page + (threadIdx.x & 3) * 8, dst + k * (NTHR * 16));
+    };
+    auto issue_b = [&](int c, int ty, int slot) {
+        char* dst = smem + OFF_B + slot * B_BYTES + wave * 1024;
+        const half_t* src = wb + (long long)ty * 3 * p.Neff * p.Cin + c * 32;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) dma16(src + b_src[k], dst + k * (NTHR * 16));
+    };
+    const int n_chunks = p.Cin >> 5;          // even (launcher)
+    const int n_stages = n_chunks * 3;
+    const half_t* Ss = (const half_t*)(smem + OFF_S);
+    auto park_style = [&](int b) {            // the sample's style row (applied to the weight fragments)
+        const int t = threadIdx.x;
+        if (t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = *(const h8*)(p.sn16 + (long long)b * p.sn_stride + t * 8);
+    };
+
+    aim_a(cur);
+    aim_b(cur);
+    if (p.sn16) {
+        park_style(cur.b);
+        __syncthreads();
+    }
+    issue_a(0, 0);
+    issue_b(0, 0, 0);
+    issue_b(0, 1, 1);
+    for (bool first = true;; first = false) {
+        int nid = id + gridDim.x;
+        Item nxt = decode(nid);
+        while (nid < n_work && !nxt.valid) { nid += gridDim.x; nxt = decode(nid); }
+        const bool has_next = nid < n_work;
+        const int b = cur.b, ty0 = cur.ty0, tx0 = cur.tx0, n0 = cur.n0;
+
+        f16x acc[RW][4];
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+        int c = 0, ty = 0;
+        for (int s = 0; s < n_stages; ++s) {
+            // DMA loads this wave issued after those this stage needs: B(s+1), and the next chunk's patch when it was issued after
+            // B(s) — "next" running on into the next work item.  After the first item, stage 0 finds its operands complete: the
+            // epilogue waited for everything in flight.
+            int younger = (s + 1 < n_stages || has_next) ? NB : 0;
+            if (ty != 0 && (c + 1 < n_chunks || has_next)) younger += NA;
+            if (s > 0 || first) wait_vm(younger);
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < n_stages) {
+                int c2 = c, t2 = ty + 2;
+                if (t2 >= 3) { t2 -= 3; c2 = c + 1; }
+                issue_b(c2, t2, (s + 2) % 3);
+            } else if (has_next) {
+                if (s + 2 == n_stages) aim_b(nxt);
+                issue_b(0, s + 2 - n_stages, (s + 2) % 3);      // n_stages % 3 == 0: stage s' of the next item lives in slot s' % 3 too
+            }
+            if (ty == 0) {
+                if (c + 1 < n_chunks) issue_a(c + 1, (c + 1) & 1);
+                else if (has_next) { aim_a(nxt); issue_a(0, 0); }   // n_chunks even: chunk 0 of the next item lives in buffer 0 too
+            }
+
+            const char* As = smem + (c & 1) * A_BYTES;
+            const char* Bs = smem + OFF_B + (s % 3) * B_BYTES;
+            const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int lc = kk * 2 + kh;
+                    h8 wf[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int row = tx * NT + j * 32 + lr;
+                        wf[j] = *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                    }
+                    if (p.sn16) {
+                        const h8 sv = *(const h8*)(Ss + c * 32 + lc * 8);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) wf[j] = wf[j] * sv;
+                    }
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        const int pix = (wave * RW + i + ty) * PW + lr + tx;
+                        const h8 xf = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                    }
+                }
+            }
+            if (++ty == 3) { ty = 0; ++c; }
+        }
+
+        // ---- epilogue: constants via LDS, batched noise / residual loads, row-order stores through patch buffer 1 -------------
+        const int t = opaque(threadIdx.x), lane = t & 63, lr = lane & 31, kh = lane >> 5;
+        float* Cc = (float*)(smem + OFF_C);
+        constexpr int OP = 80;                                      // bytes per staged pixel slice (64 + 16: bank spread)
+        char* Os = smem + A_BYTES + wave * (RW * 32 * OP);
+        const int oyb = ty0 + wave * RW, ox = tx0 + lr;              // lane's pixel of tile row i: (oyb + i, ox)
+        float c_d = 1.f, c_b = 0.f, c_s = 0.f;
+        if (t < NT) {
+            const int o = n0 + t;
+            if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
+            if (p.bias) c_b = p.bias[o];
+            if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
+        }
+        float nzr[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            nzr[i] = 0.f;
+            if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i) * p.Wo + ox];
+        }
+        float ytap[3][4];
+        h8 t6v;
+        if (TRGB) {
+            if (t < 6 * (NT / 8)) {
+                const int row6 = t / (NT / 8), piece = t % (NT / 8);
+                const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
+                t6v = *(const h8*)(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8);
+            }
+            if (p.trgb_yprev) {
+                const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+                const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
+            }
+        }
+        h8 nsty;
+        if (has_next && p.sn16 && t < (p.Cin >> 3)) nsty = *(const h8*)(p.sn16 + (long long)nxt.b * p.sn_stride + t * 8);
+        WAIT_VM(0);                            // constants landed — and with them every DMA issued so far (in-order counter)
+        __builtin_amdgcn_s_barrier();          // every wave is done with patch buffer 1, weight slot 2 and the style row
+        if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }
+        if (TRGB && t < 6 * (NT / 8)) *(h8*)(smem + G::OFF_T + t * 16) = t6v;
+        if (has_next && p.sn16 && t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = nsty;
+        __syncthreads();
+        const int rcs = p.res_cs ? p.res_cs : p.Cout;
+        f16x rgb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rgb[q] = 0.f;
+        const int tn = lr & 15;
+        const char* Trow = smem + G::OFF_T + (((tn >> 3) & 1) * 3 + min(tn & 3, 2)) * (NT * 2) + kh * 16;
+        const bool trow_ok = (tn & 3) < 3;
+        const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h4 va[RW][4];
+            h4 rq[4][RW];
+            if (p.res) {
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    const int oy = oyb + i;
+                    const half_t* rp = p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs
+                                                         : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + n0 + j * 32 + 4 * kh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rq[g][i] = *(const h4*)(rp + 8 * g);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = j * 32 + 8 * g + 4 * kh;
+                const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
+#pragma unroll
+                for (int i = 0; i < RW; ++i) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[q] = acc[i][j][g * 4 + q] * d[q];
+                        v[q] += nzr[i];
+                        v[q] += bb[q];
+                        v[q] += sh4[q];
+                    }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    if (p.res) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += (float)rq[g][i][q];
+                    }
+                    h4 out;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                    *(h4*)(Os + (i * 32 + lr) * OP + (8 * g + 4 * kh) * 2) = out;
+                    if (TRGB) va[i][g] = out;
+                }
+            }
+            if (TRGB) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const h8 wt = *(const h8*)(Trow + ((j * 2 + gp) * 2) * 16);
+#pragma unroll
+                    for (int i = 0; i < RW; ++i) {
+                        const h8 wi = (trow_ok && ((tn >> 2) & 1) == i) ? wt : hzero;
+                        rgb = mfma32(wi, __builtin_shufflevector(va[i][2 * gp], va[i][2 * gp + 1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();        // LDS is in-order per wave: only pin the compiler's order
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // 2 rows x 32 px x four 16-byte pieces of this 32-channel slice
+                const int v = lane + 64 * k, i = v >> 7, pix = (v >> 2) & 31, piece = v & 3;
+                half_t* dst = p.y + (((long long)b * p.Ho + oyb + i) * p.Wo + tx0 + pix) * p.Cout + n0 + j * 32 + piece * 8;
+                *(h8*)dst = *(const h8*)(Os + (i * 32 + pix) * OP + piece * 16);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (TRGB) {
+            const long long hw = (long long)p.Ho * p.Wo;
+            float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                float r = p.trgb_b[cc] + (rgb[cc] + rgb[4 + cc] * (1.f / 2048.f));
+                if (p.trgb_yprev) r += trgb_skip(ytap[cc], oyb + kh, ox);
+                yo[cc * hw] = r;
+            }
+        }
+        if (!has_next) break;
+        id = nid;
+        cur = nxt;
+    }
+}
+
+
 template <int TW, bool TRGB = false>
 static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const char* name) {
     using G = Geo<TW>;
@@ -328,6 +632,21 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
     if (p.dry_run) return name;
+    static const bool no_persist = getenv("GLASS_NO_GLDS_PERSIST") != nullptr;   // A/B knob: one work item per workgroup
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        n_cu = prop.multiProcessorCount - prop.multiProcessorCount % 8;       // a workgroup keeps its XCD (id % 8) across items
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+    }
+    if (TW == 32 && !no_persist && (p.Cin & 63) == 0 && PT8 * NTn >= 2 * n_cu) {   // ring parity needs an even chunk count
+        hipLaunchKernelGGL((conv_gldsp_kernel<TRGB>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+        return name;
+    }
     hipLaunchKernelGGL((conv_glds_kernel<TW, TRGB>), dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }

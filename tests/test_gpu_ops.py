@@ -250,6 +250,41 @@ def test_conv_glds_matches_tiled(B, H, W, Cin, Cout):
     check("conv_glds (style on weights) vs direct", got_s, ref_s, 4e-3)
 
 
+def test_conv_glds_persistent_matches_tiled():
+    """The persistent form of conv_glds (>= 2 work items per CU: the DMA ring runs on into the next item, epilogue through one
+    patch buffer in 32-channel slices): 512 work items of 8 stages, sample switches, borders, style, residual — the tiled
+    kernel's numbers; and the fused toRGB epilogue in that form."""
+    rng = np.random.default_rng(29)
+    B, H, W, Cin, Cout = 8, 128, 128, 128, 256
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / math.sqrt(9 * Cin)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, Cout)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32) * 0.2
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float16).astype(np.float32)
+    kw = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, res=res, out_scale=0.7)
+    got = ops.conv(x, w, impl=5, **kw)
+    ref_t = ops.conv(x, w, impl=2, **kw)
+    assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
+    sn = rng.uniform(-1.0, 1.0, (B, Cin)).astype(np.float32)
+    check("persistent conv_glds (style on weights) vs direct", ops.conv(x, w, impl=5, sn=sn, **kw), ops.conv(x, w, impl=1, sn=sn, **kw), 4e-3)
+    # fused toRGB: one n tile, 16 x 8 x 4 = 512 items
+    B, C = 16, 128
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    kw = dict(sn=rng.uniform(0.5, 1.0, (B, C)).astype(np.float32), dscale=rng.uniform(0.5, 2.0, (B, C)).astype(np.float32),
+              noise=rng.standard_normal((B, H, W)).astype(np.float32), noise_strength=0.3, batch_size=1,
+              bias=(rng.standard_normal(C) * 0.2).astype(np.float32), act=True)
+    wrgb = (rng.standard_normal((3, C)) / math.sqrt(C)).astype(np.float32)
+    brgb = (rng.standard_normal(3) * 0.1).astype(np.float32)
+    srgb = rng.uniform(0.2, 1.0, (B, C)).astype(np.float32)
+    smax = rng.uniform(0.5, 3.0, B).astype(np.float32)
+    yprev = rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32)
+    got = ops.conv(x, w, impl=5, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw)
+    feat = ops.conv(x, w, impl=5, **kw)
+    check("persistent conv_glds fused toRGB", got, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
+
+
 @pytest.mark.parametrize("impl", [1, 2])
 def test_conv_modulated_demod_noise(impl):
     got, ref = _modconv_case(False, impl)
