@@ -430,6 +430,42 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
+        // epilogue operands from global memory (per-channel constants, noise, toRGB table / skip taps, the next item's style row)
+        // are fetched under the LAST stage's MFMAs: at the top of the epilogue they would cost a ~2 us round trip per item
+        float c_d = 1.f, c_b = 0.f, c_s = 0.f;
+        float nzr[RW] = {0.f, 0.f};
+        float ytap[3][4];
+        h8 t6v, nsty;
+        auto prefetch_epilogue = [&]() {
+            const int t = opaque(threadIdx.x), lr = t & 31, kh = (t >> 5) & 1;
+            const int oyb = ty0 + wave * RW, ox = tx0 + lr;
+            if (t < NT) {
+                const int o = n0 + t;
+                if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
+                if (p.bias) c_b = p.bias[o];
+                if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
+            }
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+                if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i) * p.Wo + ox];
+            if (TRGB) {
+                if (t < 6 * (NT / 8)) {
+                    const int row6 = t / (NT / 8), piece = t % (NT / 8);
+                    const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
+                    t6v = *(const h8*)(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8);
+                }
+                if (p.trgb_yprev) {
+                    const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+                    const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
+                }
+            }
+            if (has_next && p.sn16 && t < (p.Cin >> 3)) nsty = *(const h8*)(p.sn16 + (long long)nxt.b * p.sn_stride + t * 8);
+        };
         int c = 0, ty = 0;
         for (int s = 0; s < n_stages; ++s) {
             // DMA loads this wave issued after those this stage needs: B(s+1), and the next chunk's patch when it was issued after
@@ -451,6 +487,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                 if (c + 1 < n_chunks) issue_a(c + 1, (c + 1) & 1);
                 else if (has_next) { aim_a(nxt); issue_a(0, 0); }   // n_chunks even: chunk 0 of the next item lives in buffer 0 too
             }
+            if (s == n_stages - 1) prefetch_epilogue();
 
             const char* As = smem + (c & 1) * A_BYTES;
             const char* Bs = smem + OFF_B + (s % 3) * B_BYTES;
@@ -489,39 +526,6 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
         constexpr int OP = 80;                                      // bytes per staged pixel slice (64 + 16: bank spread)
         char* Os = smem + A_BYTES + wave * (RW * 32 * OP);
         const int oyb = ty0 + wave * RW, ox = tx0 + lr;              // lane's pixel of tile row i: (oyb + i, ox)
-        float c_d = 1.f, c_b = 0.f, c_s = 0.f;
-        if (t < NT) {
-            const int o = n0 + t;
-            if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
-            if (p.bias) c_b = p.bias[o];
-            if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
-        }
-        float nzr[RW];
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            nzr[i] = 0.f;
-            if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i) * p.Wo + ox];
-        }
-        float ytap[3][4];
-        h8 t6v;
-        if (TRGB) {
-            if (t < 6 * (NT / 8)) {
-                const int row6 = t / (NT / 8), piece = t % (NT / 8);
-                const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
-                t6v = *(const h8*)(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8);
-            }
-            if (p.trgb_yprev) {
-                const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-                const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
-#pragma unroll
-                for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
-            }
-        }
-        h8 nsty;
-        if (has_next && p.sn16 && t < (p.Cin >> 3)) nsty = *(const h8*)(p.sn16 + (long long)nxt.b * p.sn_stride + t * 8);
         WAIT_VM(0);                            // constants landed — and with them every DMA issued so far (in-order counter)
         __builtin_amdgcn_s_barrier();          // every wave is done with patch buffer 1, weight slot 2 and the style row
         if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }
