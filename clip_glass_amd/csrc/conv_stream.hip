@@ -21,7 +21,6 @@
 
 namespace {
 constexpr int TH = 8, PH = TH + 2, PW = 34;
-constexpr int NVA = PH * PW * 4, NA = (NVA + 255) / 256;   // 1360 16-byte vectors -> 6 per thread
 constexpr int W_BYTES = 9 * 32 * 64;                       // 18432  weight image, rows tap * 32 + n
 constexpr int PP = 36;                                     // LDS pitch of a patch row in pixels (multiple of 4: the swizzle key ignores the row)
 constexpr int A_BYTES = PH * PP * 64;                      // 23040  patch image, rows pr * 36 + pc
