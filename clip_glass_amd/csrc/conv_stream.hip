@@ -20,7 +20,7 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int TH = 8, PH = TH + 2, PW = 34;
+constexpr int TH = 8, PH = TH + 2;                      // tile rows, patch rows (the patch is 34 px wide: 32 + two halo columns)
 constexpr int W_BYTES = 9 * 32 * 64;                       // 18432  weight image, rows tap * 32 + n
 constexpr int PP = 36;                                     // LDS pitch of a patch row in pixels (multiple of 4: the swizzle key ignores the row)
 constexpr int A_BYTES = PH * PP * 64;                      // 23040  patch image, rows pr * 36 + pc
