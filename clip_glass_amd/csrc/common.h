@@ -104,6 +104,9 @@ struct ConvParams {
     float* trgb_yout;       // [B][3][Ho][Wo]
     const half_t* trgb_tab; // conv_tiled / conv_glds (their output map IS stored too): [B][2][16][Neff] fp16 weight tables from
                             // launch_trgb_tables (the MFMA A operand of the 1x1 conv in accumulator-lane channel order)
+    // conv_tiled<3,1,8,N> only: FIR 4x4 (pad 1) + ::2 of the INPUT map [B][H/2][W/2][Cin] as a by-product of the staged patch — the D
+    // block's skip-branch input (modules.py:1238-1254 via 1587-1601), which is a function of the same tensor the block's first conv reads
+    half_t* xs_out;
     // upfir only: per-(sample, channel) factor applied to the finished output — the NEXT layer's style, so that the consumer runs
     // without its activation-side modulation (x * s is the same product wherever it is formed)
     const half_t* post_scale16;   // [B][post_stride] (nullable)

@@ -657,7 +657,7 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
 
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
     static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
-    if ((!on && !force) || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
+    if ((!on && !force) || p.up || p.xs_out || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;

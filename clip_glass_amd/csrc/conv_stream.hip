@@ -458,7 +458,7 @@ static int stream_slots() {
 bool conv_stream_applies(const ConvParams& p) {
     static const bool off = getenv("GLASS_NO_STREAM") != nullptr;   // experiment knob
     const bool trgb = p.trgb_yout != nullptr;
-    if (off || p.up || p.y32 || (!p.y && !trgb) || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return false;
+    if (off || p.up || p.xs_out || p.y32 || (!p.y && !trgb) || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return false;
     const bool frgb = p.rgb_y != nullptr;
     if (frgb && (!p.rgb_w || !p.rgb_b || (!p.rgb_x_out && !p.rgb_xs_out) || p.sn || trgb)) return false;
     if (trgb && (!p.trgb_w || !p.trgb_b || !p.trgb_sn || !p.trgb_smax || p.Ho != p.Hc || p.Wo != p.Wc)) return false;

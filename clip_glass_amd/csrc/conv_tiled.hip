@@ -30,7 +30,8 @@
 // separate toRGB pass would re-read the whole map.
 // SKIP (stride 2, fast path): ConvParams::skip_x / skip_w — the residual branch's 1x1 conv as extra K stages after an in-register
 // activation.
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false>
+// XS (3x3 stride 1, TH = 8, one n tile): ConvParams::xs_out — the blur-down of the input map from the patch already in LDS.
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = TH / 4;                 // tile rows per wave
     constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
@@ -202,6 +203,28 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             if (ty == 0) store_a();
             store_b();
             __syncthreads();
+            if (XS && ty == 0) {
+                // the 8 x 32 tile of this 32-channel chunk (+ halo, zeros outside the image) sits in LDS: its 4 x 16 down-sampled
+                // pixels are 16 reads + 5 packed-fp16 FIRs per thread, and the separate blur-down pass (a full read of the map) goes
+                static_assert(!XS || (KS == 3 && S == 1 && TH == 8), "patch = tile + 1-pixel halo");
+                int tq = threadIdx.x;
+                asm volatile("" : "+v"(tq));                      // (geometry derived here, not hoisted above the MFMA blocks as loop invariants)
+                const int part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
+                h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass (one row live at a time)
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy) {
+                    const char* rp = As + ((2 * ly + jy) * PW + 2 * lx) * ROWB + part * 16;
+                    const h8 a0 = *(const h8*)rp, a1 = *(const h8*)(rp + ROWB), a2 = *(const h8*)(rp + 2 * ROWB), a3 = *(const h8*)(rp + 3 * ROWB);
+                    const h8 hr = (a0 + a3) * (half_t)0.125f + (a1 + a2) * (half_t)0.375f;
+                    if (jy == 0) s03 = hr;
+                    else if (jy == 1) s12 = hr;
+                    else if (jy == 2) s12 = s12 + hr;
+                    else s03 = s03 + hr;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const h8 o = s03 * (half_t)0.125f + s12 * (half_t)0.375f;
+                *(h8*)(p.xs_out + (((long long)cur.b * (p.H >> 1) + (cur.ty0 >> 1) + ly) * (p.W >> 1) + (cur.tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
+            }
             int nc = c, nty = ty + 1;
             if (nty == KS) { nty = 0; nc = c + 1; }
             if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
@@ -486,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
@@ -495,7 +518,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>,
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
@@ -508,7 +531,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static int resident = 0;
     if (!resident) {
         int per_cu = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>, 256, LDS);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>, 256, LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         hipDeviceProp_t prop;
         int dev = 0;
@@ -521,7 +544,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
     if (p.dry_run) return name;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -536,6 +559,13 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
             (p.x_bstride == 0 && p.B > 1) || (long long)p.H * p.W * p.Cin >= (1LL << 31))
             return nullptr;
         return launch_inst<3, 1, 8, 64, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,torgb>");
+    }
+    if (p.xs_out) {   // blur-down of the input as a by-product: un-transformed input, every chunk staged exactly once per pixel tile
+        if (p.KS != 3 || p.stride != 1 || p.pad != 1 || p.sn || p.pre_shift || p.in_up || p.up || p.Neff != 64 || p.Cout != 64 || p.no_tstore ||
+            p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || p.trgb_yout || (p.x_bstride == 0 && p.B > 1) ||
+            (long long)p.H * p.W * p.Cin >= (1LL << 31))
+            return nullptr;
+        return launch_inst<3, 1, 8, 64, false, false, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,xs>");
     }
     if ((p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16)) return nullptr;   // fp16 tables not provided: direct path
     if (p.x_bstride == 0 && p.B > 1) return nullptr;  // broadcast input (4x4 const): direct path

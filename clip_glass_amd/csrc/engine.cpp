@@ -1028,7 +1028,17 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         }
         if (i == 0 && rgb_y && !fused_rgb) run_fromrgb(e, B, rgb_y, X);
         snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
-        if (!fused_rgb) run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin);
+        if (!fused_rgb) {
+            static const bool no_xs = getenv("GLASS_NO_XS_FUSE") != nullptr;   // A/B knob
+            ConvParams qx = p;
+            qx.xs_out = XS; qx.dry_run = 1;
+            if (!no_xs && !have_xs && launch_conv_tiled(qx, e->cur)) {   // the skip branch's blur-down rides in the first conv
+                qx.dry_run = 0;
+                p = qx;
+                have_xs = true;
+            }
+            run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin + (have_xs ? 0.5 * B * (double)r * r * d.cin : 0.0));
+        }
         if (!have_xs) {
             snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);

@@ -111,6 +111,13 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         p.skip_w = dv.up16v(pks);
         p.skip_x = dv.up16(d->skip_x, (size_t)d->B * d->Ho * d->Wo * d->Cin);
     }
+    half_t* xs_dev = nullptr;
+    const size_t nxs = (size_t)d->B * (d->H / 2) * (d->W / 2) * d->Cin;
+    if (d->xs_out) {
+        OPREQ(d->impl == 2, "blur-down by-product: impl 2");
+        xs_dev = dv.alloc<half_t>(nxs);
+        p.xs_out = xs_dev;
+    }
     float* yrgb = nullptr;
     const size_t nrgb = (size_t)d->B * 3 * d->Ho * d->Wo;
     if (d->trgb_yout) {
@@ -151,6 +158,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         GLASS_HIP(hipMemcpy(d->trgb_yout, yrgb, nrgb * sizeof(float), hipMemcpyDeviceToHost));
         return GLASS_OK;
     }
+    if (xs_dev && (rc = down16(d->xs_out, xs_dev, nxs))) return rc;
     return down16(d->y, y, nout);
 }
 

@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
                 ("trgb_w", C.POINTER(C.c_float)), ("trgb_b", C.POINTER(C.c_float)), ("trgb_sn", C.POINTER(C.c_float)),
                 ("trgb_smax", C.POINTER(C.c_float)), ("trgb_yprev", C.POINTER(C.c_float)),
                 ("trgb_yout", C.POINTER(C.c_float)),
-                ("skip_x", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float))]
+                ("skip_x", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float)), ("xs_out", C.POINTER(C.c_float))]
 
 
 def _opt(a):
@@ -35,7 +35,7 @@ def _opt(a):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None, skip=None):
+         torgb=None, skip=None, xs_out=None):
     """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout].
     torgb = dict(w [3,Cout], b [3], sn [B,Cout], smax [B], yprev [B,3,Ho/2,Wo/2] or None) with impl=4: the fused conv + toRGB
     form of the streaming kernel — returns the skip image [B,3,Ho,Wo] instead of y."""
@@ -67,6 +67,8 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
             a, p = _opt(val)
             keep.append(a)
             setattr(d, name, p)
+    if xs_out is not None:    # float32 [B,H/2,W/2,Cin] array that receives the blur-down by-product (impl 2, 64 -> 64)
+        d.xs_out = _fp(xs_out)
     yrgb = None
     if torgb is not None:
         yrgb = np.empty((B, 3, Ho, Wo), dtype=np.float32)

@@ -41,6 +41,8 @@ typedef struct glass_conv_desc {
     /* impl 2, stride 2, both or none: the D block's skip branch as extra K stages — y = (act(conv + bias) + conv1x1(skip_x)) * out_scale */
     const float* skip_x;     /* [B,Ho,Wo,Cin] */
     const float* skip_w;     /* [Cout,Cin,1,1] reference layout, un-scaled */
+    /* impl 2, 3x3 stride 1, 64 -> 64: FIR 4x4 (pad 1) + ::2 of the INPUT map as a by-product of the staged patch */
+    float* xs_out;           /* [B,H/2,W/2,Cin] or NULL */
 } glass_conv_desc;
 
 int glass_op_conv(int32_t device, const glass_conv_desc* d);

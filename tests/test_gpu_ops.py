@@ -181,6 +181,23 @@ def test_conv_gemm_matches_direct(case):
     check("conv_gemm %s vs direct" % case, got, ref, 2e-3)
 
 
+def test_conv_tiled_blurdown_byproduct():
+    """conv_tiled<3,1,8,64,xs>: the D block's skip-branch input (FIR pad 1 + ::2 of the block input, modules.py:1587-1601) taken
+    from the patch the first conv stages anyway — against the separate blur-down pass; the conv output is unchanged."""
+    rng = np.random.default_rng(31)
+    B, H, W, C = 3, 64, 96, 64
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    bias = (rng.standard_normal(C) * 0.2).astype(np.float32)
+    xs = np.empty((B, H // 2, W // 2, C), dtype=np.float32)
+    y = ops.conv(x, w, impl=2, bias=bias, act=True, xs_out=xs)
+    np.testing.assert_array_equal(y, ops.conv(x, w, impl=2, bias=bias, act=True))
+    f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref = sum(f[a] * f[b2] * xp[:, a:a + H:2, b2:b2 + W:2] for a in range(4) for b2 in range(4))
+    check("blur-down by-product", xs, ref, 2e-3)
+
+
 def _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev):
     """float64 toRGB (stylegan2/models.py:852-870) + FIR-upsampled skip image (modules.py:580-602) of an NHWC map."""
     B, H, W, _ = feat.shape
