@@ -54,8 +54,9 @@ __device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base) {
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 #define WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-__device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8}: the queue depths this pipeline produces
-    if (n >= 8) WAIT_VM(8);
+__device__ __forceinline__ void wait_vm(int n) {   // n in {0, 3, 5, 8, 9}: the queue depths this pipeline produces
+    if (n >= 9) WAIT_VM(9);
+    else if (n >= 8) WAIT_VM(8);
     else if (n >= 5) WAIT_VM(5);
     else if (n >= 3) WAIT_VM(3);
     else WAIT_VM(0);
@@ -325,7 +326,9 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 // and an even chunk count (patch buffer parity), stages 0 and 1 and chunk 0 of the NEXT tile are exactly what "two stages ahead" /
 // "one chunk ahead" mean at the end of a tile.  The epilogue therefore runs while those loads are in flight, in the one patch
 // buffer and nowhere else: the output transposition goes through it in four 32-channel slices (4 KB + pad per wave).
-template <bool TRGB>
+// XS: ConvParams::xs_out — FIR 4x4 (pad 1) + ::2 of the INPUT map (the D block's skip-branch input) from the patch of each chunk as it
+// becomes visible: 8 x 16 pixels x 4 parts = one vector per thread per chunk (n tile 0 only); its store is one more op in the wait counts.
+template <bool TRGB, bool XS = false>
 __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int TW = 32;
     using G = Geo<TW>;
@@ -473,6 +476,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             // epilogue waited for everything in flight.
             int younger = (s + 1 < n_stages || has_next) ? NB : 0;
             if (ty != 0 && (c + 1 < n_chunks || has_next)) younger += NA;
+            if (XS && ty != 0 && n0 == 0) younger += 1;           // this chunk's blur-down store (issued in its ty == 0 iteration)
             if (s > 0 || first) wait_vm(younger);
             __builtin_amdgcn_s_barrier();
             if (s + 2 < n_stages) {
@@ -491,6 +495,26 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
 
             const char* As = smem + (c & 1) * A_BYTES;
             const char* Bs = smem + OFF_B + (s % 3) * B_BYTES;
+            if (XS && ty == 0 && n0 == 0) {
+                const int tq = opaque(threadIdx.x), part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
+                h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass
+#pragma unroll
+                for (int jy = 0; jy < 4; ++jy) {
+                    h8 a[4];
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) {
+                        const int P = (2 * ly + jy) * PW + 2 * lx + jx;
+                        a[jx] = *(const h8*)(As + P * 64 + ((part ^ ((P >> 2) & 3)) << 4));
+                    }
+                    const h8 hr = (a[0] + a[3]) * (half_t)0.125f + (a[1] + a[2]) * (half_t)0.375f;
+                    if (jy == 0) s03 = hr;
+                    else if (jy == 1) s12 = hr;
+                    else if (jy == 2) s12 = s12 + hr;
+                    else s03 = s03 + hr;
+                }
+                const h8 o = s03 * (half_t)0.125f + s12 * (half_t)0.375f;
+                *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + ly) * (p.W >> 1) + (tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
+            }
             const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
 #pragma unroll
             for (int tx = 0; tx < 3; ++tx) {
@@ -635,7 +659,6 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
-    if (p.dry_run) return name;
     static const bool no_persist = getenv("GLASS_NO_GLDS_PERSIST") != nullptr;   // A/B knob: one work item per workgroup
     static int n_cu = 0;
     if (!n_cu) {
@@ -646,18 +669,23 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
         n_cu = prop.multiProcessorCount - prop.multiProcessorCount % 8;       // a workgroup keeps its XCD (id % 8) across items
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
     }
     if (TW == 32 && !no_persist && (p.Cin & 63) == 0 && PT8 * NTn >= 2 * n_cu) {   // ring parity needs an even chunk count
-        hipLaunchKernelGGL((conv_gldsp_kernel<TRGB>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+        if (p.dry_run) return name;
+        if (p.xs_out && !TRGB) hipLaunchKernelGGL((conv_gldsp_kernel<false, true>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+        else hipLaunchKernelGGL((conv_gldsp_kernel<TRGB>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
         return name;
     }
+    if (p.xs_out) return nullptr;            // (the blur-down by-product exists in the persistent form only)
+    if (p.dry_run) return name;
     hipLaunchKernelGGL((conv_glds_kernel<TW, TRGB>), dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force) {
     static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
-    if ((!on && !force) || p.up || p.xs_out || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
+    if ((!on && !force) || p.up || (p.xs_out && (p.sn || p.trgb_yout || p.Wc % 32 != 0)) || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;

@@ -1032,7 +1032,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
             static const bool no_xs = getenv("GLASS_NO_XS_FUSE") != nullptr;   // A/B knob
             ConvParams qx = p;
             qx.xs_out = XS; qx.dry_run = 1;
-            if (!no_xs && !have_xs && launch_conv_tiled(qx, e->cur)) {   // the skip branch's blur-down rides in the first conv
+            if (!no_xs && !have_xs && (launch_conv_glds(qx, e->cur) || launch_conv_tiled(qx, e->cur))) {   // the skip branch's blur-down rides in the first conv
                 qx.dry_run = 0;
                 p = qx;
                 have_xs = true;

@@ -114,7 +114,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     half_t* xs_dev = nullptr;
     const size_t nxs = (size_t)d->B * (d->H / 2) * (d->W / 2) * d->Cin;
     if (d->xs_out) {
-        OPREQ(d->impl == 2, "blur-down by-product: impl 2");
+        OPREQ(d->impl == 2 || d->impl == 5, "blur-down by-product: impl 2 / 5");
         xs_dev = dv.alloc<half_t>(nxs);
         p.xs_out = xs_dev;
     }

@@ -285,6 +285,15 @@ def test_conv_glds_persistent_matches_tiled():
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     sn = rng.uniform(-1.0, 1.0, (B, Cin)).astype(np.float32)
     check("persistent conv_glds (style on weights) vs direct", ops.conv(x, w, impl=5, sn=sn, **kw), ops.conv(x, w, impl=1, sn=sn, **kw), 4e-3)
+    # blur-down of the input as a by-product of the staged patches (two n tiles per pixel tile: only the first one writes it)
+    xs = np.full((B, H // 2, W // 2, Cin), np.nan, dtype=np.float32)
+    kw2 = dict(bias=bias, act=True, out_scale=0.7)
+    y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
+    np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, **kw2))
+    f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    check("persistent conv_glds blur-down by-product", xs,
+          sum(f[a] * f[b2] * xp[:, a:a + H:2, b2:b2 + W:2] for a in range(4) for b2 in range(4)), 2e-3)
     # fused toRGB: one n tile, 16 x 8 x 4 = 512 items
     B, C = 16, 128
     x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
