@@ -25,7 +25,8 @@ def mfma_probe(a, b):
 
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
-         batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0):
+         batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
+         torgb=None, skip=None, xs_out=None):
     x = np.asarray(x, np.float32)
     Bx, H, W, Cin = x.shape
     B = B or Bx
@@ -34,17 +35,20 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
     pk = real_ops.host_pack_conv(w, up)                      # [taps][Neff][Cin]
     Neff = pk.shape[1]
     xa = np.broadcast_to(_h(x), (B, H, W, Cin)).copy()
+    if xs_out is not None:                                   # FIR pad 1 + ::2 of the input (the D block's skip-branch input)
+        xs_out[...] = blur(xa, 1)
     if sn is not None:
         xa = _h(xa * np.asarray(sn, np.float32)[:, None, None, :])
     Hc = H if up else (H + 2 * pad - KS) // stride + 1
+    Wc = W if up else (W + 2 * pad - KS) // stride + 1
     xp = np.pad(xa, ((0, 0), (pad, pad), (pad, pad), (0, 0)))
-    acc = np.zeros((B, Hc, Hc, Neff), np.float64)
+    acc = np.zeros((B, Hc, Wc, Neff), np.float64)
     for ty in range(KS):
         for tx in range(KS):
-            sl = xp[:, ty:ty + (Hc - 1) * stride + 1:stride, tx:tx + (Hc - 1) * stride + 1:stride, :]
+            sl = xp[:, ty:ty + (Hc - 1) * stride + 1:stride, tx:tx + (Wc - 1) * stride + 1:stride, :]
             acc += sl.astype(np.float64) @ pk[ty * KS + tx].astype(np.float64).T
     if up:
-        acc = acc.reshape(B, Hc, Hc, 2, 2, Cout).transpose(0, 1, 3, 2, 4, 5).reshape(B, 2 * Hc, 2 * Hc, Cout)
+        acc = acc.reshape(B, Hc, Wc, 2, 2, Cout).transpose(0, 1, 3, 2, 4, 5).reshape(B, 2 * Hc, 2 * Wc, Cout)
     v = acc
     if dscale is not None:
         v = v * np.asarray(dscale, np.float64)[:, None, None, :]
@@ -56,7 +60,34 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
         v = np.where(v > 0, v, 0.2 * v) * math.sqrt(2)
     if res is not None:
         v = v + _h(res)
-    return _h(v * out_scale)
+    if skip is not None:                                     # skip branch as extra K stages: fp32 accumulate on top of the activation
+        sx, sw = skip
+        v = v + _h(sx).astype(np.float64) @ real_ops.host_pack_conv(np.asarray(sw, np.float32), False)[0].astype(np.float64).T
+    y = _h(v * out_scale)
+    if torgb is not None:                                    # toRGB + skip-image sum on the stored (fp16) map
+        return _torgb_rect(y, torgb["w"], torgb["b"], torgb["sn"], torgb["smax"], torgb.get("yprev"))
+    return y
+
+
+def _torgb_rect(x, wrgb, bias, sn, smax, yprev=None):
+    x = np.asarray(x, np.float64)
+    B, H, W, _ = x.shape
+    wm = np.asarray(wrgb, np.float64)[None] * np.asarray(sn, np.float64)[:, None, :] * np.asarray(smax, np.float64)[:, None, None]
+    y = np.einsum("bhwc,bkc->bkhw", x, wm) + np.asarray(bias)[None, :, None, None]
+    if yprev is not None:
+        yp = np.pad(np.asarray(yprev, np.float64), ((0, 0), (0, 0), (1, 0), (1, 0)))
+        h, w2 = yprev.shape[2], yprev.shape[3]
+        a = np.array([[0.75, 0.25], [0.25, 0.75]])
+        upm = np.zeros_like(y)
+        for py in range(2):
+            for px in range(2):
+                s = 0
+                for dy in range(2):
+                    for dx in range(2):
+                        s = s + a[py][dy] * a[px][dx] * yp[:, :, dy:dy + h, dx:dx + w2]
+                upm[:, :, py::2, px::2] = s
+        y = y + upm
+    return y.astype(np.float32)
 
 
 def gemm(a, w, bias=None, mode=3, impl=0, acc=None, device=0):
