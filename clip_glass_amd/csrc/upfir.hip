@@ -18,6 +18,7 @@
 // slice per tap-row stage, register prefetch).
 #include "common.h"
 #include "kernels.h"
+#include <stdlib.h>
 
 #define ROWB 80
 
@@ -260,10 +261,418 @@ __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, in
     }
 }
 
+
+// =====================================================================================================================
+// upfir2 (round 3): the same arithmetic on a different tile geometry.  Per-launch MFMA work of upfir_kernel ran at 0.77-0.92
+// PFLOP/s, but only 33 % (r64) / 48 % (r128) / 58 % (r256) of it was useful: 8 x 32 computed per 6 x 30 kept (t halo), 60-wide
+// output tiles over 64 / 128 / 256 columns, 12-row tiles over 2^k rows.  Two changes, both pure index math:
+//   * ROLLING STRIPS: a workgroup walks S consecutive 8-row steps down the image and keeps the FIR's sliding window (three
+//     horizontally filtered rows per thread) in registers, so only a segment's first step recomputes the vertical t halo:
+//     16 output rows per 8 computed rows instead of 12.
+//   * VIRTUAL IMAGE GRID (shared-weight layers): the NXI x NYI candidates of a launch are laid side by side with ONE zero row /
+//     column between them (pitch W + 1).  That zero column is exactly what the transposed conv needs at an image edge
+//     (t[2W] = x[W-1] w[2] + 0 * w[0], t[-1] = 0), so tiles and strips run straight across image boundaries and the
+//     quantisation loss of a 60-wide tile over a 64-wide image (53 % useful) becomes 32 / 33.  Every per-sample operand
+//     (style, demodulation, consumer style, noise plane) is looked up per lane / per row from small LDS tables filled at
+//     the top of each step; a tile touches at most 4 x 2 images (W >= 16, H >= 8).
+//   * work order: XCD (block id % 8) owns a fixed group of n tiles (weights of a group stay in its 4 MiB L2) and a slice of
+//     the pixel work (the 4.7 MB of 512 x 512 weights were re-streamed per pixel tile, 15-25x read over-fetch).
+// =====================================================================================================================
+struct UpGeo {
+    int NTn, ngroups;          // 32-wide n tiles; XCD groups the n tiles are dealt to (divides 8 and NTn)
+    int tiles_x, n_seg, S;     // 60-column tiles per virtual row, segments per grid, 8-row steps per segment
+    int NXI, NYI, n_grids;     // candidates per virtual grid (x, y), grids per launch
+    int WT;                    // pixel work items = n_grids * n_seg * tiles_x
+    unsigned invPX, invPY;     // ceil(2^32 / (W + 1)), ceil(2^32 / (H + 1)): exact n / pitch for the ranges used here
+    unsigned inv2PX, inv2PY;   // same for the output pitches 2 (W + 1), 2 (H + 1)
+};
+
+namespace {
+constexpr int U_PH = 9, U_PW = 33;
+constexpr int U_NVA = U_PH * U_PW * 4, U_NA = (U_NVA + 255) / 256;     // 1188 -> 5
+constexpr int U_NVB = 9 * 32 * 4, U_NB = (U_NVB + 255) / 256;          // 1152 -> 5
+constexpr int U_A_BYTES = ((U_PH * U_PW * ROWB + 15) / 16) * 16;       // 23760
+// per-step constant tables live in the tail of the T tile that the staging images do not reach (46800 ..): they are read
+// into registers before the T tile is written
+constexpr int U_OFF_STY = 46848;                   // [8 images][Cin] fp16 style rows (Cin <= 512)
+constexpr int U_OFF_DS = U_OFF_STY + 8 * 1024;     // [8][32] fp32 demodulation
+constexpr int U_OFF_PS = U_OFF_DS + 8 * 128;       // [8][32] fp16 consumer style
+constexpr int U_OFF_BI = U_OFF_PS + 8 * 64;        // [32] fp32 bias
+constexpr int U_OFF_NZ = U_OFF_BI + 128;           // [16 rows][60 cols] fp32 noise * strength
+static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32 * ROWB, "constant tables fit behind the staging images");
+__device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
+    constexpr int PW = U_PW, NVA = U_NVA, NA = U_NA, NVB = U_NVB, NB = U_NB, A_BYTES = U_A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;
+    char* Bs = smem + A_BYTES;
+    half_t* T = (half_t*)smem;                  // [16][64][32] fp16, overlays the staging area afterwards
+
+    // ---- work item: XCD xcd owns n-tile group xcd % G and pixel slice xcd / G ---------------------------------------
+    const int id = blockIdx.x;
+    const int xcd = id & 7, rest = id >> 3;
+    const int G = g.ngroups, NTg = g.NTn / G, Pp = 8 / G;
+    const int nt = (xcd % G) * NTg + rest % NTg;
+    const int wt = (rest / NTg) * Pp + xcd / G;
+    if (wt >= g.WT) return;
+    const int txi = wt % g.tiles_x, seg = (wt / g.tiles_x) % g.n_seg, gi = wt / (g.tiles_x * g.n_seg);
+    const int n0 = nt * 32;
+    const int img0 = gi * g.NXI * g.NYI;
+    const int PX = p.W + 1, PY = p.H + 1;
+    const int mx0 = txi * 30 - 1;                           // virtual m column of lane 0
+    const int Y0 = seg * (12 + 16 * (g.S - 1));             // first virtual output row of the segment
+    const int out_rows = 2 * PY * g.NYI - 2;                // virtual output rows that exist
+    const int ixi0 = (int)__umulhi((unsigned)max(mx0 - 1, 0), g.invPX);     // first image column the tile's patch touches
+    const bool multi = g.NXI * g.NYI > 1;
+
+    const half_t* wb = p.w_up + (p.w_bstride ? (long long)img0 * p.w_bstride : 0LL);   // per-sample weights: one image per grid
+    // weight vector u = t + 256 k sits at tap (u >> 7), row (u >> 2) & 31: k only moves the tap, by a uniform 2 k * Cout * Cin
+    // (the last, half-empty round re-reads round 3's vector in threads >= 128)
+    const int b_goff0 = ((threadIdx.x >> 7) * p.Cout + n0 + ((threadIdx.x >> 2) & 31)) * p.Cin + (threadIdx.x & 3) * 8;
+    const int b_step = 2 * p.Cout * p.Cin;
+    h8 hs[4];   // FIR threads: horizontally filtered t rows, a sliding window that runs on from step to step
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hs[i][j] = (half_t)0.f;
+
+    for (int step = 0; step < g.S; ++step) {
+        const int o_first = Y0 + (step ? 16 * step - 4 : 0);   // first output row this step emits
+        if (o_first >= out_rows) break;                         // (uniform) the segment runs off the grid
+        const int my0 = (Y0 >> 1) - 1 + 8 * step;               // virtual m row of the step's first computed row
+        const int iyi0 = (int)__umulhi((unsigned)max(my0 - 1, 0), g.invPY);
+        // table entry sel = dy * 4 + dx  <->  image (iyi0 + dy, ixi0 + dx), clamped to an image that exists (its values then
+        // only ever meet masked operands, but they must be finite)
+        auto sel_img = [&](int sel) {
+            const int iyi = min(iyi0 + (sel >> 2), g.NYI - 1), ixi = min(ixi0 + (sel & 3), g.NXI - 1);
+            return min(img0 + iyi * g.NXI + ixi, p.B - 1);
+        };
+
+        // ---- staging geometry of this step (re-derived from an opaque thread id: nothing here may be hoisted and kept) ----
+        int a_goff[NA];
+        int okm = 0, selm = 0;
+        {
+            const int t = u_opaque(threadIdx.x), part = t & 3;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {
+                const int v = t + 256 * k;
+                const int pix = v >> 2;
+                const int pr = pix / PW, pc = pix - pr * PW;
+                const int vy = my0 - 1 + pr, vx = mx0 - 1 + pc;
+                const int iyi = (int)__umulhi((unsigned)max(vy, 0), g.invPY), ixi = (int)__umulhi((unsigned)max(vx, 0), g.invPX);
+                const int iy = vy - iyi * PY, ix = vx - ixi * PX;
+                const int img = img0 + iyi * g.NXI + ixi;
+                const bool ok = v < NVA && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
+                a_goff[k] = ok ? img * (int)p.x_bstride + (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
+                okm |= (ok ? 1 : 0) << k;
+                selm |= ((((iyi - iyi0) << 2) + (ixi - ixi0)) & 7) << (3 * k);
+            }
+        }
+        // interior tile of a single-image grid whose weights carry the style: registers -> LDS as they are
+        const bool plain = !multi && !p.sn16 && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
+
+        h8 ra[NA], rb[NB];
+        auto load_a = [&](int c0) {
+#pragma unroll
+            for (int k = 0; k < NA; ++k) ra[k] = *(const h8*)(p.x + a_goff[k] + c0);
+        };
+        auto load_b = [&](int c0) {
+            const half_t* wp = wb + b_goff0 + c0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) rb[k] = *(const h8*)(wp + ((k == NB - 1 && threadIdx.x >= 128) ? k - 1 : k) * b_step);
+        };
+        auto store_a = [&](int c0) {
+            const int t = threadIdx.x, part = t & 3;
+            char* ab = As + (t >> 2) * ROWB + part * 16;          // vector k sits 64 rows further down
+            if (plain) {
+#pragma unroll
+                for (int k = 0; k < NA; ++k)
+                    if (k < NA - 1 || t + 256 * k < NVA) *(h8*)(ab + k * 64 * ROWB) = ra[k];
+            } else {
+                const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                const char* sty = smem + U_OFF_STY + (c0 + part * 8) * 2;
+#pragma unroll
+                for (int k = 0; k < NA; ++k) {
+                    if (k < NA - 1 || t + 256 * k < NVA) {
+                        h8 a = ((okm >> k) & 1) ? ra[k] : zero;
+                        if (p.sn16) a = a * *(const h8*)(sty + ((selm >> (3 * k)) & 7) * 1024);   // the vector's own image's style
+                        *(h8*)(ab + k * 64 * ROWB) = a;
+                    }
+                }
+            }
+        };
+        auto store_b = [&]() {
+            const int t = threadIdx.x, part = t & 3;
+            char* bb = Bs + (t >> 2) * ROWB + part * 16;
+#pragma unroll
+            for (int k = 0; k < NB; ++k)
+                if (k < NB - 1 || t + 256 * k < NVB) *(h8*)(bb + k * 64 * ROWB) = rb[k];
+        };
+
+        __syncthreads();   // the previous step's FIR is done with the T tile (and with the tables behind it)
+        // ---- constant tables of this step: ONE batch of global loads, issued ahead of stage 0's operands --------------
+        {
+            const int t = u_opaque(threadIdx.x);
+            const int cin8 = p.Cin >> 3;
+            h8 sv[2];
+            float dsv = 1.f, biv = 0.f, nzv4[4];
+            half_t psv = (half_t)1.f;
+            if (p.sn16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = min(t + 256 * u, 8 * cin8 - 1);
+                    const int sel = e / cin8, piece = e - sel * cin8;
+                    sv[u] = *(const h8*)(p.sn16 + (long long)sel_img(sel) * p.sn_stride + piece * 8);
+                }
+            }
+            const int sel = t >> 5, ch = t & 31;
+            if (p.dscale) dsv = p.dscale[(long long)sel_img(sel) * p.ds_stride + n0 + ch];
+            if (p.post_scale16) psv = p.post_scale16[(long long)sel_img(sel) * p.post_stride + n0 + ch];
+            if (p.bias && t < 32) biv = p.bias[n0 + t];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                nzv4[u] = 0.f;
+                if (p.noise) {
+                    const int e = min(t + 256 * u, 959);
+                    const int r = e / 60, c = e - r * 60;
+                    const int ovy = max(Y0 + 16 * step + r - 4, 0), ovx = txi * 60 + c;
+                    const int iyi = (int)__umulhi((unsigned)ovy, g.inv2PY), ixi = (int)__umulhi((unsigned)ovx, g.inv2PX);
+                    const int oy = min(ovy - iyi * 2 * PY, p.Ho - 1), ox = min(ovx - ixi * 2 * PX, p.Wo - 1);
+                    const int img = min(img0 + min(iyi, g.NYI - 1) * g.NXI + min(ixi, g.NXI - 1), p.B - 1);
+                    nzv4[u] = p.noise[((long long)(img / p.batch_size) * p.Ho + oy) * p.Wo + ox];
+                }
+            }
+            load_a(0);
+            load_b(0);
+            if (p.sn16) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = t + 256 * u;
+                    if (e < 8 * cin8) {
+                        const int sel = e / cin8, piece = e - sel * cin8;
+                        *(h8*)(smem + U_OFF_STY + sel * 1024 + piece * 16) = sv[u];
+                    }
+                }
+            }
+            *(float*)(smem + U_OFF_DS + t * 4) = dsv;
+            *(half_t*)(smem + U_OFF_PS + t * 2) = psv;
+            if (t < 32) *(float*)(smem + U_OFF_BI + t * 4) = biv;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (t + 256 * u < 960) *(float*)(smem + U_OFF_NZ + (t + 256 * u) * 4) = p.noise_strength * nzv4[u];
+        }
+        __syncthreads();   // style rows visible to stage 0's store_a
+
+        f16x acc[2][4];   // [m-row of this wave][parity class ry*2+rx]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        // tap (ky,kx) feeds parity class (ky&1, kx&1) and reads x[m - (ky>>1), n - (kx>>1)] (see upfir_kernel)
+        auto mfma_block = [&]() {
+            const int tm = u_opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, wave = tm >> 6;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int ay = 0; ay < 2; ++ay) {
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax) {
+                        h8 wf[2][2];
+#pragma unroll
+                        for (int ky = ay * 2; ky < (ay ? 3 : 2); ++ky)
+#pragma unroll
+                            for (int kx = ax * 2; kx < (ax ? 3 : 2); ++kx)
+                                wf[ky & 1][kx & 1] = *(const h8*)(Bs + ((ky * 3 + kx) * 32 + lr) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int prow = wave * 2 + i + 1 - ay;
+                            const h8 xf = *(const h8*)(As + (prow * PW + lr + 1 - ax) * ROWB + kk * 32 + kh * 16);
+#pragma unroll
+                            for (int ky = ay * 2; ky < (ay ? 3 : 2); ++ky)
+#pragma unroll
+                                for (int kx = ax * 2; kx < (ax ? 3 : 2); ++kx)
+                                    acc[i][(ky & 1) * 2 + (kx & 1)] = mfma32(wf[ky & 1][kx & 1], xf, acc[i][(ky & 1) * 2 + (kx & 1)]);
+                        }
+                    }
+                }
+            }
+        };
+        const int n_stages = p.Cin >> 5;
+        for (int s = 0; s + 1 < n_stages; ++s) {
+            if (s > 0) __syncthreads();
+            store_a(s * 32);
+            store_b();
+            __syncthreads();
+            load_a((s + 1) * 32);
+            load_b((s + 1) * 32);
+            mfma_block();
+        }
+        if (n_stages > 1) __syncthreads();
+        store_a((n_stages - 1) * 32);
+        store_b();
+        __syncthreads();
+        mfma_block();
+
+        // ---- this step's constants: LDS tables -> registers (the T tile is about to cover them) -------------------------
+        const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+        const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
+        f4 dq[2][4];
+        {
+            const int ixl = (int)__umulhi((unsigned)max(mx0 + lr, 0), g.invPX) - ixi0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int iyl = (int)__umulhi((unsigned)max(my0 + 2 * wave + i, 0), g.invPY) - iyi0;
+                const char* dp = smem + U_OFF_DS + (((iyl << 2) + ixl) & 7) * 128 + kh * 16;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) dq[i][gq] = *(const f4*)(dp + gq * 32);
+            }
+        }
+        const int ovx = txi * 60 + min(oxl, 59);
+        const int ixo = (int)__umulhi((unsigned)ovx, g.inv2PX);
+        const int ox = ovx - ixo * 2 * PX;
+        const bool col_on = t < 240 && ox < p.Wo && ixo < g.NXI;
+        h8 bias8, psa, psb;
+        {
+            const f4 b0 = *(const f4*)(smem + U_OFF_BI + cg * 32), b1 = *(const f4*)(smem + U_OFF_BI + cg * 32 + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)b0[j]; bias8[j + 4] = (half_t)b1[j]; }
+            const int sx = (ixo - ixi0) & 3;
+            psa = *(const h8*)(smem + U_OFF_PS + sx * 64 + cg * 16);
+            psb = *(const h8*)(smem + U_OFF_PS + (4 + sx) * 64 + cg * 16);
+        }
+        float nzr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nzr[r] = *(const float*)(smem + U_OFF_NZ + (r * 60 + min(oxl, 59)) * 4);
+        __syncthreads();   // everyone is done with the staging area and the tables: overlay T
+
+        // ---- t tile -> LDS (demod applied; it commutes with the FIR); layout as in upfir_kernel --------------------------
+        {
+            char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+            int so[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        h4 o;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][gq * 4 + q] * dq[i][gq][q]);
+                        *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                    }
+        }
+        __syncthreads();
+
+        // ---- FIR (separable [1,3,3,1]/4 per axis) + noise + bias + lrelu; T row r <-> virtual output row Y0 + 16 step + r - 4 ----
+        if (col_on) {
+            const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+            const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+            const char* tr[4];
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const int ltx = oxl + 1 + jx;
+                tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+            }
+            const int ovy0 = Y0 + 16 * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
+            const int yb = 2 * PY * (iyi0 + 1);                        // first virtual output row of the step's second image row
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
+                         v3 = *(const h8*)(tr[3] + r * 4096);
+                hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
+                const int ovy = ovy0 + r;
+                const bool second = ovy >= yb;
+                const int iyo = iyi0 + (second ? 1 : 0);
+                const int oy = ovy - 2 * PY * iyo;
+                const int img = img0 + iyo * g.NXI + ixo;
+                if ((step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B) {
+                    const h8 bn = bias8 + (half_t)nzr[r];
+                    h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
+                    half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
+                    *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
+                }
+            }
+        }
+    }
+}
+
+static unsigned u_inv(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+
+static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
+    if (p.Cin > 512 || p.H < 8 || p.W < 16) return nullptr;
+    if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
+    if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
+    constexpr int LDS = 64 * 1024;
+    static bool attr[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)upfir2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr[dev] = true;
+    }
+    static const int env_ng = getenv("GLASS_UPFIR_NG") ? atoi(getenv("GLASS_UPFIR_NG")) : 0;      // A/B knobs
+    static const int env_s = getenv("GLASS_UPFIR_S") ? atoi(getenv("GLASS_UPFIR_S")) : 0;
+    static const bool no_grid = getenv("GLASS_UPFIR_NO_GRID") != nullptr;
+    UpGeo g;
+    g.NTn = p.Cout / 32;
+    // candidates per virtual grid: per-sample weights -> one (its tiles share a weight set); shared weights -> up to 8 x 8
+    if (p.w_bstride || no_grid) { g.NXI = 1; g.NYI = 1; }
+    else {
+        g.NXI = p.B < 8 ? p.B : 8;
+        g.NYI = (p.B + g.NXI - 1) / g.NXI;
+        if (g.NYI > 8) g.NYI = 8;
+    }
+    g.n_grids = (p.B + g.NXI * g.NYI - 1) / (g.NXI * g.NYI);
+    const int PX = p.W + 1, PY = p.H + 1;
+    g.tiles_x = (2 * PX * g.NXI - 2 + 59) / 60;
+    const int out_rows = 2 * PY * g.NYI - 2;
+    // steps per segment: as long as possible (only a segment's first step recomputes the t halo) while the launch still has
+    // >= 8 workgroups per CU-slot pair to balance (2048); never longer than the grid
+    int S = 8;
+    for (; S > 1; --S) {
+        const int R = 12 + 16 * (S - 1);
+        const long long wgs = (long long)g.n_grids * g.tiles_x * ((out_rows + R - 1) / R) * g.NTn;
+        if (wgs >= 2048 && R <= out_rows + 15) break;
+    }
+    if (env_s > 0) S = env_s;
+    g.S = S;
+    const int R = 12 + 16 * (S - 1);
+    g.n_seg = (out_rows + R - 1) / R;
+    g.WT = g.n_grids * g.n_seg * g.tiles_x;
+    // n tiles per XCD group: the group's weights (9 * 32 * Cin * 2 B per n tile) should stay resident in a 4 MiB L2 next to the
+    // input patches; per-sample weights are image-local already
+    int ng = 1;
+    if (!p.w_bstride) {
+        const long long per_tile = 9LL * 32 * p.Cin * 2;
+        while (ng < 8 && g.NTn % (ng * 2) == 0 && (g.NTn / ng) * per_tile > (1200LL << 10)) ng *= 2;
+    }
+    if (env_ng > 0 && 8 % env_ng == 0 && g.NTn % env_ng == 0) ng = env_ng;
+    g.ngroups = ng;
+    g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
+    if (p.dry_run) return "upfir2_kernel";
+    const int Pp = 8 / ng;
+    const int grid = 8 * ((g.WT + Pp - 1) / Pp) * (g.NTn / ng);
+    hipLaunchKernelGGL(upfir2_kernel, dim3(grid), dim3(256), LDS, st, p, g);
+    return "upfir2_kernel";
+}
+
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     if (!p.up || !p.w_up || p.y32 || !p.y || p.res || (p.sn && !p.sn16)) return nullptr;
-    if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.W < 16 || p.KS != 3) return nullptr;
+    if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.KS != 3) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;
+    static const bool v1 = getenv("GLASS_UPFIR_V1") != nullptr;      // A/B knob: round 2's one-tile-per-workgroup kernel
+    if (!v1) {
+        const char* k = launch_upfir2(p, st);
+        if (k) return k;
+    }
+    if (p.W < 16) return nullptr;
+
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     constexpr int LDS = 64 * 1024;  // T tile (16*64*32*2 B); staging (31.5 KB) lives inside it
     static bool attr = false;

@@ -342,3 +342,134 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
                         for i in range(64):
                             out[b, ty0 + wave, tx0 + pix[i], chv[i] * 8:chv[i] * 8 + 8] = data[i]
     return out.astype(np.float32)
+
+
+# upfir.hip / upfir2_kernel emulated at the level of its tile GEOMETRY: virtual image grid (pitch W + 1, H + 1), 60-column tiles,
+# rolling 8-row steps with the FIR window carried from step to step, per-lane / per-row image look-ups through the 8-entry
+# tables (sel = dy * 4 + dx), parity-class accumulation of the nine taps, T tile [16][64], packed-fp16 FIR.  LDS addressing of the
+# staging images and of the T tile is unchanged from round 2's upfir_kernel and is not re-emulated.
+def upfir2_geometry(B, H, W, Cout, per_sample_weights=False, S=None):
+    """launch_upfir2()'s choices (csrc/upfir.hip)."""
+    NTn = Cout // 32
+    if per_sample_weights:
+        NXI = NYI = 1
+    else:
+        NXI = min(B, 8)
+        NYI = min((B + NXI - 1) // NXI, 8)
+    n_grids = (B + NXI * NYI - 1) // (NXI * NYI)
+    PX, PY = W + 1, H + 1
+    tiles_x = (2 * PX * NXI - 2 + 59) // 60
+    out_rows = 2 * PY * NYI - 2
+    if S is None:
+        S = 8
+        while S > 1:
+            R = 12 + 16 * (S - 1)
+            if n_grids * tiles_x * ((out_rows + R - 1) // R) * NTn >= 2048 and R <= out_rows + 15:
+                break
+            S -= 1
+    R = 12 + 16 * (S - 1)
+    return dict(NTn=NTn, NXI=NXI, NYI=NYI, n_grids=n_grids, tiles_x=tiles_x, S=S, n_seg=(out_rows + R - 1) // R, out_rows=out_rows)
+
+
+def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_size=1, bias=None, act=False, out_scale=1.0,
+           post_scale=None, geo=None):
+    f16 = np.float16
+    x = np.asarray(x, np.float32).astype(f16)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    g = geo or upfir2_geometry(B, H, W, Cout)
+    wk = real_ops.host_pack_conv(np.asarray(w, np.float32), False).astype(f16)      # [9][Cout][Cin]
+    PX, PY, NXI, NYI, S = W + 1, H + 1, g["NXI"], g["NYI"], g["S"]
+    Ho, Wo = 2 * H, 2 * W
+    out = np.full((B, Ho, Wo, Cout), np.nan, np.float32)
+    written = np.zeros((B, Ho, Wo), np.int32)
+    sn16 = None if sn is None else np.asarray(sn, np.float32).astype(f16)
+    ps16 = None if post_scale is None else np.asarray(post_scale, np.float32).astype(f16)
+    k1 = f16((math.sqrt(2) if act else 1.0) * out_scale)
+    k2 = f16((0.2 * math.sqrt(2) if act else 1.0) * out_scale)
+    lr = np.arange(32)
+
+    def pk(a):                    # result of one packed-fp16 instruction
+        return np.asarray(a, np.float32).astype(f16)
+
+    for gi in range(g["n_grids"]):
+        img0 = gi * NXI * NYI
+        for seg in range(g["n_seg"]):
+            for txi in range(g["tiles_x"]):
+                mx0 = txi * 30 - 1
+                Y0 = seg * (12 + 16 * (S - 1))
+                ixi0 = max(mx0 - 1, 0) // PX
+                hs = np.zeros((4, 60, Cout), f16)                    # sliding window (all n tiles at once)
+                for step in range(S):
+                    o_first = Y0 + (16 * step - 4 if step else 0)
+                    if o_first >= g["out_rows"]:
+                        break
+                    my0 = (Y0 >> 1) - 1 + 8 * step
+                    iyi0 = max(my0 - 1, 0) // PY
+
+                    def sel_img(sel):
+                        iyi = min(iyi0 + (sel >> 2), NYI - 1); ixi = min(ixi0 + (sel & 3), NXI - 1)
+                        return min(img0 + iyi * NXI + ixi, B - 1)
+                    # staged patch [9][33][Cin] (style applied per vector from the table of its own image)
+                    patch = np.zeros((9, 33, Cin), f16)
+                    for pr in range(9):
+                        for pc in range(33):
+                            vy, vx = my0 - 1 + pr, mx0 - 1 + pc
+                            iyi, ixi = max(vy, 0) // PY, max(vx, 0) // PX
+                            iy, ix = vy - iyi * PY, vx - ixi * PX
+                            img = img0 + iyi * NXI + ixi
+                            ok = vy >= 0 and vx >= 0 and iy < H and ix < W and iyi < NYI and ixi < NXI and img < B
+                            sel = (((iyi - iyi0) << 2) + (ixi - ixi0)) & 7
+                            if ok:
+                                assert sel_img(sel) == img, "table entry of a live vector must be its image"
+                                a = x[img, iy, ix]
+                                patch[pr, pc] = a if sn16 is None else pk(a.astype(np.float32) * sn16[img].astype(np.float32))
+                    # transposed conv by parity class: acc[j][class][pixel lane][ch]
+                    acc = np.zeros((8, 4, 32, Cout), np.float64)
+                    for ky in range(3):
+                        for kx in range(3):
+                            ay, ax = ky >> 1, kx >> 1
+                            for j in range(8):
+                                xf = patch[j + 1 - ay, lr + 1 - ax].astype(np.float64)            # [32][Cin]
+                                acc[j, (ky & 1) * 2 + (kx & 1)] += xf @ wk[ky * 3 + kx].astype(np.float64).T
+                    # T tile (demod applied per lane from the table of the lane's image)
+                    T = np.zeros((16, 64, Cout), f16)
+                    for j in range(8):
+                        iyl = max(my0 + j, 0) // PY - iyi0
+                        for l in range(32):
+                            ixl = max(mx0 + l, 0) // PX - ixi0
+                            d = 1.0 if dscale is None else np.asarray(dscale, np.float32)[sel_img(((iyl << 2) + ixl) & 7)]
+                            for ph in range(4):
+                                T[2 * j + (ph >> 1), 2 * l + (ph & 1)] = (acc[j, ph, l].astype(np.float32) * d).astype(f16)
+                    # FIR
+                    yb = 2 * PY * (iyi0 + 1)
+                    for r in range(16):
+                        v = [T[r, 1 + jx:61 + jx].astype(np.float32) for jx in range(4)]
+                        hs[r & 3] = pk(pk(pk(v[0] + v[3]).astype(np.float32) * 0.25) + pk(pk(v[1] + v[2]).astype(np.float32) * 0.75))
+                        ovy = Y0 + 16 * step - 4 + r
+                        second = ovy >= yb
+                        iyo = iyi0 + (1 if second else 0)
+                        oy = ovy - 2 * PY * iyo
+                        if not ((step > 0 or r >= 4) and 0 <= oy < Ho and iyo < NYI):
+                            continue
+                        a = pk(hs[(r - 3) & 3].astype(np.float32) + hs[r & 3].astype(np.float32))
+                        m = pk(hs[(r - 2) & 3].astype(np.float32) + hs[(r - 1) & 3].astype(np.float32))
+                        for oxl in range(60):
+                            ovx = txi * 60 + oxl
+                            ixo = ovx // (2 * PX)
+                            ox = ovx - ixo * 2 * PX
+                            img = img0 + iyo * NXI + ixo
+                            if not (ox < Wo and ixo < NXI and img < B):
+                                continue
+                            nz = 0.0 if noise is None else noise_strength * float(np.asarray(noise, np.float32)[img // batch_size, oy, ox])
+                            bn = pk((0.0 if bias is None else np.asarray(bias, np.float32)).astype(f16).astype(np.float32) + np.float32(f16(nz)))
+                            vv = pk(a[oxl].astype(np.float32) * 0.25 + pk(m[oxl].astype(np.float32) * 0.75 + bn.astype(np.float32)).astype(np.float32))
+                            o = np.maximum(pk(vv.astype(np.float32) * np.float32(k1)), pk(vv.astype(np.float32) * np.float32(k2)))
+                            sx = (ixo - ixi0) & 3
+                            if ps16 is not None:
+                                o = pk(o.astype(np.float32) * ps16[sel_img((4 if second else 0) + sx)].astype(np.float32))
+                                assert sel_img((4 if second else 0) + sx) == img
+                            out[img, oy, ox] = o.astype(np.float32)
+                            written[img, oy, ox] += 1
+    assert (written == 1).all(), "every output pixel is written exactly once (%d .. %d)" % (written.min(), written.max())
+    return out

@@ -323,6 +323,20 @@ def test_conv_modulated_up(impl):
     check("modconv-up impl%s" % (impl,), nchw(got), ref, 5e-3)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,bs", [
+    (5, 16, 32, 32, 1),      # 5 x 1 virtual grid of 16 x 16 images (a tile spans three of them)
+    (12, 16, 64, 64, 4),     # 8 x 2 grid, noise planes shared by minibatches of 4
+    (9, 32, 32, 32, 3),      # 8 x 2 grid with seven empty slots
+    (20, 16, 32, 96, 1),     # 8 x 3 grid, three n tiles
+    (70, 16, 32, 32, 2),     # two grids (8 x 8 + 6)
+    (3, 64, 96, 64, 1),      # three chunks, rolling segments inside one image row
+])
+def test_conv_up_virtual_grid(B, H, Cin, Cout, bs):
+    """upfir2_kernel (round 3): tiles and strips run across the candidates of a launch (csrc/upfir.hip)."""
+    got, ref = _modconv_case(True, (3, H, Cin, Cout), B=B, batch_size=bs)
+    check("modconv-up grid B%d H%d %d->%d" % (B, H, Cin, Cout), nchw(got), ref, 5e-3)
+
+
 def test_conv_broadcast_const():
     got, ref = _modconv_case(False, 1, B=4, H=4, Cin=32, Cout=32, broadcast=True)
     check("modconv const-input", nchw(got), ref, 5e-3)
