@@ -303,6 +303,10 @@ static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32
 __device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 }  // namespace
 
+// GRID = true: shared weights, candidates on a virtual grid, per-image operands through the LDS tables.
+// GRID = false: per-sample weights (which carry style and demodulation): one candidate per grid, no tables, no index
+// divisions — the 512^2 / 1024^2 layers are instruction-issue bound, every instruction per step counts.
+template <bool GRID>
 __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     constexpr int PW = U_PW, NVA = U_NVA, NA = U_NA, NVB = U_NVB, NB = U_NB, A_BYTES = U_A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -324,8 +328,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     const int mx0 = txi * 30 - 1;                           // virtual m column of lane 0
     const int Y0 = seg * (12 + 16 * (g.S - 1));             // first virtual output row of the segment
     const int out_rows = 2 * PY * g.NYI - 2;                // virtual output rows that exist
-    const int ixi0 = (int)__umulhi((unsigned)max(mx0 - 1, 0), g.invPX);     // first image column the tile's patch touches
-    const bool multi = g.NXI * g.NYI > 1;
+    const int ixi0 = GRID ? (int)__umulhi((unsigned)max(mx0 - 1, 0), g.invPX) : 0;     // first image column the tile's patch touches
 
     const half_t* wb = p.w_up + (p.w_bstride ? (long long)img0 * p.w_bstride : 0LL);   // per-sample weights: one image per grid
     // weight vector u = t + 256 k sits at tap (u >> 7), row (u >> 2) & 31: k only moves the tap, by a uniform 2 k * Cout * Cin
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         const int o_first = Y0 + (step ? 16 * step - 4 : 0);   // first output row this step emits
         if (o_first >= out_rows) break;                         // (uniform) the segment runs off the grid
         const int my0 = (Y0 >> 1) - 1 + 8 * step;               // virtual m row of the step's first computed row
-        const int iyi0 = (int)__umulhi((unsigned)max(my0 - 1, 0), g.invPY);
+        const int iyi0 = GRID ? (int)__umulhi((unsigned)max(my0 - 1, 0), g.invPY) : 0;
         // table entry sel = dy * 4 + dx  <->  image (iyi0 + dy, ixi0 + dx), clamped to an image that exists (its values then
         // only ever meet masked operands, but they must be finite)
         auto sel_img = [&](int sel) {
@@ -361,17 +364,23 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 const int pix = v >> 2;
                 const int pr = pix / PW, pc = pix - pr * PW;
                 const int vy = my0 - 1 + pr, vx = mx0 - 1 + pc;
-                const int iyi = (int)__umulhi((unsigned)max(vy, 0), g.invPY), ixi = (int)__umulhi((unsigned)max(vx, 0), g.invPX);
-                const int iy = vy - iyi * PY, ix = vx - ixi * PX;
-                const int img = img0 + iyi * g.NXI + ixi;
-                const bool ok = v < NVA && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
-                a_goff[k] = ok ? img * (int)p.x_bstride + (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
-                okm |= (ok ? 1 : 0) << k;
-                selm |= ((((iyi - iyi0) << 2) + (ixi - ixi0)) & 7) << (3 * k);
+                if (GRID) {
+                    const int iyi = (int)__umulhi((unsigned)max(vy, 0), g.invPY), ixi = (int)__umulhi((unsigned)max(vx, 0), g.invPX);
+                    const int iy = vy - iyi * PY, ix = vx - ixi * PX;
+                    const int img = img0 + iyi * g.NXI + ixi;
+                    const bool ok = v < NVA && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
+                    a_goff[k] = ok ? img * (int)p.x_bstride + (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
+                    okm |= (ok ? 1 : 0) << k;
+                    selm |= ((((iyi - iyi0) << 2) + (ixi - ixi0)) & 7) << (3 * k);
+                } else {
+                    const bool ok = v < NVA && vy >= 0 && vx >= 0 && vy < p.H && vx < p.W;
+                    a_goff[k] = ok ? img0 * (int)p.x_bstride + (vy * p.W + vx) * p.Cin + part * 8 : part * 8;
+                    okm |= (ok ? 1 : 0) << k;
+                }
             }
         }
         // interior tile of a single-image grid whose weights carry the style: registers -> LDS as they are
-        const bool plain = !multi && !p.sn16 && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
+        const bool plain = !GRID && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
 
         h8 ra[NA], rb[NB];
         auto load_a = [&](int c0) {
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int k = 0; k < NA; ++k) {
                     if (k < NA - 1 || t + 256 * k < NVA) {
                         h8 a = ((okm >> k) & 1) ? ra[k] : zero;
-                        if (p.sn16) a = a * *(const h8*)(sty + ((selm >> (3 * k)) & 7) * 1024);   // the vector's own image's style
+                        if (GRID && p.sn16) a = a * *(const h8*)(sty + ((selm >> (3 * k)) & 7) * 1024);   // the vector's own image's style
                         *(h8*)(ab + k * 64 * ROWB) = a;
                     }
                 }
@@ -412,8 +421,8 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         };
 
         __syncthreads();   // the previous step's FIR is done with the T tile (and with the tables behind it)
-        // ---- constant tables of this step: ONE batch of global loads, issued ahead of stage 0's operands --------------
-        {
+        if (GRID) {
+            // ---- constant tables of this step: ONE batch of global loads, issued ahead of stage 0's operands --------------
             const int t = u_opaque(threadIdx.x);
             const int cin8 = p.Cin >> 3;
             h8 sv[2];
@@ -462,8 +471,11 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
                 if (t + 256 * u < 960) *(float*)(smem + U_OFF_NZ + (t + 256 * u) * 4) = p.noise_strength * nzv4[u];
+            __syncthreads();   // style rows visible to stage 0's store_a
+        } else {
+            load_a(0);
+            load_b(0);
         }
-        __syncthreads();   // style rows visible to stage 0's store_a
 
         f16x acc[2][4];   // [m-row of this wave][parity class ry*2+rx]
 #pragma unroll
@@ -515,87 +527,160 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         store_a((n_stages - 1) * 32);
         store_b();
         __syncthreads();
-        mfma_block();
 
-        // ---- this step's constants: LDS tables -> registers (the T tile is about to cover them) -------------------------
-        const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
-        const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
-        f4 dq[2][4];
-        {
-            const int ixl = (int)__umulhi((unsigned)max(mx0 + lr, 0), g.invPX) - ixi0;
+        const int ovy0 = Y0 + 16 * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
+        if (GRID) {
+            mfma_block();
+            // ---- this step's constants: LDS tables -> registers (the T tile is about to cover them) -------------------------
+            const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+            const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
+            f4 dq[2][4];
+            {
+                const int ixl = (int)__umulhi((unsigned)max(mx0 + lr, 0), g.invPX) - ixi0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int iyl = (int)__umulhi((unsigned)max(my0 + 2 * wave + i, 0), g.invPY) - iyi0;
-                const char* dp = smem + U_OFF_DS + (((iyl << 2) + ixl) & 7) * 128 + kh * 16;
+                for (int i = 0; i < 2; ++i) {
+                    const int iyl = (int)__umulhi((unsigned)max(my0 + 2 * wave + i, 0), g.invPY) - iyi0;
+                    const char* dp = smem + U_OFF_DS + (((iyl << 2) + ixl) & 7) * 128 + kh * 16;
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) dq[i][gq] = *(const f4*)(dp + gq * 32);
+                    for (int gq = 0; gq < 4; ++gq) dq[i][gq] = *(const f4*)(dp + gq * 32);
+                }
             }
-        }
-        const int ovx = txi * 60 + min(oxl, 59);
-        const int ixo = (int)__umulhi((unsigned)ovx, g.inv2PX);
-        const int ox = ovx - ixo * 2 * PX;
-        const bool col_on = t < 240 && ox < p.Wo && ixo < g.NXI;
-        h8 bias8, psa, psb;
-        {
-            const f4 b0 = *(const f4*)(smem + U_OFF_BI + cg * 32), b1 = *(const f4*)(smem + U_OFF_BI + cg * 32 + 16);
+            const int ovx = txi * 60 + min(oxl, 59);
+            const int ixo = (int)__umulhi((unsigned)ovx, g.inv2PX);
+            const int ox = ovx - ixo * 2 * PX;
+            const bool col_on = t < 240 && ox < p.Wo && ixo < g.NXI;
+            h8 bias8, psa, psb;
+            {
+                const f4 b0 = *(const f4*)(smem + U_OFF_BI + cg * 32), b1 = *(const f4*)(smem + U_OFF_BI + cg * 32 + 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)b0[j]; bias8[j + 4] = (half_t)b1[j]; }
-            const int sx = (ixo - ixi0) & 3;
-            psa = *(const h8*)(smem + U_OFF_PS + sx * 64 + cg * 16);
-            psb = *(const h8*)(smem + U_OFF_PS + (4 + sx) * 64 + cg * 16);
-        }
-        float nzr[16];
+                for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)b0[j]; bias8[j + 4] = (half_t)b1[j]; }
+                const int sx = (ixo - ixi0) & 3;
+                psa = *(const h8*)(smem + U_OFF_PS + sx * 64 + cg * 16);
+                psb = *(const h8*)(smem + U_OFF_PS + (4 + sx) * 64 + cg * 16);
+            }
+            float nzr[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nzr[r] = *(const float*)(smem + U_OFF_NZ + (r * 60 + min(oxl, 59)) * 4);
-        __syncthreads();   // everyone is done with the staging area and the tables: overlay T
+            for (int r = 0; r < 16; ++r) nzr[r] = *(const float*)(smem + U_OFF_NZ + (r * 60 + min(oxl, 59)) * 4);
+            __syncthreads();   // everyone is done with the staging area and the tables: overlay T
 
-        // ---- t tile -> LDS (demod applied; it commutes with the FIR); layout as in upfir_kernel --------------------------
-        {
-            char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
-            int so[4];
+            // ---- t tile -> LDS (demod applied; it commutes with the FIR); layout as in upfir_kernel --------------------------
+            {
+                char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+                int so[4];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
+                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int ph = 0; ph < 4; ++ph)
+                    for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        h4 o;
+                        for (int gq = 0; gq < 4; ++gq) {
+                            h4 o;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][gq * 4 + q] * dq[i][gq][q]);
-                        *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                            for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][gq * 4 + q] * dq[i][gq][q]);
+                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                        }
+            }
+            __syncthreads();
+
+            // ---- FIR (separable [1,3,3,1]/4 per axis) + noise + bias + lrelu; T row r <-> virtual output row ovy0 + r ----
+            if (col_on) {
+                const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+                const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+                const char* tr[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int ltx = oxl + 1 + jx;
+                    tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+                }
+                const int yb = 2 * PY * (iyi0 + 1);                        // first virtual output row of the step's second image row
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
+                             v3 = *(const h8*)(tr[3] + r * 4096);
+                    hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
+                    const int ovy = ovy0 + r;
+                    const bool second = ovy >= yb;
+                    const int iyo = iyi0 + (second ? 1 : 0);
+                    const int oy = ovy - 2 * PY * iyo;
+                    const int img = img0 + iyo * g.NXI + ixo;
+                    if ((step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B) {
+                        const h8 bn = bias8 + (half_t)nzr[r];
+                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
+                        half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
+                        *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
                     }
-        }
-        __syncthreads();
-
-        // ---- FIR (separable [1,3,3,1]/4 per axis) + noise + bias + lrelu; T row r <-> virtual output row Y0 + 16 step + r - 4 ----
-        if (col_on) {
-            const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
-            const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
-            const char* tr[4];
-#pragma unroll
-            for (int jx = 0; jx < 4; ++jx) {
-                const int ltx = oxl + 1 + jx;
-                tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+                }
             }
-            const int ovy0 = Y0 + 16 * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
-            const int yb = 2 * PY * (iyi0 + 1);                        // first virtual output row of the step's second image row
+        } else {
+            // ---- single image: everything the FIR needs from global memory is fetched HERE, unconditionally and in one batch, so that
+            // it lands under the last MFMA block (upfir_kernel's scheme) ----
+            const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+            const int cg = t & 3, oxl = t >> 2;
+            const int ox = txi * 60 + oxl;
+            const int pxc = min(ox, p.Wo - 1);
+            f4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                bq0 = *(const f4*)(p.bias + n0 + cg * 8);
+                bq1 = *(const f4*)(p.bias + n0 + cg * 8 + 4);
+            }
+            h8 ps8;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
-                         v3 = *(const h8*)(tr[3] + r * 4096);
-                hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
-                const int ovy = ovy0 + r;
-                const bool second = ovy >= yb;
-                const int iyo = iyi0 + (second ? 1 : 0);
-                const int oy = ovy - 2 * PY * iyo;
-                const int img = img0 + iyo * g.NXI + ixo;
-                if ((step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B) {
-                    const h8 bn = bias8 + (half_t)nzr[r];
-                    h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
-                    half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
-                    *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
+            for (int j = 0; j < 8; ++j) ps8[j] = (half_t)1.f;
+            if (p.post_scale16) ps8 = *(const h8*)(p.post_scale16 + (long long)img0 * p.post_stride + n0 + cg * 8);
+            float nzr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nzr[r] = 0.f;
+            if (p.noise) {
+                const float* nzp = p.noise + (long long)(img0 / p.batch_size) * p.Ho * p.Wo + pxc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nzr[r] = nzp[(long long)min(max(ovy0 + r, 0), p.Ho - 1) * p.Wo];
+            }
+            mfma_block();
+            __syncthreads();   // everyone is done with the staging area: overlay T
+            {
+                char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+                int so[4];
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            h4 o;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) o[q] = (half_t)acc[i][ph][gq * 4 + q];
+                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                        }
+            }
+            __syncthreads();
+            if (t < 240 && ox < p.Wo) {
+                const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+                h8 bias8;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)bq0[j]; bias8[j + 4] = (half_t)bq1[j]; }
+                const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+                const char* tr[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    const int ltx = oxl + 1 + jx;
+                    tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+                }
+                const long long rowpitch = (long long)p.Wo * p.Cout;
+                half_t* yp = p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
+                             v3 = *(const h8*)(tr[3] + r * 4096);
+                    hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
+                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) {
+                        const h8 bn = bias8 + (half_t)(p.noise_strength * nzr[r]);
+                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
+                        *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * ps8;
+                    }
+                    yp += rowpitch;
                 }
             }
         }
@@ -613,7 +698,8 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev >= 0 && dev < 16 && !attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)upfir2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)upfir2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr[dev] = true;
     }
     static const int env_ng = getenv("GLASS_UPFIR_NG") ? atoi(getenv("GLASS_UPFIR_NG")) : 0;      // A/B knobs
@@ -655,11 +741,15 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     if (env_ng > 0 && 8 % env_ng == 0 && g.NTn % env_ng == 0) ng = env_ng;
     g.ngroups = ng;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
-    if (p.dry_run) return "upfir2_kernel";
+    // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
+    const bool lean = p.w_bstride && !p.sn16 && !p.dscale && g.NXI * g.NYI == 1;
+    const char* name = lean ? "upfir2_kernel<false>" : "upfir2_kernel<true>";
+    if (p.dry_run) return name;
     const int Pp = 8 / ng;
     const int grid = 8 * ((g.WT + Pp - 1) / Pp) * (g.NTn / ng);
-    hipLaunchKernelGGL(upfir2_kernel, dim3(grid), dim3(256), LDS, st, p, g);
-    return "upfir2_kernel";
+    if (lean) hipLaunchKernelGGL(upfir2_kernel<false>, dim3(grid), dim3(256), LDS, st, p, g);
+    else hipLaunchKernelGGL(upfir2_kernel<true>, dim3(grid), dim3(256), LDS, st, p, g);
+    return name;
 }
 
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
