@@ -31,10 +31,12 @@
 // SKIP (stride 2, fast path): ConvParams::skip_x / skip_w — the residual branch's 1x1 conv as extra K stages after an in-register
 // activation.
 // XS (3x3 stride 1, TH = 8, one n tile): ConvParams::xs_out — the blur-down of the input map from the patch already in LDS.
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false>
+// SPL: the four waves form a 2 x 2 grid (row pair x n half) instead of 4 x 1: each weight fragment a wave reads feeds two tile rows
+// (stride-2 convs, TH = 4: 8 fragment reads per 8 MFMAs instead of 10).
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false>
 __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
-    constexpr int RW = TH / 4;                 // tile rows per wave
-    constexpr int NJ = NT / 32;                // 32-wide n tiles per wave
+    constexpr int RW = SPL ? TH / 2 : TH / 4;  // tile rows per wave
+    constexpr int NJ = SPL ? NT / 64 : NT / 32; // 32-wide n tiles per wave
     constexpr int PH = (TH - 1) * S + KS;      // patch rows
     constexpr int PW = 31 * S + KS;            // patch cols
     constexpr int NVA = PH * PW * 4;           // 16-byte vectors in the A patch
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     constexpr int NVB = KS * NT * 4;           // 16-byte vectors in one weight stage
     constexpr int NB = (NVB + 255) / 256;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
-    constexpr int LDS_K_ = A_BYTES + KS * NT * ROWB, LDS_O_ = TH * 32 * (NT * 2 + 16);
+    constexpr int LDS_K_ = A_BYTES + KS * NT * ROWB, LDS_O_ = 4 * RW * 32 * (NJ * 64 + 16);
     constexpr int CC_OFF = LDS_K_ > LDS_O_ ? LDS_K_ : LDS_O_;   // epilogue constants sit behind both images
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     char* Bs = smem + A_BYTES;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wr = SPL ? (wave & 1) : wave, wn = SPL ? (wave >> 1) : 0;   // this wave's row group / n group
     const int lr = lane & 31, kh = lane >> 5;
     const int part = t & 3;
     const int tpi = tiles_x * tiles_y;
@@ -243,10 +246,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     h8 wf[NJ];
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        wf[j] = *(const h8*)(Bs + (tx * NT + j * 32 + lr) * ROWB + kk * 32 + kh * 16);
+                        wf[j] = *(const h8*)(Bs + (tx * NT + (wn * NJ + j) * 32 + lr) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
-                        const int prow = (wave * RW + i) * S + ty;
+                        const int prow = (wr * RW + i) * S + ty;
                         const int pcol = S == 2 ? ((tx & 1) ? (PW + 1) / 2 + lr + (tx >> 1) : lr + (tx >> 1)) : lr + tx;
                         const h8 xf = *(const h8*)(As + (prow * PW + pcol) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bq[j][g] = f4{0.f, 0.f, 0.f, 0.f};
-                    if (p.bias) bq[j][g] = *(const f4*)(p.bias + cur.n0 + j * 32 + 8 * g + 4 * kh);
+                    if (p.bias) bq[j][g] = *(const f4*)(p.bias + cur.n0 + (wn * NJ + j) * 32 + 8 * g + 4 * kh);
                 }
 #pragma unroll
             for (int i = 0; i < RW; ++i)
@@ -304,10 +307,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                 for (int kk = 0; kk < 2; ++kk) {
                     h8 wf[NJ];
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) wf[j] = *(const h8*)(Bs + (j * 32 + lr) * ROWB + kk * 32 + kh * 16);
+                    for (int j = 0; j < NJ; ++j) wf[j] = *(const h8*)(Bs + ((wn * NJ + j) * 32 + lr) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
-                        const h8 xf = *(const h8*)(As + ((wave * RW + i) * 32 + lr) * ROWB + kk * 32 + kh * 16);
+                        const h8 xf = *(const h8*)(As + ((wr * RW + i) * 32 + lr) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
                     }
@@ -321,9 +324,9 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             // in LDS at kernel start, the noise values and residual quads of a tile row are fetched as one batch, and
             // the finished fp16 quads go through a per-wave LDS image and leave as 16-byte vectors in row order (one
             // store instruction = 1 KB of whole 64-byte lines instead of 64 scattered 8-byte pieces).
-            constexpr int OROW = NT * 2 + 16;             // bytes per staged pixel (+16: bank spread)
+            constexpr int OROW = NJ * 64 + 16;            // bytes per staged pixel: this wave's channels (+16: bank spread)
             char* Os = smem + wave * (RW * 32 * OROW);    // this wave's RW tile rows
-            const int oy0 = cur.ty0 + wave * RW, ox = cur.tx0 + lr;
+            const int oy0 = cur.ty0 + wr * RW, ox = cur.tx0 + lr;
             // ONE batch of global loads: this thread's per-channel constants (threads < NT) and its pixels' noise values
             float c_d = 1.f, c_b = 0.f, c_s = 0.f;
             if (t < NT && !SKIP) {                         // (SKIP: bias and activation were applied before the skip stages)
@@ -370,14 +373,15 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     for (int i = 0; i < RW; ++i) {
                         const int oy = oy0 + i;
                         const half_t* rp = p.res + (p.res_up ? (((long long)b * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * rcs
-                                                             : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + cur.n0 + j * 32 + 4 * kh;
+                                                             : (((long long)b * p.Ho + oy) * p.Wo + ox) * rcs) + cur.n0 + (wn * NJ + j) * 32 + 4 * kh;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) rq[g][i] = *(const h4*)(rp + 8 * g);
                     }
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nl = j * 32 + 8 * g + 4 * kh;   // first of 4 consecutive channels, local to the n tile
+                    const int nw = j * 32 + 8 * g + 4 * kh;   // first of 4 consecutive channels, local to the wave's channels
+                    const int nl = wn * NJ * 32 + nw;          // ... local to the n tile
                     const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                         h4 out;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
-                        *(h4*)(Os + (i * 32 + lr) * OROW + nl * 2) = out;
+                        *(h4*)(Os + (i * 32 + lr) * OROW + nw * 2) = out;
                         if (TRGB) va[i][g] = out;
                     }
                     __builtin_amdgcn_sched_barrier(0);    // keep one quad's constants live at a time (no hoisting of all
@@ -431,16 +435,17 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             __builtin_amdgcn_wave_barrier();              // LDS is in-order per wave: only pin the compiler's order
 #pragma unroll
             for (int i = 0; i < RW; ++i) {
-                half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + cur.tx0) * p.Cout + cur.n0;
+                half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + cur.tx0) * p.Cout + cur.n0 + wn * NJ * 32;
 #pragma unroll
-                for (int k = 0; k < NT / 16; ++k) {
+                for (int k = 0; k < NJ * 2; ++k) {
                     const int v = lane + 64 * k;
-                    const int pix = v / (NT / 8), chv = v % (NT / 8);
+                    const int pix = v / (NJ * 4), chv = v % (NJ * 4);
                     *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
                 }
             }
         } else {
             // generic path (folded up-conv with depth-to-space, odd channel counts, persistent variant)
+            static_assert(!SPL || SKIP, "the 2 x 2 wave grid exists for the fast-path stride-2 instances only");
 #pragma unroll
             for (int i = 0; i < RW; ++i) {
                 const int oy = cur.ty0 + wave * RW + i, ox = cur.tx0 + lr;
@@ -509,16 +514,16 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
-    constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = TH * 32 * (NT * 2 + 16);   // K-loop images | epilogue image
+    constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = 4 * (SPL ? TH / 2 : TH / 4) * 32 * ((SPL ? NT / 64 : NT / 32) * 64 + 16);   // K-loop images | epilogue image
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
     static bool attr = false;
     if (!attr) {
         if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>,
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
@@ -531,7 +536,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     static int resident = 0;
     if (!resident) {
         int per_cu = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>, 256, LDS);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>, 256, LDS);
         per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         hipDeviceProp_t prop;
         int dev = 0;
@@ -544,7 +549,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
     if (p.dry_run) return name;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -590,6 +595,8 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
         if (KS != 3 || S != 2 || p.pad != 0 || !p.skip_w || p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.up ||
             (p.Cout & 7) || p.no_tstore || p.Hc % 4 != 0)
             return nullptr;
+        static const bool spl = getenv("GLASS_S2_SPLIT") != nullptr;     // A/B knob: 2 x 2 wave grid
+        if (spl && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl>");
         if (p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip>");
         if (p.Neff % 64 == 0) return launch_inst<3, 2, 4, 64, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,64,skip>");
         return nullptr;

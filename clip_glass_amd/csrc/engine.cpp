@@ -167,6 +167,7 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     e->cur = e->stream;
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_noise, hipEventDisableTiming);
     if (err != hipSuccess) {
         delete e;
         glass_set_error(std::string("stream/event creation failed: ") + hipGetErrorString(err));
@@ -190,6 +191,7 @@ extern "C" void glass_engine_destroy(glass_engine* e) {
     for (auto ev : e->ev_d) hipEventDestroy(ev);
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
+    if (e->ev_noise) hipEventDestroy(e->ev_noise);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->stream_d) hipStreamDestroy(e->stream_d);
     delete e;
@@ -813,15 +815,19 @@ static void run_styles(glass_engine* e, int P) {
     const int L = c.latent_size;
     {
         Prof pr(e, "mapping", 2.0 * P * L * L * c.mapping_layers, 4.0 * L * L * c.mapping_layers);
-        launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->cur);
-        float *a = e->d_w0, *b = e->d_w1;
-        for (int i = 0; i < c.mapping_layers; ++i) {
-            if (L % 64 == 0 && L <= 768) launch_dense_splitk(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 1, e->cur);
-            else launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->cur);
-            std::swap(a, b);
+        static const bool no_fused = getenv("GLASS_NO_MAP_FUSE") != nullptr;   // A/B knob
+        if (no_fused || c.mapping_layers < 1 ||
+            !launch_mapping_fused(e->d_z, e->d_w0, P, L, 1e-8f, e->map_wt.data(), e->map_b.data(), c.mapping_layers, e->cur)) {
+            launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->cur);
+            float *a = e->d_w0, *b = e->d_w1;
+            for (int i = 0; i < c.mapping_layers; ++i) {
+                if (L % 64 == 0 && L <= 768) launch_dense_splitk(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 1, e->cur);
+                else launch_dense(a, L, P, L, e->map_wt[i], L, e->map_b[i], b, L, 0, 1, nullptr, 0, e->cur);
+                std::swap(a, b);
+            }
+            if (a != e->d_w0)  // result must end in d_w0
+                hipMemcpyAsync(e->d_w0, a, (size_t)P * L * sizeof(float), hipMemcpyDeviceToDevice, e->cur);
         }
-        if (a != e->d_w0)  // result must end in d_w0
-            hipMemcpyAsync(e->d_w0, a, (size_t)P * L * sizeof(float), hipMemcpyDeviceToDevice, e->cur);
     }
     {
         Prof pr(e, "styles", 2.0 * P * L * e->S_total, 4.0 * L * e->S_total);
@@ -1224,9 +1230,23 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
         if (e->profiling) collect_profile(e);
         return GLASS_OK;
     }
-    run_styles(e, P);
-    int rc = upload_noise(e, P, generation, first_mb, noise);
-    if (rc) return rc;
+    // device-generated noise planes depend on nothing but (seed, generation, minibatch, layer): their 17 short launches run on the
+    // second stream next to the mapping network / style / demodulation chain instead of ahead of it
+    const bool noise_ov = e->clip_overlap && c.noise_mode == 1 && !getenv("GLASS_NO_NOISE_OVERLAP");
+    int rc;
+    if (noise_ov) {
+        e->cur = e->stream_d;
+        rc = upload_noise(e, P, generation, first_mb, noise);
+        e->cur = e->stream;
+        if (rc) return rc;
+        GLASS_HIP(hipEventRecord(e->ev_noise, e->stream_d));
+        run_styles(e, P);
+        GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_noise, 0));
+    } else {
+        run_styles(e, P);
+        rc = upload_noise(e, P, generation, first_mb, noise);
+        if (rc) return rc;
+    }
     const bool want_d = out_F && c.use_discriminator && c.n_obj == 2;
     const int n = c.n_blocks;
     const int nlow = std::min(n, e->n_low);           // G blocks 0..nlow-1 run for the whole population

@@ -33,6 +33,9 @@ void launch_dense_splitk(const float* x, int ldx, int P, int K, const float* wt,
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
                   hipStream_t st);
+// pixel norm + every mapping layer in one launch (L = 256 / 512, <= 8 layers); false: not applicable, run the per-layer path
+bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, const float* const* wt, const float* const* b, int n_layers,
+                          hipStream_t st);
 struct DenseDesc {
     const float* x; int ldx; int K; const float* wt; int N; const float* bias; float* out; int ldo;
     const float* eps_row; int eps_stride;

@@ -147,6 +147,100 @@ void launch_dense_splitk(const float* x, int ldx, int P, int K, const float* wt,
     dim3 g((N + 63) / 64, (P + DENSE_PB - 1) / DENSE_PB);
     hipLaunchKernelGGL(dense_splitk_kernel, g, dim3(256), lds, st, x, ldx, P, K, wt, N, bias, out, ldo, mode);
 }
+// The whole mapping network (stylegan2/models.py:590-627: pixel norm + n_layers x [dense L -> L, bias, lrelu * sqrt2]) as ONE launch:
+// eight dependent 34-MFLOP launches cost 35 us each (launch gap + ramp + an L2-latency-bound K walk).  A workgroup owns four
+// candidates for all layers; its 16 waves each walk 1/16 of K for every output column (float4 columns per lane, 16 independent
+// 16-byte loads in flight per thread), partial sums meet in LDS in a fixed order — a candidate's result does not depend on P.
+struct MapDesc { const float* wt[8]; const float* b[8]; int n; };
+template <int NC>   // L = 256 * NC
+__global__ __launch_bounds__(1024) void mapping_fused_kernel(const float* z, float* out, int P, float eps, MapDesc d) {
+    constexpr int L = 256 * NC, KQ = L / 16;
+    extern __shared__ float msm[];
+    float* xs = msm;                          // [4][L]
+    float* red = msm + 4 * L;                 // [16][4][L]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int p0 = blockIdx.x * 4;
+    if (wave < 4) {
+        const int p = p0 + wave;
+        float s = 0.f;
+        for (int i = lane; i < L; i += 64) { const float v = p < P ? z[(long long)p * L + i] : 0.f; s += v * v; }
+        s = wave_sum(s);
+        const float k = rsqrtf(s / (float)L + eps);
+        for (int i = lane; i < L; i += 64) xs[wave * L + i] = p < P ? z[(long long)p * L + i] * k : 0.f;
+    }
+    __syncthreads();
+    const int kb = wave * KQ;
+    for (int layer = 0; layer < d.n; ++layer) {
+        const float* wt = d.wt[layer];
+        f4 acc[4][NC];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int kk = 0; kk < KQ; kk += 8) {
+            f4 w[8][NC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) w[u][c] = *(const f4*)(wt + (long long)(kb + kk + u) * L + (c * 64 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f4 xa = *(const f4*)(xs + r * L + kb + kk), xb = *(const f4*)(xs + r * L + kb + kk + 4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float xv = u < 4 ? xa[u & 3] : xb[u & 3];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) acc[r][c] += w[u][c] * xv;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) *(f4*)(red + (wave * 4 + r) * L + (c * 64 + lane) * 4) = acc[r][c];
+        __syncthreads();
+        float vout[(4 * L) / 1024];
+#pragma unroll
+        for (int j = 0; j < (4 * L) / 1024; ++j) {
+            const int e = t + 1024 * j, r = e / L, n = e - r * L;
+            float q[16];
+#pragma unroll
+            for (int w2 = 0; w2 < 16; ++w2) q[w2] = red[(w2 * 4 + r) * L + n];
+#pragma unroll
+            for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+                for (int w2 = 0; w2 < 16; w2 += 2 * st) q[w2] += q[w2 + st];          // fixed pairwise order
+            vout[j] = lrelu_sqrt2(q[0] + d.b[layer][n]);
+        }
+        __syncthreads();                       // every partial sum has been read
+#pragma unroll
+        for (int j = 0; j < (4 * L) / 1024; ++j) xs[t + 1024 * j] = vout[j];
+        __syncthreads();
+    }
+    for (int e = t; e < 4 * L; e += 1024) {
+        const int r = e / L, n = e - r * L;
+        if (p0 + r < P) out[(long long)(p0 + r) * L + n] = xs[e];
+    }
+}
+bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, const float* const* wt, const float* const* b, int n_layers,
+                          hipStream_t st) {
+    if ((L != 256 && L != 512) || n_layers < 1 || n_layers > 8) return false;
+    MapDesc d;
+    d.n = n_layers;
+    for (int i = 0; i < n_layers; ++i) { d.wt[i] = wt[i]; d.b[i] = b[i]; }
+    const size_t lds = (size_t)(4 + 64) * L * sizeof(float);
+    static bool attr[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && !attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 256 * sizeof(float)));
+        (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 512 * sizeof(float)));
+        attr[dev] = true;
+    }
+    if (L == 256) hipLaunchKernelGGL(mapping_fused_kernel<1>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
+    else hipLaunchKernelGGL(mapping_fused_kernel<2>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
+    return true;
+}
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
                   hipStream_t st) {
