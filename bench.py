@@ -30,32 +30,61 @@ HBM_PEAK_GBS = 8000.0       # HBM3E spec peak (6.3 TB/s measured achievable), MI
 POP, BATCH = 64, 4
 
 
-def cpu_baseline(sd, cfg, target):
-    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
-    sample of the same workload: one minibatch (P = 4) of StyleGAN2_ffhq_d."""
+def match_kernel(name, table):
+    """Row of a {kernel symbol: row} table (tools/traffic_table.py: rocprofv3 names without spaces / signature) for the engine's
+    kernel label: same base name, and the label's template arguments a prefix of the symbol's (defaults are printed by rocprofv3)."""
+    def split(n):
+        n = n.replace(" ", "")
+        base, _, args = n.partition("<")
+        return base, [x for x in args.rstrip(">").split(",") if x]
+    b0, a0 = split(name)
+    for sym, row in table.items():
+        b1, a1 = split(sym)
+        if b0 == b1 and a1[:len(a0)] == a0:
+            return row
+    return None
+
+
+def cpu_baseline(sd, cfg, target, pop=BATCH, budget_s=75.0):
+    """the oracle (CPU restatement of problem.py:14-29, kind 'port') on this box's host cores, same
+    synthetic weights / batch_size-4 grouping / fixed noise planes as the GPU run, fp32: wall per `_evaluate` as the MEDIAN of
+    >= 3 calls after one warm-up call, with the per-stage split (G / CLIP / D).  Bounded sample: `pop` candidates (default one
+    minibatch of 4; --cpu-baseline-pop 64 times the whole headline population, ~4 min); the timed calls stop early once
+    `budget_s` is spent (never fewer than 2)."""
     import torch
     from clip_glass_amd import synth
     from oracle import fitness_ref
     tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
-    x = synth.latents(123, BATCH, cfg["latent"])
+    x = synth.latents(123, pop, cfg["latent"])
     planes = synth.g_noise_planes(9, 0, 0, cfg["channels"])
-    best = None
-    for _ in range(2):
-        t = time.time()
-        fitness_ref.evaluate(tsd, x, target, BATCH, True, lambda i: planes, clip_size=cfg["clip"][4])
-        dt = time.time() - t
-        best = dt if best is None else min(best, dt)
-        if dt > 15:
-            break
+
+    def one_call():
+        with torch.no_grad():
+            t0 = time.time()
+            img = fitness_ref.generate(tsd, x, BATCH, lambda i: planes)
+            t1 = time.time()
+            fitness_ref.clip_similarity(tsd, img, target, cfg["clip"][4])
+            t2 = time.time()
+            fitness_ref.discriminate(tsd, img, BATCH)
+            t3 = time.time()
+        return t3 - t0, t1 - t0, t2 - t1, t3 - t2
+    one_call()                                            # warm-up (allocator, thread pool, oneDNN primitive caches)
+    calls, spent = [], 0.0
+    while len(calls) < 3 and (len(calls) < 2 or spent < budget_s):
+        calls.append(one_call())
+        spent += calls[-1][0]
+    med = [float(np.median([c[i] for c in calls])) for i in range(4)]
     try:
         import psutil
         phys = psutil.cpu_count(logical=False)
     except Exception:
         phys = None
-    return dict(value=BATCH / best, unit="candidates/s", cores=torch.get_num_threads(), physical_cores=phys,
-                logical_cpus=os.cpu_count(), kind="port",
-                sample="oracle/ (torch-CPU fp32 restatement) on P=4 (one minibatch = one G call + one D call, models.py:108-129) of "
-                       "the same workload, torch intra-op threads = cores, best of <=2 calls, %.2f s" % best)
+    return dict(value=pop / med[0], unit="candidates/s", cores=torch.get_num_threads(), physical_cores=phys,
+                logical_cpus=os.cpu_count(), kind="port", seconds_per_evaluate=med[0],
+                stage_seconds=dict(G=med[1], CLIP=med[2], D=med[3]), timed_calls=len(calls), warmup_calls=1,
+                sample="oracle/ (torch-CPU fp32 restatement) on P=%d of the same workload (%d minibatch(es) of 4: one G call + one D "
+                       "call each, models.py:108-129), torch intra-op threads = cores; median of %d calls after 1 warm-up call, "
+                       "%.2f s per _evaluate (G %.2f / CLIP %.2f / D %.2f)" % (pop, pop // BATCH, len(calls), med[0], med[1], med[2], med[3]))
 
 
 def bench_gpt2(args):
@@ -125,6 +154,7 @@ def main():
     ap.add_argument("--config", default="ffhq", help="model size key (tests/models.py naming); ffhq = the headline")
     ap.add_argument("--pop", type=int, default=POP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-pop", type=int, default=BATCH, help="candidates in the CPU baseline sample (multiple of 4; 64 = the whole headline population, ~4 min)")
     ap.add_argument("--chunk", type=int, default=0)
     args = ap.parse_args()
 
@@ -213,8 +243,10 @@ def main():
     eng.finalize()
     # synthetic target: a pass with a dummy target to get features, then sims in ~[0.5, 0.9]
     eng.set_target(np.ones(emb, np.float32))
-    eng.evaluate(population(999, BATCH))
-    target = synth.make_target(eng.details(BATCH)["features"])
+    # (GLASS_BENCH_UNIFORM_POP: the PMC passes want every launch of the run at the full population — tools/measure_traffic.sh)
+    P0 = P if os.environ.get("GLASS_BENCH_UNIFORM_POP") else BATCH
+    eng.evaluate(population(999, P0))
+    target = synth.make_target(eng.details(P0)["features"][:BATCH])
     eng.set_target(target)
 
     ev = ShardedEvaluator(eng, dist, rank, world, BATCH)
@@ -301,18 +333,24 @@ def main():
         # the roof that binds = the one the kernel sits closer to (the same kernel runs
         # MFMA-bound mid-resolution layers and HBM-bound 512^2/1024^2 layers)
         frac_mfma, frac_hbm = tf / MFMA_PEAK_TFLOPS, gbs / HBM_PEAK_GBS
-        traffic = None
+        # `traffic`: NOT measured in this run — the counters need their own rocprofv3 --pmc passes (tools/measure_traffic.sh: one
+        # FETCH_SIZE and one WRITE_SIZE pass of this same command, every launch at the full population); the stored table is
+        # profiles/traffic_latest.json and the line says so
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):   # PMC FETCH_SIZE/WRITE_SIZE passes (tools/measure_traffic.sh), bytes per launch
-            for kname, row in json.load(open(tpath)).items():
-                if kern.split("<")[0] in kname:
-                    traffic = row["bytes_per_launch"]
-                    break
+        if os.path.exists(tpath):
+            row = match_kernel(kern, json.load(open(tpath)).get("per_kernel", {}))
+            if row:
+                traffic = row["bytes_per_launch"]
+                traffic_src = ("stored rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/measure_traffic.sh -> profiles/traffic_latest.json), "
+                               "average over this kernel's %d launches at P = %d; not collected by this run" % (row["launches"], P))
         if frac_hbm > frac_mfma:
             roofline = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=frac_hbm)
         else:
             roofline = dict(bound="mfma", achieved=tf, peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=frac_mfma)
+        alg_bpl = a["bytes"] / max(a["launches"], 1)
         roofline.update(kernel=kern, launches=a["launches"], avg_ms=a["total_ms"] / max(a["launches"], 1), traffic=traffic,
+                        traffic_source=traffic_src, traffic_ratio=(traffic / alg_bpl if traffic and alg_bpl else None),
                         algorithmic_tflops=tf, algorithmic_gbs=gbs, frac_of_mfma_peak=frac_mfma, frac_of_hbm_peak=frac_hbm,
                         algorithmic_bytes_per_launch=a["bytes"] / max(a["launches"], 1),
                         algorithmic_flop_per_launch=a["flops"] / max(a["launches"], 1),
@@ -326,8 +364,13 @@ def main():
                                      1: "two HIP streams (GLASS_OVERLAP=1): durations include co-running kernels",
                                      2: "G and D on one stream; CLIP's image tower on a second stream next to D (G launches never "
                                         "have a co-runner, D launches may; `isolated` = one-stream pass)"}[mode],
-                        whole_pass_tflops=total_flops / (total_ms * 1e-3) / 1e12 if total_ms else None,
-                        whole_pass_frac_of_mfma_peak=(total_flops / (total_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if total_ms else None)
+                        # whole pass: algorithmic FLOP of one population (the reference's op count: every launch's tag) over the
+                        # TIMED region's ms_per_step (driver-comparable) — and over the instrumented one-stream pass for reference
+                        whole_pass_tflops=total_flops / (dt / args.steps) / 1e12,
+                        whole_pass_frac_of_mfma_peak=total_flops / (dt / args.steps) / 1e12 / MFMA_PEAK_TFLOPS,
+                        whole_pass_algorithmic_gflop_per_candidate=total_flops / P / 1e9,
+                        instrumented_pass_ms=total_ms,
+                        instrumented_pass_frac_of_mfma_peak=(total_flops / (total_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS) if total_ms else None)
         if biggan:
             metric = "candidate latents scored/sec (GAN→CLIP fitness), DeepMindBigGAN512 pop=%d" % P
             workload = ("DeepMindBigGAN512: BigGAN-deep 512px G + CLIP ViT-B/32, pop=%d per GPU, batch_size=%d, n_obj=1" % (P, BATCH))
@@ -339,10 +382,10 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
                    config=dict(workload=workload, pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,
-                               device=device_info(local_rank)["name"]),
+                               device="%(name)s, %(cus)d CUs" % device_info(local_rank), hbm_gib=round(device_info(local_rank)["hbm_bytes"] / 2 ** 30)),
                    roofline=roofline)
         if world == 1 and not args.no_cpu_baseline and not biggan:
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, target)
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH))
         if os.environ.get("GLASS_BENCH_DETAIL"):
             with open(os.environ["GLASS_BENCH_DETAIL"], "w") as f:
                 wk = {}

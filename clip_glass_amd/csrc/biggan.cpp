@@ -372,6 +372,7 @@ static int bg_take_tap(glass_engine* e, const half_t* x, int B, int res, int C) 
     e->bg_tap_data.resize(h.size());
     for (size_t i = 0; i < h.size(); ++i) e->bg_tap_data[i] = (float)h[i];
     e->bg_tap_dims[0] = B; e->bg_tap_dims[1] = res; e->bg_tap_dims[2] = res; e->bg_tap_dims[3] = C;
+    e->bg_tap = -2;   // one-shot, as include/glass.h documents ("the next pass"): later passes run without the sync + copy
     return GLASS_OK;
 }
 

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 }
 
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
-    if (p.w_bstride != 0) abort();  // per-sample weights are a tiled/upfir-only path (engine guarantees it)
+    if (p.w_bstride != 0) return nullptr;  // per-sample weights are a tiled / up-conv-only path: refuse, the caller reports it
     const long long M = (long long)p.B * p.Hc * p.Wc;
     if (p.Neff > 64 && ((M + 127) / 128) * ((p.Neff + 127) / 128) >= 256) {   // enough 128 x 128 blocks to fill the chip: row-parallel
         hipLaunchKernelGGL((conv_direct_kernel<4, false>), dim3((unsigned)((M + 127) / 128), (p.Neff + 127) / 128), dim3(256), 0,

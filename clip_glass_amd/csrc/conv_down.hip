@@ -332,16 +332,12 @@ const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1
     const int Ro = R / 2, tiles_x = Ro / 32, tiles_y = Ro / TH;
     const long long tiles = (long long)B * tiles_x * tiles_y;
     if (tiles >= (1LL << 30)) return nullptr;
-    static int slots = 0;
-    if (!slots) {
+    static DevOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)conv_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipGetDeviceProperties(&prop, dev);
-        slots = prop.multiProcessorCount * 2;
     }
+    const int slots = glass_cu_count() * 2;
     const int per_block = (int)((tiles + slots - 1) / slots);
     const int grid = (int)((tiles + per_block - 1) / per_block);
     if (p.trace) hipLaunchKernelGGL(conv_down_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, (int)tiles, per_block);

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
     static const bool off = getenv("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
     if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.pre_shift || p.in_up || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
+    if (p.xs_out || p.post_scale16) return nullptr;   // by-products / output transforms this path does not implement: refuse, never ignore
     if ((p.KS != 1 && p.KS != 3) || p.Cin % 64 != 0 || p.Neff % 64 != 0 || (p.Cout & 3) || (p.res_cs & 3)) return nullptr;
     const long long M = (long long)p.B * p.Hc * p.Wc, K = (long long)p.KS * p.KS * p.Cin;
     if ((long long)p.Hc * p.Wc * K > cap_a || (long long)p.Hc * p.Wc * p.Neff > cap_c || M * K >= (1LL << 31)) return nullptr;

@@ -441,18 +441,13 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
 }
 
 static int stream_slots() {
-    static int slots = 0;
-    if (!slots) {
+    static DevOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipGetDeviceProperties(&prop, dev);
-        slots = prop.multiProcessorCount * 3;      // 168 VGPRs, 51.5 KB of LDS: three workgroups per CU
     }
-    return slots;
+    return glass_cu_count() * 3;      // 168 VGPRs, 51.5 KB of LDS: three workgroups per CU
 }
 
 bool conv_stream_applies(const ConvParams& p) {

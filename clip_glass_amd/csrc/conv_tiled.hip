@@ -520,31 +520,26 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
     constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = 4 * (SPL ? TH / 2 : TH / 4) * 32 * ((SPL ? NT / 64 : NT / 32) * 64 + 16);   // K-loop images | epilogue image
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
-    static bool attr = false;
-    if (!attr) {
-        if (LDS > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
+    static DevOnce once;                       // (one per template instance)
+    if (once.first() && LDS > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
     // persistent grid: as many workgroups as are resident at once (256 CUs x blocks/CU), a multiple of 8
     // so a block keeps its XCD; each block walks its work items with cross-tile prefetch
-    static int resident = 0;
-    if (!resident) {
-        int per_cu = 1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>, 256, LDS);
-        per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
-        hipDeviceProp_t prop;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipGetDeviceProperties(&prop, dev);
-        resident = prop.multiProcessorCount * per_cu;
+    int resident = 1 << 30;
+    if (PERSIST) {
+        static int per_cu_cache = 0;           // occupancy is a property of the kernel + architecture; the CU count is per device
+        if (!per_cu_cache) {
+            int per_cu = 1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>, 256, LDS);
+            per_cu_cache = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+        }
+        resident = glass_cu_count() * per_cu_cache;
         resident -= resident % 8;
-        if (!PERSIST) resident = 1 << 30;
     }
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;

@@ -546,13 +546,19 @@ static int alloc_buffers(glass_engine* e) {
     if (e->cfg.generator != GLASS_GEN_BIGGAN_DEEP && e->cfg.n_blocks > 0) {
         // StyleGAN2's low-resolution layers as im2col + GEMM (conv_gemm.hip): conv grids up to 16 x 16 per candidate, widest
         // channel count (151 + 134 MB at P = 64).  The capacities are per candidate: whether a layer takes this path must not
-        // depend on how many candidates a launch carries (results are chunking- and sharding-invariant to the bit).
+        // depend on how many candidates a launch carries.  (A few OTHER dispatchers do look at the launch size — conv_stream wants
+    // enough tiles per workgroup, gemm_tiled picks its tile by M, gpt2's split-K depth follows M — so chunking / sharding
+    // invariance holds to fp16 rounding, not to the bit: tests/test_gpu_engine.py::test_pop512_as_eight_shards_of_64.)
         int cmax = 16;
         for (int i = 0; i < e->cfg.n_blocks; ++i) cmax = std::max(cmax, (int)e->cfg.channels[i]);
         e->cap_a = 256LL * 9 * cmax;
         e->cap_c = 256LL * 4 * cmax;
         if ((rc = dev_alloc(e, &e->ws_a, (size_t)(e->cap_a * P)))) return rc;
         if ((rc = dev_alloc(e, &e->ws_c, (size_t)(e->cap_c * P)))) return rc;
+        if (e->cfg.use_discriminator) {   // stream mode 1 runs D on the second stream next to G: its own scratch
+            if ((rc = dev_alloc(e, &e->ws_a2, (size_t)(e->cap_a * P)))) return rc;
+            if ((rc = dev_alloc(e, &e->ws_c2, (size_t)(e->cap_c * P)))) return rc;
+        }
     }
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;
@@ -758,8 +764,15 @@ void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flop
     if (!k) k = launch_conv_stream(p, e->cur);
     if (!k) k = launch_conv_glds(p, e->cur);
     if (!k) k = launch_conv_tiled(p, e->cur);
-    if (!k) k = launch_conv_gemm(p, e->ws_a, e->cap_a, e->ws_c, e->cap_c, e->cur);
+    if (!k) {
+        const bool second = e->cur == e->stream_d && e->ws_a2;
+        k = launch_conv_gemm(p, second ? e->ws_a2 : e->ws_a, e->cap_a, second ? e->ws_c2 : e->ws_c, e->cap_c, e->cur);
+    }
     if (!k) k = launch_conv_direct(p, e->cur);
+    if (!k) {   // no kernel family accepts this layer: remember it, the pass returns an error instead of a wrong result
+        if (e->launch_error.empty()) e->launch_error = std::string("no kernel accepts layer ") + tag;
+        k = "(refused)";
+    }
     if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
     if (e->profiling) e->tag_kernel[tag] = k;
 }
@@ -982,9 +995,10 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             snprintf(tag, sizeof tag, "G.torgb.r%d", r.res);
             Prof pr(e, tag, 2.0 * B * (double)r.res * r.res * 3 * r.cin,
                     B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));
-            launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
-                         e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style, yprev, yb[yi],
-                         e->cur);
+            if (!launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
+                              e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style, yprev, yb[yi], e->cur) &&
+                e->launch_error.empty())
+                e->launch_error = std::string("toRGB width not instantiated: ") + tag;
         }
         yprev = yb[yi];
         yi ^= 1;
@@ -1356,6 +1370,13 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     GLASS_HIP(hipStreamSynchronize(e->cur));
     GLASS_HIP(hipGetLastError());
     GLASS_HIP(hipEventElapsedTime(&e->last_ms, e->ev0, e->ev1));
+    if (!e->launch_error.empty()) {
+        const std::string msg = e->launch_error;
+        e->launch_error.clear();
+        if (e->profiling) collect_profile(e);
+        glass_set_error(msg);
+        return GLASS_ERR_STATE;
+    }
     if (out_F) memcpy(out_F, e->h_pinned, (size_t)P * c.n_obj * sizeof(float));
     e->last_P = P;
     if (e->profiling) collect_profile(e);
@@ -1663,10 +1684,8 @@ extern "C" int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, i
 extern "C" int glass_device_info(int32_t device, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes) {
     hipDeviceProp_t prop;
     GLASS_HIP(hipGetDeviceProperties(&prop, device));
-    if (name && name_len > 0) {
-        strncpy(name, prop.name, name_len - 1);
-        name[name_len - 1] = 0;
-    }
+    if (name && name_len > 0)   // the marketing name the driver reports can be generic ("AMD Radeon Graphics"): the ISA name says what it is
+        snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
     if (cus) *cus = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
     return GLASS_OK;

@@ -101,6 +101,7 @@ struct glass_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_noise = nullptr;
     float last_ms = 0.f;
     int last_P = 0;
+    std::string launch_error;   // a launcher refused a layer during the pass (reported by run_pass; nothing aborts)
 
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
@@ -155,6 +156,8 @@ struct glass_engine {
     half_t* d_s16 = nullptr;   // fp16 copy of d_s (normalised styles)
     half_t* ws_a = nullptr;   // conv_gemm.hip scratch: patch matrix of a low-resolution layer (cap_a halfs) and its fp32 product (cap_c)
     float* ws_c = nullptr;
+    half_t* ws_a2 = nullptr;  // second scratch set: launches on the second stream never share a buffer with the main stream's
+    float* ws_c2 = nullptr;
     long long cap_a = 0, cap_c = 0;
     half_t* d_trgb_tab = nullptr;   // [P][2][16][128] fp16: toRGB weight tables of the fused conv epilogues
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,

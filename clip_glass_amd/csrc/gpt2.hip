@@ -233,11 +233,8 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
                            float* out, hipStream_t st, const int* past_dev) {
     const int ns = past_dev ? Tmax : past + nd;      // graph replay: LDS sized for the longest history
     const size_t lds = (size_t)(nd * 65 + 2 * ns * 65 + nd * (ns + 1)) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gpt2_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static DevOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)gpt2_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(gpt2_attention_kernel, dim3(P * heads), dim3(256), lds, st, qkv, kc, vc, nd, past, Tmax, heads, out, past_dev);
 }
 

@@ -290,11 +290,9 @@ void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, in
         return;
     }
     const size_t lds = (size_t)(3 * L * 65 + L * (L + 1)) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {  // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS
+    static DevOnce once;
+    if (once.first())   // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS
         (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL(attention_kernel, dim3(n_img * heads), dim3(256), lds, st, qkv, L, heads, causal, out);
 }
 

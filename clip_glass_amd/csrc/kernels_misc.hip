@@ -229,13 +229,10 @@ bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, c
     d.n = n_layers;
     for (int i = 0; i < n_layers; ++i) { d.wt[i] = wt[i]; d.b[i] = b[i]; }
     const size_t lds = (size_t)(4 + 64) * L * sizeof(float);
-    static bool attr[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && !attr[dev]) {
+    static DevOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 256 * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 512 * sizeof(float)));
-        attr[dev] = true;
     }
     if (L == 256) hipLaunchKernelGGL(mapping_fused_kernel<1>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
     else hipLaunchKernelGGL(mapping_fused_kernel<2>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
@@ -483,19 +480,20 @@ static void launch_torgb_t(const half_t* x, int B, int H, int W, int C, const fl
     hipLaunchKernelGGL(torgb_kernel<LPP>, dim3(gx, B), dim3(256), 0, st, x, H, W, C, wrgb, bias, sn, sn_stride, smax,
                        smax_stride, yprev, yout);
 }
-void launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
+bool launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                   const float* sn, int sn_stride, const float* smax, int smax_stride, const float* yprev,
                   float* yout, hipStream_t st) {
 #define TORGB_PIX(CC) if (C == CC) { hipLaunchKernelGGL(torgb_pix_kernel<CC>, dim3((H * W + 255) / 256, B), dim3(256), 0, st, x, H, W, \
-                                                       wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout); return; }
+                                                       wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout); return true; }
     TORGB_PIX(16) TORGB_PIX(32) TORGB_PIX(64)
 #undef TORGB_PIX
 #define TORGB_CASE(L) case L: launch_torgb_t<L>(x, B, H, W, C, wrgb, bias, sn, sn_stride, smax, smax_stride, yprev, yout, st); break;
     switch (C / 8) {
         TORGB_CASE(2) TORGB_CASE(4) TORGB_CASE(8) TORGB_CASE(16) TORGB_CASE(32) TORGB_CASE(64)
-        default: abort();  // channels are powers of two >= 16 (checked at engine creation for C % 16)
+        default: return false;  // not instantiated (the engine checks its channel widths at creation; the diagnostic ABI reports it)
     }
 #undef TORGB_CASE
+    return true;
 }
 
 // toRGB weight tables for the fused conv epilogues (common.h: trgb_channel / trgb_table_value): [B][2][16][NT] fp16

@@ -137,7 +137,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
             p.trgb_tab = tab;
         }
     }
-    if (d->impl == 1) launch_conv_direct(p, 0);
+    if (d->impl == 1) { if (!launch_conv_direct(p, 0)) { glass_set_error("direct conv: unsupported launch"); return GLASS_ERR_ARG; } }
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 2) {
@@ -151,7 +151,10 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         if (!launch_conv_gemm(p, wa, cap_a, wc, cap_c, 0)) { glass_set_error("im2col + GEMM conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 5) {
         if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }
-    } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0)) launch_conv_direct(p, 0);
+    } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0) && !launch_conv_direct(p, 0)) {
+        glass_set_error("no kernel accepts this convolution");
+        return GLASS_ERR_ARG;
+    }
     int rc = finish();
     if (rc) return rc;
     if (yrgb) {
@@ -209,7 +212,7 @@ extern "C" int glass_op_torgb(int32_t device, int32_t B, int32_t H, int32_t C, c
     float* dw = dv.up32(wrgb, 3 * C); float* db = dv.up32(bias, 3); float* ds = dv.up32(sn, (size_t)B * C);
     float* dm = dv.up32(smax, B); float* dp = dv.up32(yprev, (size_t)B * 3 * (H / 2) * (H / 2));
     float* dy = dv.alloc<float>((size_t)B * 3 * H * H);
-    launch_torgb(dx, B, H, H, C, dw, db, ds, C, dm, 1, dp, dy, 0);
+    OPREQ(launch_torgb(dx, B, H, H, C, dw, db, ds, C, dm, 1, dp, dy, 0), "toRGB: channel width not instantiated");
     int rc = finish();
     if (rc) return rc;
     GLASS_HIP(hipMemcpy(yout, dy, (size_t)B * 3 * H * H * sizeof(float), hipMemcpyDeviceToHost));

@@ -694,13 +694,10 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
     if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
     constexpr int LDS = 64 * 1024;
-    static bool attr[16] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 16 && !attr[dev]) {
+    static DevOnce once;
+    if (once.first()) {
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr[dev] = true;
     }
     static const int env_ng = getenv("GLASS_UPFIR_NG") ? atoi(getenv("GLASS_UPFIR_NG")) : 0;      // A/B knobs
     static const int env_s = getenv("GLASS_UPFIR_S") ? atoi(getenv("GLASS_UPFIR_S")) : 0;
@@ -765,11 +762,8 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
 
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     constexpr int LDS = 64 * 1024;  // T tile (16*64*32*2 B); staging (31.5 KB) lives inside it
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)upfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
+    static DevOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)upfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int tiles_y = (p.Ho + 11) / 12, tiles_x = (p.Wo + 59) / 60;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Cout / 32;

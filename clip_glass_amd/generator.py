@@ -89,11 +89,27 @@ class Generator:
         self.config = config
         self.augmentation = None
         self.model = config.model(config)                                   # generator.py:19
+        # dist = None: pick up the process group when one is initialised (a `torchrun` launch: one process per GPU, backend
+        # "nccl" = RCCL); every rank then scores its contiguous shard of the SAME population and one all-gather returns all rows
+        if dist is None:
+            try:
+                import torch.distributed as td
+                if td.is_available() and td.is_initialized() and td.get_world_size() > 1:
+                    dist = td
+            except ImportError:
+                pass
+        sharded = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
         device = getattr(config, "device", 0)
-        if ":" in str(device):
+        if sharded and getattr(config, "device_per_rank", None) is None:
+            # one process per GPU: every rank sees the same command line ("cuda", "cuda:0", 0 ...), so the device is this rank's
+            # LOCAL_RANK unless the caller names a device per rank explicitly (config.device_per_rank = [ids], indexed by rank)
+            device = int(os.environ.get("LOCAL_RANK", dist.get_rank()))
+        elif sharded:
+            device = int(config.device_per_rank[dist.get_rank()])
+        elif ":" in str(device):
             device = int(str(device).split(":")[1])
-        elif not isinstance(device, int):       # bare "cuda": under a one-process-per-GPU launch this rank's GPU
-            device = int(os.environ.get("LOCAL_RANK", "0")) if dist is not None else 0
+        elif not isinstance(device, int):       # bare "cuda"
+            device = 0
         pop = int(getattr(config, "max_pop", max(config.pop_size, config.batch_size)))
         self.generation = 0
         self.sharder = None
@@ -136,7 +152,7 @@ class Generator:
             self.tokens = tok.tokenize([self.config.target])
             self.text_features = self.engine.encode_text(self.tokens)
         self.engine.set_target(self.text_features[0])
-        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if sharded:
             from .parallel import ShardedEvaluator
             self.sharder = ShardedEvaluator(self.engine, dist, dist.get_rank(), dist.get_world_size(), config.batch_size)
 
@@ -160,6 +176,10 @@ class Generator:
             return -self.clip_similarity_texts(texts)[:, None]
         z = ls.population()
         if self.sharder is not None:        # one process per GPU: this rank scores its shard, ONE all-gather of the rows
+            if noise is not None or first_minibatch:
+                # caller-provided planes / offsets address ONE engine's minibatches; the sharded path derives both from the
+                # global minibatch index (device noise), so accepting them here would silently ignore them
+                raise ValueError("noise / first_minibatch cannot be combined with a sharded (multi-GPU) Generator")
             F = self.sharder.evaluate_global(z, generation=self.generation)
         else:
             F = self.engine.evaluate(z, generation=self.generation, first_minibatch=first_minibatch, noise=noise)

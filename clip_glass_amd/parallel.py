@@ -6,7 +6,9 @@ population is cut into contiguous blocks that are multiples of batch_size; weigh
 the target feature are replicated; the only collective on the data path is ONE
 all-gather of the [P_local, n_obj] float32 fitness rows per generation (512 B per rank
 at 64 x 2 — latency-bound on xGMI).  Noise is a pure function of (seed, generation,
-GLOBAL minibatch index, layer), so results do not depend on the sharding.
+GLOBAL minibatch index, layer), so the OPERANDS of every candidate do not depend on the sharding; a few kernel dispatchers
+look at the launch size (conv_stream's tile count, gemm_tiled's tile choice), so a sharded run reproduces the single-GPU
+result to fp16 rounding (-sim within 1e-3 relative, the north-star bar), and the same shard call twice bit for bit.
 """
 import numpy as np
 

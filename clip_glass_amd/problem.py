@@ -29,8 +29,9 @@ from .generator import Generator
 
 class GenerationProblem(Problem):
     def __init__(self, config, dist=None):
-        """dist: an initialised torch.distributed module (one process per GPU; backend "nccl" = RCCL).  Every rank calls
-        _evaluate with the SAME x; each scores its contiguous shard and one all-gather returns all rows (parallel.py)."""
+        """dist: an initialised torch.distributed module (one process per GPU; backend "nccl" = RCCL), or None = use the default
+        process group if one is initialised with more than one rank (generator.py).  Every rank calls _evaluate with the SAME x;
+        each scores its contiguous shard and one all-gather returns all rows (parallel.py)."""
         self.generator = Generator(config, dist=dist)
         self.config = config
         super().__init__(**self.config.problem_args)

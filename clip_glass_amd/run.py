@@ -33,6 +33,10 @@ def build_parser():
     p.add_argument("--bpe-path", type=str, default=None)
     p.add_argument("--pop-size", type=int, default=None)
     p.add_argument("--seed", type=int, default=1)
+    p.add_argument("--dist", action="store_true",
+                   help="multi-GPU: run under `torchrun --nproc-per-node N -m clip_glass_amd.run --dist ...` (one process per GPU, "
+                        "RCCL); every rank runs the same seeded search, scores its shard of each population, and one all-gather "
+                        "returns all fitness rows; rank 0 writes the outputs")
     return p
 
 
@@ -46,11 +50,22 @@ def main(argv=None, extra_config=None):
     if extra_config:
         vars(config).update(extra_config)
     state = dict(iteration=0)
+    dist, rank0 = None, True
+    if getattr(config, "dist", False):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            backend = os.environ.get("GLASS_DIST_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm (gloo: CPU tests)
+            if backend == "nccl":
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(backend)
+        rank0 = dist.get_rank() == 0
 
     def save_callback(algorithm):                                              # run.py:29-51
         state["iteration"] += 1
         it = state["iteration"]
-        if it % config.save_each == 0 or it == config.generations:
+        if rank0 and (it % config.save_each == 0 or it == config.generations):
             if config.problem_args["n_obj"] == 1:
                 X = np.stack([p.X for p in sorted(algorithm.pop, key=lambda p: p.F)])
             else:
@@ -62,11 +77,14 @@ def main(argv=None, extra_config=None):
             name = "genetic-it-%d.%s" % (it, ext) if it < config.generations else "genetic-it-final.%s" % ext
             algorithm.problem.generator.save(generated, os.path.join(config.tmp_folder, name))
 
-    problem = GenerationProblem(config)
+    problem = GenerationProblem(config, dist=dist)
     operators = get_operators(config)
     os.makedirs(config.tmp_folder, exist_ok=True)
+    # (same seed on every rank => identical GA state everywhere: no broadcast of the population is needed)
     res = search.minimize(problem, config.algorithm, config.pop_size, config.generations, operators["sampling"],
-                          seed=config.seed, callback=save_callback, verbose=True, mask=operators.get("mask"))
+                          seed=config.seed, callback=save_callback, verbose=rank0, mask=operators.get("mask"))
+    if not rank0:
+        return res
     with open(os.path.join(config.tmp_folder, "genetic_result"), "wb") as f:   # run.py:79-84
         pickle.dump(dict(X=res.X, F=res.F, G=res.G, CV=res.CV), f)
     if config.problem_args["n_obj"] == 2:

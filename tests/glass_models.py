@@ -13,6 +13,10 @@ CONFIGS = {
     "mid": dict(channels=[32, 64, 64, 64, 64], latent=64, mapping=3, clip=(128, 2, 2, 8, 32, 64)),
     # the real thing: StyleGAN2 ffhq config-f 1024 px + CLIP ViT-B/32
     "ffhq": dict(channels=synth.FFHQ_CHANNELS, latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
+    # config.py:96-135 (StyleGAN2_church_* 256 px, StyleGAN2_car_* 512 px): config-f channel tables of the smaller networks
+    # (convert_from_tf.py:154-175 builds square networks; the car images are letter-boxed 512 x 384 content)
+    "church": dict(channels=synth.FFHQ_CHANNELS[2:], latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
+    "car": dict(channels=synth.FFHQ_CHANNELS[1:], latent=512, mapping=8, clip=(768, 12, 12, 32, 224, 512)),
 }
 
 

@@ -37,8 +37,9 @@ def modules_case(name, P, bs, seed, noise_seed, generation):
     """Reference G/D/CLIP nn.Modules driven like models.py:108-129 + generator.py:29-60."""
     c = M.CONFIGS[name]
     sd = M.make_state(name, seed)
-    sd.update(synth.make_state(synth.clip_text_spec(width=c["clip"][0] if name != "ffhq" else 512,
-                                                    layers=2 if name != "ffhq" else 12, out_dim=c["clip"][5]), seed))
+    full = name not in ("mini", "mid")
+    sd.update(synth.make_state(synth.clip_text_spec(width=c["clip"][0] if not full else 512,
+                                                    layers=2 if not full else 12, out_dim=c["clip"][5]), seed))
     G = rh.build_ref_G(sd, c["channels"], c["latent"], c["mapping"])
     D = rh.build_ref_D(sd, c["channels"])
     clip_model = rh.build_ref_clip(sd)
@@ -67,12 +68,16 @@ def modules_case(name, P, bs, seed, noise_seed, generation):
                 image_small=small[:2].numpy().astype(np.float16))
 
 
-def problem_case(seed=0, noise_seed=5):
-    """The reference's own problem.py / generator.py / models.py / latent.py driven end to end."""
-    name, P, bs = "mini", 8, 4
+def problem_case(seed=0, noise_seed=5, name="mini", config_name="StyleGAN2_ffhq_d", P=8, crafted_target=False):
+    """The reference's own problem.py / generator.py / models.py / latent.py driven end to end.
+    crafted_target: after construction the text feature is replaced (attribute assignment on the reference's Generator object,
+    generator.py:23-24) by a synthetic target built from the population's own image features, so that the similarities sit in
+    ~[0.5, 0.9] where the 1e-3 RELATIVE bar is meaningful; the fixture then holds both F's."""
+    bs = 4
     c = M.CONFIGS[name]
+    full = name not in ("mini", "mid")
     sd = M.make_state(name, seed)
-    sd.update(synth.make_state(synth.clip_text_spec(width=64, layers=2, out_dim=c["clip"][5]), seed))
+    sd.update(synth.make_state(synth.clip_text_spec(width=512 if full else 64, layers=12 if full else 2, out_dim=c["clip"][5]), seed))
     R = rh.load_reference()
     A = rh.load_author_modules()
     tmp = tempfile.mkdtemp(prefix="glass_golden_")
@@ -80,8 +85,8 @@ def problem_case(seed=0, noise_seed=5):
     rh.build_ref_D(sd, c["channels"]).save(os.path.join(tmp, "D.pth"))
     clip_model = rh.build_ref_clip(sd)
     R["clip_clip"].load = lambda *a, **k: (clip_model, None)                 # no download (clip.py:24-78)
-    cfg = types.SimpleNamespace(device="cpu", config="StyleGAN2_ffhq_d", target="a wolf at night with the moon in the background")
-    vars(cfg).update(A["config"].get_config("StyleGAN2_ffhq_d"))
+    cfg = types.SimpleNamespace(device="cpu", config=config_name, target="a wolf at night with the moon in the background")
+    vars(cfg).update(A["config"].get_config(config_name))
     cfg.weights = tmp
     cfg.dim_z = c["latent"]
     cfg.batch_size = bs
@@ -99,9 +104,21 @@ def problem_case(seed=0, noise_seed=5):
     x = synth.latents(seed + 1, P, c["latent"])
     out = {}
     prob._evaluate(x, out)
-    return dict(config=name, P=P, batch_size=bs, seed=seed, noise_seed=noise_seed, text_features=text_features,
-                F=np.asarray(out["F"], dtype=np.float32), G=np.asarray(out["G"]),
-                tokens=R["clip_clip"].tokenize([cfg.target]).numpy()[0])
+    res = dict(config=name, reference_config=config_name, P=P, batch_size=bs, seed=seed, noise_seed=noise_seed, text_features=text_features,
+               F=np.asarray(out["F"], dtype=np.float32), G=np.asarray(out["G"]),
+               tokens=R["clip_clip"].tokenize([cfg.target]).numpy()[0])
+    if crafted_target:
+        with torch.no_grad():
+            ls = cfg.latent(cfg)
+            ls.set_from_population(x)
+            img = prob.generator.generate(ls, minibatch=bs)                     # generator.py:29-34
+            feats = prob.generator.CLIP.encode_image(kornia.resize(img, (224, 224)))   # generator.py:45-49
+        target = synth.make_target(feats.numpy())
+        prob.generator.text_features = torch.tensor(target)[None]
+        out2 = {}
+        prob._evaluate(x, out2)
+        res.update(target=target, F_target=np.asarray(out2["F"], dtype=np.float32), features=feats.numpy())
+    return res
 
 
 def gpt2_case(seed=2, P=8):
@@ -118,12 +135,28 @@ def gpt2_case(seed=2, P=8):
                 tokens=np.asarray(out, dtype=np.int64), last_logits=logits[:, -1, :64].numpy())
 
 
+def r3_cases():
+    # BASELINE.json configs[0]: StyleGAN2_ffhq_nod, pop = 8, through the reference's own problem.py at the true 1024 px size
+    np.savez_compressed(os.path.join(HERE, "ffhq_nod_problem.npz"),
+                        **problem_case(seed=0, noise_seed=5, name="ffhq", config_name="StyleGAN2_ffhq_nod", P=8, crafted_target=True))
+    print("ffhq_nod_problem.npz")
+    # config.py:96-135: the church (256 px) and car (512 px) config-f channel tables, P = 4 (one minibatch)
+    np.savez_compressed(os.path.join(HERE, "church_modules.npz"), **modules_case("church", 4, 4, 0, 11, 2))
+    print("church_modules.npz")
+    np.savez_compressed(os.path.join(HERE, "car_modules.npz"), **modules_case("car", 4, 4, 0, 11, 2))
+    print("car_modules.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ffhq", action="store_true")
     ap.add_argument("--only-ffhq", action="store_true")
+    ap.add_argument("--only-r3", action="store_true", help="round-3 additions only: full-size C1 problem case, church / car geometry")
     args = ap.parse_args()
     assert rh.available(), "needs /root/reference"
+    if args.only_r3:
+        r3_cases()
+        return
     if args.only_ffhq:
         np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 8, 4, 0, 11, 2))
         print("ffhq_modules.npz")
@@ -137,6 +170,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "mini_modules.npz"), **modules_case("mini", 8, 4, 0, 11, 2))
     print("mini_modules.npz")
     if not args.skip_ffhq:
+        r3_cases()
         # P = 8: two minibatches = two shared noise planes per layer and two mbstd groups (SURVEY 8a notes 4-5)
         np.savez_compressed(os.path.join(HERE, "ffhq_modules.npz"), **modules_case("ffhq", 8, 4, 0, 11, 2))
         print("ffhq_modules.npz")

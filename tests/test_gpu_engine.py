@@ -8,7 +8,7 @@ import torch
 from clip_glass_amd import synth
 from oracle import fitness_ref
 import glass_models as M
-from util import check, diag
+from util import check, check_logits, diag
 
 pytestmark = pytest.mark.gpu
 
@@ -52,8 +52,8 @@ def _run_case(name, P, batch_size, use_d, noise_mode, chunk=0, seed=0):
     np.testing.assert_allclose(Fe[:, 0], -det["sim"], rtol=0, atol=1e-7)
     if use_d:
         dis_o = detail["dis"].numpy()[:, 0]
-        check(tag + " D logits", det["dis"], dis_o, 5e-3, atol=2e-3)
-        check(tag + " hinge", Fe[:, 1], np.maximum(1 - dis_o, 0), 5e-3, atol=2e-3)
+        check_logits(tag + " D logits", det["dis"], dis_o)
+        check_logits(tag + " hinge", Fe[:, 1], np.maximum(1 - dis_o, 0))
     return Fe
 
 
@@ -133,7 +133,7 @@ def test_generation_problem_drop_in():
     rel = np.abs(out["F"][:, 0] - Fo[:, 0]) / np.abs(Fo[:, 0])
     diag("[e2e] GenerationProblem drop-in: sim rel err %.3e, hinge abs err %.3e" % (rel.max(), np.abs(out["F"][:, 1] - Fo[:, 1]).max()))
     assert rel.max() < 1e-3
-    check("drop-in hinge", out["F"][:, 1], Fo[:, 1], 5e-3, atol=2e-3)
+    check_logits("drop-in hinge", out["F"][:, 1], Fo[:, 1])
     ls = cfg.latent(cfg)
     ls.set_from_population(x[:3])
     img = prob.generator.generate(ls)                      # run.py:118 — no minibatch argument
@@ -239,25 +239,36 @@ def test_pop512_as_eight_shards_of_64():
     """BASELINE.json configs[3] (StyleGAN2_ffhq_d pop=512, 64 per GPU x 8) exercised as offset shards on ONE GPU at the mid
     architecture: the eight 64-row shard calls reproduce the whole-population call row for row."""
     from clip_glass_amd.parallel import shard_bounds
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mid_modules.npz"))
     name, P, bs = "mid", 512, 4
     c = M.CONFIGS[name]
-    sd = M.make_state(name, 0)
-    x = synth.latents(11, P, c["latent"])
-    e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1, noise_seed=3)
-    e.set_target(np.ones(c["clip"][5], np.float32))
-    e.evaluate(x[:64], generation=0)
-    e.set_target(M.make_target(e.details(64)["features"]))
-    F_whole = e.evaluate(x, generation=2)
-    parts = [e.evaluate(x[lo:hi], generation=2, first_minibatch=lo // bs) for lo, hi in shard_bounds(P, 8, bs)]
+    Pg = int(g["P"])
+    sd = M.make_state(name, int(g["seed"]))
+    # rows 0-7 = the reference-generated fixture's population (same seeds, device noise = the fixture's planes), so that C4 meets
+    # the REFERENCE and not only itself; the other 504 rows are fresh latents
+    x = np.concatenate([synth.latents(int(g["seed"]) + 1, Pg, c["latent"]), synth.latents(11, P - Pg, c["latent"])])
+    e = M.make_engine(name, sd, batch_size=bs, use_discriminator=True, max_pop=P, noise_mode=1, noise_seed=int(g["noise_seed"]))
+    e.set_target(g["target"])
+    gen = int(g["generation"])
+    F_whole = e.evaluate(x, generation=gen)
+    det = e.details(P)
+    parts = [e.evaluate(x[lo:hi], generation=gen, first_minibatch=lo // bs) for lo, hi in shard_bounds(P, 8, bs)]
     assert all(p.shape == (64, 2) for p in parts)
     Fs = np.concatenate(parts)
+    for tag, Fx in (("whole", F_whole), ("shard 0", parts[0])):
+        rel = np.abs(-Fx[:Pg, 0] - g["sim"]) / np.abs(g["sim"])
+        diag("[e2e] pop512 %s rows 0-%d vs reference fixture: sim rel err %.3e, hinge abs err %.3e" % (tag, Pg - 1, rel.max(), np.abs(Fx[:Pg, 1] - g["hinge"]).max()))
+        assert rel.max() < 1e-3
+        check_logits("pop512 %s hinge rows 0-%d" % (tag, Pg - 1), Fx[:Pg, 1], g["hinge"])
+    check_logits("pop512 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"])
     # a 512-row launch and a 64-row launch may pick different kernel instances for the same layer (launch-size thresholds:
     # streaming vs tiled conv, split-K depth), so rows agree to rounding, not bitwise: -sim to 1e-3 relative (the
     # north-star bar), the D hinge to the D tolerance used everywhere else in this file
     np.testing.assert_allclose(Fs[:, 0], F_whole[:, 0], rtol=1e-3, atol=0)
-    np.testing.assert_allclose(Fs[:, 1], F_whole[:, 1], rtol=5e-3, atol=2e-3)
+    check_logits("pop512 shards vs whole hinge", Fs[:, 1], F_whole[:, 1])
     # the SAME 64-row launch repeated with the same offsets is bitwise reproducible
-    again = e.evaluate(x[64:128], generation=2, first_minibatch=16)
+    again = e.evaluate(x[64:128], generation=gen, first_minibatch=16)
     np.testing.assert_array_equal(again, parts[1])
     e.close()
 
@@ -307,8 +318,8 @@ def test_full_size_ffhq_full_population():
     diag("[e2e] ffhq P=64 default chunk: rows 0-%d vs reference fixture: sim rel err %.3e, D abs err %.3e; chunk 64 vs 4 max |dF| %.3e"
          % (Pg - 1, rel.max(), np.abs(det["dis"][:Pg] - g["dis"]).max(), np.abs(Fs[0] - Fs[1]).max()))
     assert rel.max() < 1e-3
-    check("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], 5e-3, atol=2e-3)
+    check_logits("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"])
     assert np.isfinite(Fs[0]).all() and Fs[0].shape == (P, 2)
     # chunk 64 and chunk 4 launches may select different kernel instances per layer: equal to rounding
     np.testing.assert_allclose(Fs[0][:, 0], Fs[1][:, 0], rtol=1e-3, atol=0)
-    np.testing.assert_allclose(Fs[0][:, 1], Fs[1][:, 1], rtol=5e-3, atol=2e-3)
+    check_logits("ffhq P=64 chunk 64 vs 4 hinge", Fs[0][:, 1], Fs[1][:, 1])

@@ -208,6 +208,78 @@ def test_population_sharding_two_process_gloo():
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
+def _gloo_problem_worker(rank, world, port, q):
+    """GenerationProblem on two gloo ranks with a recording stand-in for the device engine (no GPU here): the default process
+    group is picked up when dist is None, the device is this rank's LOCAL_RANK, rows come back identical on every rank."""
+    import types
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from clip_glass_amd import config as gconfig, generator
+    made = []
+
+    class FakeEngine:
+        def __init__(self, channels, **kw):
+            self.kw = kw
+            self.cfg = types.SimpleNamespace(n_obj=kw.get("n_obj", 2))
+            made.append(self)
+
+        def load_state(self, sd): pass
+        def finalize(self): pass
+        def set_target(self, t): pass
+
+        def evaluate(self, x, generation=0, first_minibatch=0, noise=None):
+            x = np.asarray(x, np.float32)
+            return np.stack([x[:, 0] + 1000 * first_minibatch, x[:, 1] + generation], 1).astype(np.float32)
+    generator.Engine = FakeEngine
+    from clip_glass_amd.problem import GenerationProblem
+    cfg = types.SimpleNamespace(config="StyleGAN2_ffhq_d", device="cuda:0", target="unused")
+    vars(cfg).update(gconfig.get_config("StyleGAN2_ffhq_d"))
+    vars(cfg).update(weights="synthetic:0", clip_weights="synthetic:0", channels=[16, 16, 32, 32], dim_z=32, mapping_layers=2,
+                     clip_geometry=(64, 2, 1, 8, 32, 32), target_features=np.ones(32, np.float32),
+                     problem_args=dict(cfg.problem_args, n_var=32, n_constr=32))
+    x = synth.latents(3, 24, 32)
+    outs = []
+    for d in (None, dist):                       # picked up by itself / passed explicitly
+        prob = GenerationProblem(cfg, dist=d)
+        out = {}
+        prob._evaluate(x, out)
+        prob._evaluate(x, out)                   # second generation
+        outs.append(out["F"])
+    err = None
+    try:
+        ls = cfg.latent(cfg)
+        ls.set_from_population(x)
+        prob.generator.evaluate(ls, noise=[[np.zeros((4, 4), np.float32)]])
+    except ValueError as ex:
+        err = str(ex)
+    q.put((rank, outs, [e.kw.get("device") for e in made], err))
+    dist.destroy_process_group()
+
+
+def test_generation_problem_two_process_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_problem_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    x = synth.latents(3, 24, 32).astype(np.float32)
+    mb = np.repeat(np.array([0, 0, 0, 3, 3, 3]), 4)            # 6 minibatches over 2 ranks: rows 12.. ran with first_minibatch 3
+    expect = np.stack([x[:, 0] + 1000 * mb, x[:, 1] + 1], 1)   # second _evaluate = generation 1
+    for rank, outs, devices, err in res:
+        assert devices == [rank, rank], "device must be this rank's LOCAL_RANK, got %s" % (devices,)
+        for F in outs:
+            assert F.shape == (24, 2)
+            np.testing.assert_allclose(F, expect, rtol=1e-6)
+        assert err is not None and "sharded" in err
+    np.testing.assert_array_equal(res[0][1][0], res[1][1][0])
+
+
 def test_clip_tokenizer_matches_reference_known_answers():
     """Own BPE implementation vs the reference tokenizer (needs the reference's merges asset)."""
     bpe = "/root/reference/assets/bpe_simple_vocab_16e6.txt.gz"

@@ -36,6 +36,27 @@ def check(name, got, ref, rtol_scale, atol=0.0):
     assert nbad == 0, "%s: %d/%d elements exceed tol %.3e (max err %.3e at %s)" % (name, nbad, err.size, tol, err.max(), worst)
 
 
+# Second objective (D logit / hinge).  Element-wise |got - ref| <= D_ATOL + D_RTOL * |ref|.  Round 2 used 5e-3 * max|ref| + 2e-3
+# (~4.5e-3 absolute at |D| ~ 0.5): an order-of-magnitude regression would have passed.  The fp16-storage engine delivers
+# 3e-4 .. 1.4e-3 absolute over the mini / mid / ffhq cases (gpurun_out/diag.log), so the bar sits at 1.5e-3 + 1.5e-3 |ref|.
+D_ATOL, D_RTOL = 1.5e-3, 1.5e-3
+
+
+def check_logits(name, got, ref, atol=D_ATOL, rtol=D_RTOL):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    worst = np.unravel_index(int((err - tol).argmax()), err.shape) if err.size else ()
+    nbad = int((err > tol).sum())
+    diag("[check] %-34s max_err %.3e (worst vs tol at %s: got %.5g ref %.5g tol %.3e) bad %d/%d %s"
+         % (name, err.max() if err.size else 0, worst, got[worst] if err.size else 0, ref[worst] if err.size else 0,
+            tol[worst] if err.size else 0, nbad, err.size, "OK" if nbad == 0 and np.isfinite(got).all() else "FAIL"))
+    assert np.isfinite(got).all(), "%s: non-finite values" % name
+    assert nbad == 0, "%s: %d/%d elements exceed %.1e + %.1e |ref| (max err %.3e)" % (name, nbad, err.size, atol, rtol, err.max())
+
+
 def nhwc(t):
     return np.ascontiguousarray(np.asarray(t).transpose(0, 2, 3, 1))
 
