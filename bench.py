@@ -147,6 +147,7 @@ def bench_gpt2(args):
 
 
 def main():
+    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50, help="timed _evaluate calls (the config runs 50 generations)")
@@ -218,7 +219,6 @@ def main():
     biggan = cfg.get("biggan")
     w, layers, heads, patch, res, emb = cfg["clip"]
     if biggan:
-        global BATCH
         BATCH = 8
         b = biggan
         sd = synth.make_biggan_state(synth.biggan_spec(b["layers"], b["attention_pos"], b["ch"], b["z_dim"], b["num_classes"]), 0)
