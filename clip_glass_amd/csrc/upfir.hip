@@ -285,6 +285,7 @@ struct UpGeo {
     int WT;                    // pixel work items = n_grids * n_seg * tiles_x
     unsigned invPX, invPY;     // ceil(2^32 / (W + 1)), ceil(2^32 / (H + 1)): exact n / pitch for the ranges used here
     unsigned inv2PX, inv2PY;   // same for the output pitches 2 (W + 1), 2 (H + 1)
+    int prefetch;              // GRID = false: fetch the next step's stage-0 operands under this step's FIR (A/B knob)
 };
 
 namespace {
@@ -299,6 +300,9 @@ constexpr int U_OFF_DS = U_OFF_STY + 8 * 1024;     // [8][32] fp32 demodulation
 constexpr int U_OFF_PS = U_OFF_DS + 8 * 128;       // [8][32] fp16 consumer style
 constexpr int U_OFF_BI = U_OFF_PS + 8 * 64;        // [32] fp32 bias
 constexpr int U_OFF_NZ = U_OFF_BI + 128;           // [16 rows][60 cols] fp32 noise * strength
+constexpr int U_OFF_LNZ = 65536;                   // GRID = false: the same noise table, behind the T tile (it is read during the FIR)
+constexpr int U_OFF_HS = U_OFF_LNZ + 16 * 60 * 4;  // [256 threads][3 rows] h8: the FIR window between steps
+constexpr int U_LDS = U_OFF_HS + 256 * 48;         // 81664 B: two workgroups per CU (163328 of 163840)
 static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32 * ROWB, "constant tables fit behind the staging images");
 __device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 }  // namespace
@@ -335,12 +339,14 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     // (the last, half-empty round re-reads round 3's vector in threads >= 128)
     const int b_goff0 = ((threadIdx.x >> 7) * p.Cout + n0 + ((threadIdx.x >> 2) & 31)) * p.Cin + (threadIdx.x & 3) * 8;
     const int b_step = 2 * p.Cout * p.Cin;
-    h8 hs[4];   // FIR threads: horizontally filtered t rows, a sliding window that runs on from step to step
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hs[i][j] = (half_t)0.f;
+    // FIR threads keep a sliding window of horizontally filtered t rows that runs on from step to step: its three live rows wait
+    // in a thread-private LDS slot during the K loop (16 registers the K loop needs, next to the prefetched operands)
+    char* hs_slot = smem + U_OFF_HS + threadIdx.x * 48;
 
+    int a_goff[NA];
+    int okm = 0, selm = 0;
+    h8 ra[NA], rb[NB];
+    bool have = false;          // (uniform) stage 0 of this step was fetched during the previous step's FIR phase (GRID = false)
     for (int step = 0; step < g.S; ++step) {
         const int o_first = Y0 + (step ? 16 * step - 4 : 0);   // first output row this step emits
         if (o_first >= out_rows) break;                         // (uniform) the segment runs off the grid
@@ -353,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             return min(img0 + iyi * g.NXI + ixi, p.B - 1);
         };
 
-        // ---- staging geometry of this step (re-derived from an opaque thread id: nothing here may be hoisted and kept) ----
-        int a_goff[NA];
-        int okm = 0, selm = 0;
-        {
+        // ---- staging geometry of a step (re-derived from an opaque thread id: nothing here may be hoisted and kept) ----
+        auto aim = [&](int my0, int iyi0) {
+            okm = 0;
+            selm = 0;
             const int t = u_opaque(threadIdx.x), part = t & 3;
 #pragma unroll
             for (int k = 0; k < NA; ++k) {
@@ -378,17 +384,16 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     okm |= (ok ? 1 : 0) << k;
                 }
             }
-        }
+        };
         // interior tile of a single-image grid whose weights carry the style: registers -> LDS as they are
         const bool plain = !GRID && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
 
-        h8 ra[NA], rb[NB];
         auto load_a = [&](int c0) {
 #pragma unroll
             for (int k = 0; k < NA; ++k) ra[k] = *(const h8*)(p.x + a_goff[k] + c0);
         };
         auto load_b = [&](int c0) {
-            const half_t* wp = wb + b_goff0 + c0;
+            const half_t* wp = wb + u_opaque(b_goff0) + c0;       // (opaque: five hoisted 64-bit pointers would be spilled)
 #pragma unroll
             for (int k = 0; k < NB; ++k) rb[k] = *(const h8*)(wp + ((k == NB - 1 && threadIdx.x >= 128) ? k - 1 : k) * b_step);
         };
@@ -420,7 +425,15 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 if (k < NB - 1 || t + 256 * k < NVB) *(h8*)(bb + k * 64 * ROWB) = rb[k];
         };
 
-        __syncthreads();   // the previous step's FIR is done with the T tile (and with the tables behind it)
+        if (GRID) {
+            __syncthreads();   // the previous step's FIR is done with the T tile (and with the tables behind it)
+        } else {
+            // LDS-only barrier: a __syncthreads() here would also wait (vmcnt(0)) for the previous FIR's 16 row stores and for the
+            // stage-0 operands that were fetched under it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!have) aim(my0, iyi0);
         if (GRID) {
             // ---- constant tables of this step: ONE batch of global loads, issued ahead of stage 0's operands --------------
             const int t = u_opaque(threadIdx.x);
@@ -472,10 +485,11 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             for (int u = 0; u < 4; ++u)
                 if (t + 256 * u < 960) *(float*)(smem + U_OFF_NZ + (t + 256 * u) * 4) = p.noise_strength * nzv4[u];
             __syncthreads();   // style rows visible to stage 0's store_a
-        } else {
+        } else if (!have) {
             load_a(0);
             load_b(0);
         }
+        have = false;
 
         f16x acc[2][4];   // [m-row of this wave][parity class ry*2+rx]
 #pragma unroll
@@ -585,6 +599,8 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 
             // ---- FIR (separable [1,3,3,1]/4 per axis) + noise + bias + lrelu; T row r <-> virtual output row ovy0 + r ----
             if (col_on) {
+                h8 hs[4];
+                hs[1] = *(const h8*)(hs_slot); hs[2] = *(const h8*)(hs_slot + 16); hs[3] = *(const h8*)(hs_slot + 32);   // rows 13, 14, 15 of the previous step
                 const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
                 const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
                 const char* tr[4];
@@ -611,6 +627,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                         *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
                     }
                 }
+                *(h8*)(hs_slot) = hs[1]; *(h8*)(hs_slot + 16) = hs[2]; *(h8*)(hs_slot + 32) = hs[3];
             }
         } else {
             // ---- single image: everything the FIR needs from global memory is fetched HERE, unconditionally and in one batch, so that
@@ -637,6 +654,13 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int r = 0; r < 16; ++r) nzr[r] = nzp[(long long)min(max(ovy0 + r, 0), p.Ho - 1) * p.Wo];
             }
             mfma_block();
+            // the step's noise values park in LDS behind the T tile (one column per cg == 0 thread): as registers they would be live
+            // through the whole FIR next to the prefetched operands of the next step, and a spilled value's scratch reload is a VMEM
+            // op that waits for every older prefetch load (in-order vmcnt)
+            if (cg == 0 && t < 240) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *(float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4) = p.noise_strength * nzr[r];
+            }
             __syncthreads();   // everyone is done with the staging area: overlay T
             {
                 char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
@@ -656,7 +680,17 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                         }
             }
             __syncthreads();
+            // stage 0 of the NEXT step: its operands travel while this step's FIR runs (the step is latency-bound: two exposed
+            // global round trips + the store drain at the step barrier were ~2/3 of its 14 us on the two-stage 1024^2 layer)
+            if (g.prefetch && step + 1 < g.S && Y0 + 16 * (step + 1) - 4 < out_rows) {
+                aim(my0 + 8, 0);
+                load_a(0);
+                load_b(0);
+                have = true;
+            }
             if (t < 240 && ox < p.Wo) {
+                h8 hs[4];
+                hs[1] = *(const h8*)(hs_slot); hs[2] = *(const h8*)(hs_slot + 16); hs[3] = *(const h8*)(hs_slot + 32);   // rows 13, 14, 15 of the previous step
                 const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
                 h8 bias8;
 #pragma unroll
@@ -676,12 +710,13 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                              v3 = *(const h8*)(tr[3] + r * 4096);
                     hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
                     if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) {
-                        const h8 bn = bias8 + (half_t)(p.noise_strength * nzr[r]);
+                        const h8 bn = bias8 + (half_t)*(const float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4);
                         h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
                         *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * ps8;
                     }
                     yp += rowpitch;
                 }
+                *(h8*)(hs_slot) = hs[1]; *(h8*)(hs_slot + 16) = hs[2]; *(h8*)(hs_slot + 32) = hs[3];
             }
         }
     }
@@ -693,7 +728,7 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     if (p.Cin > 512 || p.H < 8 || p.W < 16) return nullptr;
     if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
     if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
-    constexpr int LDS = 64 * 1024;
+    constexpr int LDS = U_LDS;
     static DevOnce once;
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -737,6 +772,8 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     }
     if (env_ng > 0 && 8 % env_ng == 0 && g.NTn % env_ng == 0) ng = env_ng;
     g.ngroups = ng;
+    static const bool no_prefetch = getenv("GLASS_UPFIR_NO_PREFETCH") != nullptr;
+    g.prefetch = no_prefetch ? 0 : 1;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
     // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
     const bool lean = p.w_bstride && !p.sn16 && !p.dscale && g.NXI * g.NYI == 1;
