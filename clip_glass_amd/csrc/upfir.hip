@@ -772,8 +772,10 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     }
     if (env_ng > 0 && 8 % env_ng == 0 && g.NTn % env_ng == 0) ng = env_ng;
     g.ngroups = ng;
-    static const bool no_prefetch = getenv("GLASS_UPFIR_NO_PREFETCH") != nullptr;
-    g.prefetch = no_prefetch ? 0 : 1;
+    // measured (round 3, same box): prefetch on 2298 / 1476 / 1217 us vs off 2183 / 1496 / 1235 us on the r1024 / r512 / r256
+    // layers — a wash, as round 2's persistent-prefetch experiment was: the step is issue-bound, not latency-bound.  Off.
+    static const bool prefetch = getenv("GLASS_UPFIR_PREFETCH") != nullptr;
+    g.prefetch = prefetch ? 1 : 0;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
     // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
     const bool lean = p.w_bstride && !p.sn16 && !p.dscale && g.NXI * g.NYI == 1;
