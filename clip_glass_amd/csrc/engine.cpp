@@ -567,7 +567,8 @@ static int alloc_buffers(glass_engine* e) {
         const bool fused_ok = g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in >= 16;
         const bool tiled_ok = !g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in % 32 == 0;
         g.welems = 9LL * g.cin * g.cout;
-        g.premod = (fused_ok || tiled_ok) && g.welems * 2 <= (1200 << 10) && !getenv("GLASS_NO_PREMOD");
+        static const long long premod_kb = getenv("GLASS_PREMOD_MAX_KB") ? atoll(getenv("GLASS_PREMOD_MAX_KB")) : 500;   // A/B knob (round 3: the 256 -> 128 up-conv, 590 KB per sample, runs 4 % faster on the shared-weight image grid, and its consumer 5 % faster on the pre-styled output; 1200 was round 2's value)
+        g.premod = (fused_ok || tiled_ok) && g.welems * 2 <= (premod_kb << 10) && !getenv("GLASS_NO_PREMOD");
         if (g.premod && (rc = dev_alloc(e, &g.wm, (size_t)P * g.welems))) return rc;
     }
     if (c.noise_mode != 0) {
