@@ -168,6 +168,7 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_noise, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_rgb, hipEventDisableTiming);
     if (err != hipSuccess) {
         delete e;
         glass_set_error(std::string("stream/event creation failed: ") + hipGetErrorString(err));
@@ -192,6 +193,7 @@ extern "C" void glass_engine_destroy(glass_engine* e) {
     if (e->ev0) hipEventDestroy(e->ev0);
     if (e->ev1) hipEventDestroy(e->ev1);
     if (e->ev_noise) hipEventDestroy(e->ev_noise);
+    if (e->ev_rgb) hipEventDestroy(e->ev_rgb);
     if (e->stream) hipStreamDestroy(e->stream);
     if (e->stream_d) hipStreamDestroy(e->stream_d);
     delete e;
@@ -882,10 +884,20 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
     static const bool no_trgb_mid = getenv("GLASS_NO_TRGB_MID") != nullptr;
     static const bool no_pre_style = getenv("GLASS_NO_PRE_STYLE") != nullptr;
+    // A block's SEPARATE toRGB pass (blocks wider than 128 channels) is a bandwidth-bound read of the map the next block's
+    // up-conv reads too; in the two-stream mode it runs on the second stream next to that (issue-bound) up-conv.  The main
+    // stream joins before the next block's last conv: that launch overwrites the map toRGB reads and consumes its skip image.
+    static const bool no_rgb_side = getenv("GLASS_NO_TRGB_SIDE") != nullptr;      // A/B knob
+    const bool rgb_side = e->clip_overlap && e->cur == e->stream && !no_rgb_side;
+    bool rgb_pending = false;
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
         bool rgb_done = false, pre_styled = false;
         for (int l = 0; l < nl; ++l, ++gi) {
+            if (rgb_pending && l == nl - 1) {
+                hipStreamWaitEvent(e->stream, e->ev_rgb, 0);
+                rgb_pending = false;
+            }
             const GConv& g = e->gconv[gi];
             ConvParams p = conv_defaults();
             p.x = x;
@@ -994,16 +1006,30 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
         const GRgb& r = e->grgb[b];
         if (!rgb_done) {
             snprintf(tag, sizeof tag, "G.torgb.r%d", r.res);
+            const bool side = rgb_side && b + 1 < b_hi;       // (the last block's image is consumed right away)
+            if (side) {
+                hipEventRecord(e->ev_rgb, e->stream);
+                hipStreamWaitEvent(e->stream_d, e->ev_rgb, 0);
+                e->cur = e->stream_d;
+            }
+            {
             Prof pr(e, tag, 2.0 * B * (double)r.res * r.res * 3 * r.cin,
                     B * ((double)r.res * r.res * (2.0 * r.cin + 12.0 + (b ? 3.0 : 0.0))));
             if (!launch_torgb(x, B, r.res, r.res, r.cin, r.w, r.bias, e->d_s + (size_t)c0 * e->S_total + r.style_off,
                               e->S_total, e->d_smax + (size_t)c0 * e->n_style + r.style_idx, e->n_style, yprev, yb[yi], e->cur) &&
                 e->launch_error.empty())
                 e->launch_error = std::string("toRGB width not instantiated: ") + tag;
+            }
+            if (side) {
+                hipEventRecord(e->ev_rgb, e->stream_d);
+                e->cur = e->stream;
+                rgb_pending = true;
+            }
         }
         yprev = yb[yi];
         yi ^= 1;
     }
+    if (rgb_pending) hipStreamWaitEvent(e->stream, e->ev_rgb, 0);
     *x_out = x;
     *y_out = yprev;
 }
@@ -1294,6 +1320,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     }
     const bool overlap = e->overlap && out_F;
     const bool clip_ov = e->clip_overlap && !overlap && out_F && want_d;
+    static const bool clip_late = getenv("GLASS_CLIP_LATE") != nullptr;      // A/B knob
     hipStream_t sd = overlap ? e->stream_d : e->stream;
     for (int c0 = 0, k = 0; c0 < P; c0 += e->chunk, ++k) {
         const int B = std::min(e->chunk, P - c0);
@@ -1323,7 +1350,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
                 launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
                                       e->cur);
             }
-            if (clip_ov && c0 + e->chunk >= P) {   // last chunk's patches are in place: CLIP starts now on the second stream
+            if (clip_ov && !clip_late && c0 + e->chunk >= P) {   // last chunk's patches are in place: CLIP starts now on the second stream
                 GLASS_HIP(hipEventRecord(e->ev_g[0], e->stream));
                 GLASS_HIP(hipStreamWaitEvent(e->stream_d, e->ev_g[0], 0));
                 e->cur = e->stream_d;
@@ -1343,6 +1370,14 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
             }
             if (overlap) GLASS_HIP(hipEventRecord(e->ev_d[k], sd));
         }
+    }
+    if (clip_ov && clip_late) {   // CLIP's short launches next to the LOW-resolution discriminator (equally short launches) instead of
+        GLASS_HIP(hipEventRecord(e->ev_g[0], e->stream));          // next to its chip-filling high-resolution kernels
+        GLASS_HIP(hipStreamWaitEvent(e->stream_d, e->ev_g[0], 0));
+        e->cur = e->stream_d;
+        run_clip(e, P);
+        GLASS_HIP(hipEventRecord(e->ev_d[0], e->stream_d));
+        e->cur = e->stream;
     }
     // ---- phase C: low-resolution discriminator + head (second stream) || CLIP (main stream) ------
     if (want_d) {

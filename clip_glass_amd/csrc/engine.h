@@ -98,7 +98,7 @@ struct glass_engine {
     hipStream_t stream = nullptr, stream_d = nullptr, cur = nullptr;  // main, second (D/resize), current target
     bool overlap = false, clip_overlap = false;
     std::vector<hipEvent_t> ev_g, ev_d;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_noise = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_noise = nullptr, ev_rgb = nullptr;
     float last_ms = 0.f;
     int last_P = 0;
     std::string launch_error;   // a launcher refused a layer during the pass (reported by run_pass; nothing aborts)
