@@ -887,8 +887,10 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     // A block's SEPARATE toRGB pass (blocks wider than 128 channels) is a bandwidth-bound read of the map the next block's
     // up-conv reads too; in the two-stream mode it runs on the second stream next to that (issue-bound) up-conv.  The main
     // stream joins before the next block's last conv: that launch overwrites the map toRGB reads and consumes its skip image.
-    static const bool no_rgb_side = getenv("GLASS_NO_TRGB_SIDE") != nullptr;      // A/B knob
-    const bool rgb_side = e->clip_overlap && e->cur == e->stream && !no_rgb_side;
+    // Measured (round 3): 33.77 vs 33.74 ms per population — no gain, co-running kernels share the CUs they would have had
+    // anyway (the late-CLIP variant, GLASS_CLIP_LATE, loses 0.3 ms).  Opt-in knob only.
+    static const bool rgb_side_on = getenv("GLASS_TRGB_SIDE") != nullptr;
+    const bool rgb_side = e->clip_overlap && e->cur == e->stream && rgb_side_on;
     bool rgb_pending = false;
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
