@@ -72,6 +72,15 @@ inline int glass_cu_count() {   // CUs of the current device
 }
 
 __device__ __forceinline__ float lrelu_sqrt2(float v) { return (v > 0.f ? v : 0.2f * v) * GLASS_SQRT2; }
+// Branch-free activation + output scale for the conv epilogues (s > 0): max(v k1, v k2) with
+//   act 1 (lrelu 0.2 * sqrt2): (sqrt2 s, 0.2 sqrt2 s);  act 2 (relu): (s, 0);  none: (s, s).
+// As f4 arithmetic it compiles to v_pk_mul_f32 pairs + v_max_f32 — a third of the per-value compare / select / multiply chains
+// the epilogues spent before (they are VALU-issue bound: every wave of the workgroup is in its epilogue at the same time).
+struct ActK { float k1, k2; };
+__device__ __forceinline__ ActK act_consts(int act, float s) {
+    return ActK{(act == 1 ? GLASS_SQRT2 : 1.f) * s, (act == 1 ? 0.2f * GLASS_SQRT2 : act == 2 ? 0.f : 1.f) * s};
+}
+__device__ __forceinline__ f4 act_apply(f4 v, ActK k) { return __builtin_elementwise_max(v * k.k1, v * k.k2); }
 
 // Parameters of one convolution launch (implicit GEMM, NHWC fp16 activations).
 // GEMM view: M = B*Hc*Wc (conv grid), N = Neff, K = KS*KS*Cin.

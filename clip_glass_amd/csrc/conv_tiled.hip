@@ -286,14 +286,17 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     bq[j][g] = f4{0.f, 0.f, 0.f, 0.f};
                     if (p.bias) bq[j][g] = *(const f4*)(p.bias + cur.n0 + (wn * NJ + j) * 32 + 8 * g + 4 * kh);
                 }
+            const ActK aks = act_consts(p.act == 1 ? 1 : 0, 1.f);
 #pragma unroll
             for (int i = 0; i < RW; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = acc[i][j][q] + bq[j][q >> 2][q & 3];
-                        acc[i][j][q] = p.act == 1 ? lrelu_sqrt2(v) : v;
+                    for (int g = 0; g < 4; ++g) {
+                        const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+                        const f4 v = act_apply(a + bq[j][g], aks);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][j][g * 4 + q] = v[q];
                     }
             for (int cs = 0; cs < n_chunks; ++cs) {
                 __syncthreads();                             // previous stage's fragment reads are done
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                             ytap[c][q] = yp[(c * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
                 }
             }
-            if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b; Cc[2 * NT + t] = c_s; }   // Cc sits behind As / Bs / Os
+            if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b + c_s; }   // Cc sits behind As / Bs / Os
+            const ActK ak = act_consts(SKIP ? 0 : p.act, p.out_scale);
             __syncthreads();                              // every wave is done reading As / Bs; constants visible
             f16x rgb;
 #pragma unroll
@@ -382,31 +386,15 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                 for (int g = 0; g < 4; ++g) {
                     const int nw = j * 32 + 8 * g + 4 * kh;   // first of 4 consecutive channels, local to the wave's channels
                     const int nl = wn * NJ * 32 + nw;          // ... local to the n tile
-                    const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl), sh4 = *(const f4*)(Cc + 2 * NT + nl);
+                    const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl);      // bb = bias + shift
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
-                        float v[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q] = acc[i][j][g * 4 + q] * d[q];
-                            v[q] += nzr[i];
-                            v[q] += bb[q];
-                            v[q] += sh4[q];
-                        }
-                        if (!SKIP && p.act == 1) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = lrelu_sqrt2(v[q]);
-                        } else if (!SKIP && p.act == 2) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                        }
-                        if (p.res) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[q] += (float)rq[g][i][q];
-                        }
+                        const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+                        f4 v = act_apply(a * d + bb + nzr[i], ak);           // (SKIP: activation was applied before the skip stages: ak = scale only)
+                        if (p.res) v += f4{(float)rq[g][i][0], (float)rq[g][i][1], (float)rq[g][i][2], (float)rq[g][i][3]} * p.out_scale;
                         h4 out;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) out[q] = (half_t)(v[q] * p.out_scale);
+                        for (int q = 0; q < 4; ++q) out[q] = (half_t)v[q];
                         *(h4*)(Os + (i * 32 + lr) * OROW + nw * 2) = out;
                         if (TRGB) va[i][g] = out;
                     }
