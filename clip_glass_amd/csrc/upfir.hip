@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             if (col_on) {
                 h8 hs[4];
                 hs[1] = *(const h8*)(hs_slot); hs[2] = *(const h8*)(hs_slot + 16); hs[3] = *(const h8*)(hs_slot + 32);   // rows 13, 14, 15 of the previous step
-                const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+                const half_t f3 = (half_t)3.f, fq4 = (half_t)0.0625f, ft4 = (half_t)0.1875f;   // [1,3,3,1]/4 per axis: horizontal pass unscaled (x 4), vertical / 16
                 const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
                 const char* tr[4];
 #pragma unroll
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int r = 0; r < 16; ++r) {
                     const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
                              v3 = *(const h8*)(tr[3] + r * 4096);
-                    hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
+                    hs[r & 3] = (v1 + v2) * f3 + (v0 + v3);           // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
                     const int ovy = ovy0 + r;
                     const bool second = ovy >= yb;
                     const int iyo = iyi0 + (second ? 1 : 0);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     const int img = img0 + iyo * g.NXI + ixo;
                     if ((step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B) {
                         const h8 bn = bias8 + (half_t)nzr[r];
-                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
+                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
                         half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
                         *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
                     }
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             if (t < 240 && ox < p.Wo) {
                 h8 hs[4];
                 hs[1] = *(const h8*)(hs_slot); hs[2] = *(const h8*)(hs_slot + 16); hs[3] = *(const h8*)(hs_slot + 32);   // rows 13, 14, 15 of the previous step
-                const half_t fq = (half_t)0.25f, ft = (half_t)0.75f;
+                const half_t f3 = (half_t)3.f, fq4 = (half_t)0.0625f, ft4 = (half_t)0.1875f;   // [1,3,3,1]/4 per axis: horizontal pass unscaled (x 4), vertical / 16
                 h8 bias8;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)bq0[j]; bias8[j + 4] = (half_t)bq1[j]; }
@@ -708,11 +708,13 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int r = 0; r < 16; ++r) {
                     const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
                              v3 = *(const h8*)(tr[3] + r * 4096);
-                    hs[r & 3] = (v0 + v3) * fq + (v1 + v2) * ft;
+                    hs[r & 3] = (v1 + v2) * f3 + (v0 + v3);           // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
                     if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) {
                         const h8 bn = bias8 + (half_t)*(const float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4);
-                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft + bn);
-                        *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * ps8;
+                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
+                        v = __builtin_elementwise_max(v * k1, v * k2);
+                        if (p.post_scale16) v = v * ps8;                // (uniform: per-sample-weight layers feed a conv whose weights carry its style)
+                        *(h8*)yp = v;
                     }
                     yp += rowpitch;
                 }

@@ -445,7 +445,7 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
                     yb = 2 * PY * (iyi0 + 1)
                     for r in range(16):
                         v = [T[r, 1 + jx:61 + jx].astype(np.float32) for jx in range(4)]
-                        hs[r & 3] = pk(pk(pk(v[0] + v[3]).astype(np.float32) * 0.25) + pk(pk(v[1] + v[2]).astype(np.float32) * 0.75))
+                        hs[r & 3] = pk(pk(v[1] + v[2]).astype(np.float32) * 3.0 + pk(v[0] + v[3]).astype(np.float32))      # x 4 (one v_pk_fma)
                         ovy = Y0 + 16 * step - 4 + r
                         second = ovy >= yb
                         iyo = iyi0 + (1 if second else 0)
@@ -463,7 +463,7 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
                                 continue
                             nz = 0.0 if noise is None else noise_strength * float(np.asarray(noise, np.float32)[img // batch_size, oy, ox])
                             bn = pk((0.0 if bias is None else np.asarray(bias, np.float32)).astype(f16).astype(np.float32) + np.float32(f16(nz)))
-                            vv = pk(a[oxl].astype(np.float32) * 0.25 + pk(m[oxl].astype(np.float32) * 0.75 + bn.astype(np.float32)).astype(np.float32))
+                            vv = pk(a[oxl].astype(np.float32) * 0.0625 + pk(m[oxl].astype(np.float32) * 0.1875 + bn.astype(np.float32)).astype(np.float32))
                             o = np.maximum(pk(vv.astype(np.float32) * np.float32(k1)), pk(vv.astype(np.float32) * np.float32(k2)))
                             sx = (ixo - ixi0) & 3
                             if ps16 is not None:
