@@ -150,6 +150,7 @@ struct ConvParams {
     const half_t* skip_w;   // [Neff][Cin]
     int dry_run;            // conv_tiled / conv_glds launchers: report the kernel that would run, launch nothing
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
+    int row_walk;           // conv_stream A/B knob: row-major walk of the persistent workgroups (round 2) instead of down the columns
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)
     float* y32;             // output fp32, same layout
 };

@@ -72,6 +72,7 @@ struct DownParams {
     const float* b1;    // [64]
     half_t* y;          // [B][R/2][R/2][64]
     int B, R;
+    int row_walk;       // A/B knob (GLASS_ROW_WALK): round 2's row-major tile walk
     unsigned long long* trace;   // phase timestamps of workgroup 0 (GLASS_DOWN_TRACE; nullable)
 };
 #define TRACE(ph)                                                                                                  \
@@ -96,10 +97,13 @@ __global__ __launch_bounds__(256, 2) void conv_down_kernel(DownParams p, int til
     // Always 18 loads, all unconditional (clamped coordinates; tiles past the end re-read the last tile).
     int nx_it = first, nx_b, nx_ty, nx_tx;             // the walk: tile index -> (sample, tile row, tile column), no divisions
     {
+        // The walk goes DOWN a tile column (tile row fastest): consecutive windows of a workgroup then share 4 of their 12 rows,
+        // which the second one finds in L2 — with the row-major walk of round 2 every window's vertical halo came from HBM / MALL
+        // (PMC: 7.66 GB fetched for 4.8 GB of input).
         nx_b = uni(first / tpi);
         const int trem = first - nx_b * tpi;
-        nx_ty = uni(trem / tiles_x);
-        nx_tx = uni(trem - nx_ty * tiles_x);
+        if (p.row_walk) { nx_ty = uni(trem / tiles_x); nx_tx = uni(trem - nx_ty * tiles_x); }
+        else { nx_tx = uni(trem / tiles_y); nx_ty = uni(trem - nx_tx * tiles_y); }
     }
     // The 18 loads of a refill are NOT issued as one burst: a burst keeps the CU's address unit busy for ~2000 cycles with every
     // wave of the workgroup stalled at issue.  They go out in three groups of six, threaded between the rows of the
@@ -114,7 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv_down_kernel(DownParams p, int til
         is_rs = R * CIN;
         if (nx_it + 1 < last) {        // advance the walk (uniform); past the end it stays on the last tile
             ++nx_it;
-            if (++nx_tx == tiles_x) { nx_tx = 0; if (++nx_ty == tiles_y) { nx_ty = 0; ++nx_b; } }
+            if (p.row_walk) { if (++nx_tx == tiles_x) { nx_tx = 0; if (++nx_ty == tiles_y) { nx_ty = 0; ++nx_b; } } }
+            else if (++nx_ty == tiles_y) { nx_ty = 0; if (++nx_tx == tiles_x) { nx_tx = 0; ++nx_b; } }
         } else {
             nx_it = last;
         }
@@ -326,6 +331,8 @@ const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1
     DownParams p;
     p.h = h; p.xs = xs; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
     p.trace = nullptr;
+    static const bool row_walk = getenv("GLASS_ROW_WALK") != nullptr;
+    p.row_walk = row_walk ? 1 : 0;
     const char* trace_path = getenv("GLASS_DOWN_TRACE");     // dev tool: per-phase shader-clock timestamps of workgroup 0
     if (trace_path) (void)hipMalloc(&p.trace, 64 * 8 * 4 * sizeof(unsigned long long));
     if (p.trace) (void)hipMemsetAsync(p.trace, 0, 64 * 8 * 4 * sizeof(unsigned long long), st);

@@ -96,16 +96,20 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
     auto cur_at = [&](int id) {
         Cur c;
         const int tpi = tiles_x * tiles_y;
+        // the walk goes DOWN a tile column (tile row fastest): consecutive patches share 2 of their 10 rows, which the second one
+        // finds in L2 (row-major, the vertical halo of every patch came from HBM / MALL: 6.0 GB fetched for 4.3 GB of input)
         c.b = id / tpi;
         const int trem = id - c.b * tpi;
-        c.ty = trem / tiles_x;
-        c.tx = trem - c.ty * tiles_x;
+        if (p.row_walk) { c.ty = trem / tiles_x; c.tx = trem - c.ty * tiles_x; }
+        else { c.tx = trem / tiles_y; c.ty = trem - c.tx * tiles_y; }
         return c;
     };
     auto advance = [&](Cur& c) {
-        if (++c.tx == tiles_x) {
-            c.tx = 0;
-            if (++c.ty == tiles_y) { c.ty = 0; ++c.b; }
+        if (p.row_walk) {
+            if (++c.tx == tiles_x) { c.tx = 0; if (++c.ty == tiles_y) { c.ty = 0; ++c.b; } }
+        } else if (++c.ty == tiles_y) {
+            c.ty = 0;
+            if (++c.tx == tiles_x) { c.tx = 0; ++c.b; }
         }
     };
     const Cur c_first = cur_at(first);
@@ -465,8 +469,11 @@ bool conv_stream_applies(const ConvParams& p) {
     return PT >= stream_slots() * 6;           // streaming only pays with many tiles per workgroup
 }
 
-const char* launch_conv_stream(const ConvParams& p, hipStream_t st) {
-    if (!conv_stream_applies(p)) return nullptr;
+const char* launch_conv_stream(const ConvParams& p0, hipStream_t st) {
+    if (!conv_stream_applies(p0)) return nullptr;
+    ConvParams p = p0;
+    static const bool row_walk = getenv("GLASS_ROW_WALK") != nullptr;      // A/B knob: round 2's row-major tile walk
+    p.row_walk = row_walk ? 1 : 0;
     const bool trgb = p.trgb_yout != nullptr, frgb = p.rgb_y != nullptr;
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
