@@ -33,8 +33,11 @@
 // XS (3x3 stride 1, TH = 8, one n tile): ConvParams::xs_out — the blur-down of the input map from the patch already in LDS.
 // SPL: the four waves form a 2 x 2 grid (row pair x n half) instead of 4 x 1: each weight fragment a wave reads feeds two tile rows
 // (stride-2 convs, TH = 4: 8 fragment reads per 8 MFMAs instead of 10).
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false>
-__global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
+// B2: the weight slices alternate between TWO register sets and are requested two stages ahead (costs NB * 4 VGPRs).
+// DEEP: the next chunk's patch is requested as soon as this chunk's patch is in LDS (three stages ahead instead of one).
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false, bool B2 = false,
+          bool DEEP = false>
+__global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = SPL ? TH / 2 : TH / 4;  // tile rows per wave
     constexpr int NJ = SPL ? NT / 64 : NT / 32; // 32-wide n tiles per wave
     constexpr int PH = (TH - 1) * S + KS;      // patch rows
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     };
     static_assert(PH * PW * ROWB + 64 < 65536, "LDS offsets are packed in 16 bits");
 
-    h8 ra[NA], rb[NB];
+    h8 ra[NA], rb[NB], rb2[B2 ? NB : 1];   // B2: two weight-stage register sets, stage s is stored from set s & 1
     h8 sh;   // style of this thread's 8 channels of the current chunk (fp16: packed multiply at staging)
     int ld_c0 = 0;   // chunk offset of the patch held in ra (pre-activation shift is fetched at store time)
 #pragma unroll
@@ -130,13 +133,13 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
         if (p.sn16) sh = *(const h8*)(snb + c0);
         ld_c0 = c0;
     };
-    auto load_b = [&](int c0, int ty) {
+    auto load_b = [&](h8 (&RB)[NB], int c0, int ty) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int u = min(t + 256 * k, NVB - 1);
             const int tx = u / (NT * 4);
             const int n = (u >> 2) % NT;
-            rb[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
+            RB[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
         }
     };
     auto a_lds = [&](int k) { return As + ((a_loff[k >> 1] >> ((k & 1) * 16)) & 0xffff); };
@@ -161,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                     *(h8*)a_lds(k) = (((okm >> k) & 1) ? ra[k] : zero) * sh;    // 4 x v_pk_mul_f16 (1.0 without a style)
         }
     };
-    auto store_b = [&]() {
+    auto store_b = [&](const h8 (&RB)[NB]) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int u = t + 256 * k;
-            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = rb[k];
+            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = RB[k];
         }
     };
 
@@ -181,9 +184,17 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     const bool fast = TRGB || SKIP || (!PERSIST && !p.up && (p.Cout & 7) == 0 && !p.no_tstore);
     float* Cc = (float*)(smem + CC_OFF);   // [3][NT]
     char* Tt = smem + CC_OFF + 3 * NT * 4;  // TRGB: this sample's weight tables [2][16][NT] fp16
+    // DEEP prefetch (round 3): every register-staged kernel ran at ~3.3 us per K stage whatever its MFMA count (24 - 36 per
+    // wave = 0.3 - 0.5 us) — one stage of prefetch distance means every stage waits out a loaded L2 / HBM round trip.  The patch
+    // of the NEXT chunk is now requested right after this chunk's patch has gone to LDS (three stages ahead instead of one: its
+    // registers are free from then on), and the weight slices alternate between two register sets, requested two stages ahead.
+    constexpr bool deep = DEEP && !PERSIST;
     aim(cur);
     load_a(0);
-    load_b(0, 0);
+    load_b(rb, 0, 0);
+    if constexpr (B2) {
+        if (deep && n_stages > 1) load_b(rb2, KS > 1 ? 0 : 32, KS > 1 ? 1 : 0);
+    }
 
     for (;;) {
         // next valid work item of this block (uniform across the block)
@@ -201,10 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
         int c = 0, ty = 0;
-        for (int s = 0; s < n_stages; ++s) {
+        auto stage = [&](int s, h8 (&RBc)[NB], h8 (&RBo)[NB]) {   // RBc: the set this stage stores from; RBo: the other one
             __syncthreads();  // previous stage's (or previous tile's) fragment reads are done
             if (ty == 0) store_a();
-            store_b();
+            store_b(RBc);
             __syncthreads();
             if (XS && ty == 0) {
                 // the 8 x 32 tile of this 32-channel chunk (+ halo, zeros outside the image) sits in LDS: its 4 x 16 down-sampled
@@ -230,13 +241,23 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             }
             int nc = c, nty = ty + 1;
             if (nty == KS) { nty = 0; nc = c + 1; }
-            if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
+            if (deep) {
+                if (ty == 0 && c + 1 < n_chunks) load_a((c + 1) * 32);          // this chunk's patch is in LDS: its registers carry the next one
+                if (B2) {
+                    if (s + 2 < n_stages) {                                      // the set just stored takes stage s + 2
+                        const int t2 = ty + 2;
+                        load_b(RBc, (c + t2 / KS) * 32, t2 % KS);
+                    }
+                } else if (s + 1 < n_stages) {
+                    load_b(RBo, nc * 32, nty);
+                }
+            } else if (s + 1 < n_stages) {  // prefetch the next stage while this one computes
                 if (nty == 0) load_a(nc * 32);
-                load_b(nc * 32, nty);
+                load_b(RBo, nc * 32, nty);
             } else if (has_next) {   // last stage: prefetch stage 0 of the NEXT tile; it stays in flight
                 aim(nxt);            // through this tile's MFMA block and store epilogue
                 load_a(0);
-                load_b(0, 0);
+                load_b(RBo, 0, 0);
             }
             // ---- MFMA block: KS taps x 2 k16 steps x RW x NJ --------------------------------
 #pragma unroll
@@ -259,6 +280,14 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
             }
             c = nc;
             ty = nty;
+        };
+        if constexpr (B2) {
+            for (int s = 0; s < n_stages; s += 2) {
+                stage(s, rb, rb2);
+                if (s + 1 < n_stages) stage(s + 1, rb2, rb);
+            }
+        } else {
+            for (int s = 0; s < n_stages; ++s) stage(s, rb, rb);          // (single weight set)
         }
 
         const int b = cur.b;
@@ -502,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_kernel(ConvParams p, int NT
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false, bool B2 = false, bool DEEP = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
@@ -510,7 +539,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
     static DevOnce once;                       // (one per template instance)
     if (once.first() && LDS > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>,
+        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
@@ -523,7 +552,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
         static int per_cu_cache = 0;           // occupancy is a property of the kernel + architecture; the CU count is per device
         if (!per_cu_cache) {
             int per_cu = 1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>, 256, LDS);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>, 256, LDS);
             per_cu_cache = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         }
         resident = glass_cu_count() * per_cu_cache;
@@ -532,7 +561,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
     if (p.dry_run) return name;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -540,12 +569,15 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
     static const bool no_ts = getenv("GLASS_NO_TSTORE") != nullptr;   // experiment knob
     if (no_ts) p.no_tstore = 1;
+    // A/B knob GLASS_DEEP: 0 = round 2's one-stage prefetch distance, 1 = patch three stages ahead, 2 = + two weight register sets (stride 2)
+    static const int deep_on = getenv("GLASS_DEEP") ? atoi(getenv("GLASS_DEEP")) : 1;
     if (p.y32 || !p.y) return nullptr;
     if (p.trgb_yout) {   // fused toRGB: only where one workgroup holds every output channel of its pixels
         if (!p.trgb_tab || !p.trgb_b || p.up || p.KS != 3 || p.stride != 1 || p.pad != 1 || p.no_tstore || p.Neff != 64 || p.Cout != 64 ||
             p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || (p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16) ||
             (p.x_bstride == 0 && p.B > 1) || (long long)p.H * p.W * p.Cin >= (1LL << 31))
             return nullptr;
+        if (deep_on) return launch_inst<3, 1, 8, 64, false, true, false, false, false, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,torgb,deep>");
         return launch_inst<3, 1, 8, 64, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,torgb>");
     }
     if (p.xs_out) {   // blur-down of the input as a by-product: un-transformed input, every chunk staged exactly once per pixel tile
@@ -553,6 +585,7 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
             p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || p.trgb_yout || (p.x_bstride == 0 && p.B > 1) ||
             (long long)p.H * p.W * p.Cin >= (1LL << 31))
             return nullptr;
+        if (deep_on) return launch_inst<3, 1, 8, 64, false, false, false, true, false, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,xs,deep>");
         return launch_inst<3, 1, 8, 64, false, false, false, true>(p, st, "conv_tiled_kernel<3,1,8,64,xs>");
     }
     if ((p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16)) return nullptr;   // fp16 tables not provided: direct path
@@ -579,6 +612,8 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
             (p.Cout & 7) || p.no_tstore || p.Hc % 4 != 0)
             return nullptr;
         static const bool spl = getenv("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
+        if (spl && deep_on == 2 && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,b2,deep>");
+        if (spl && deep_on && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,deep>");
         if (spl && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl>");
         if (p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip>");
         if (p.Neff % 64 == 0) return launch_inst<3, 2, 4, 64, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,64,skip>");
