@@ -18,9 +18,16 @@
 // Epilogue contract identical to conv_direct.hip (demod, noise, bias, lrelu, residual).
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 #define ROWB 80  // bytes per LDS row (32 halfs + 8 pad)
+
+// dev tool (GLASS_TILED_TRACE=path): shader-clock stamps of the K stages of ONE workgroup in the middle of the grid (TR instance only)
+__device__ unsigned long long* g_tiled_trace = nullptr;
+#define TTRACE(ph) \
+    if (TR && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0 && s < 64) \
+        g_tiled_trace[(s * 8 + (ph)) * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime()
 
 // PERSIST: the block walks several work items and prefetches the first stage of the next tile during
 // the last MFMA block + store epilogue of the current one (memory-bound small-K layers); otherwise
@@ -36,7 +43,7 @@
 // B2: the weight slices alternate between TWO register sets and are requested two stages ahead (costs NB * 4 VGPRs).
 // DEEP: the next chunk's patch is requested as soon as this chunk's patch is in LDS (three stages ahead instead of one).
 template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false, bool B2 = false,
-          bool DEEP = false>
+          bool DEEP = false, bool TR = false>
 __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void conv_tiled_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int RW = SPL ? TH / 2 : TH / 4;  // tile rows per wave
     constexpr int NJ = SPL ? NT / 64 : NT / 32; // 32-wide n tiles per wave
@@ -213,10 +220,14 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
 
         int c = 0, ty = 0;
         auto stage = [&](int s, h8 (&RBc)[NB], h8 (&RBo)[NB]) {   // RBc: the set this stage stores from; RBo: the other one
+            TTRACE(0);
             __syncthreads();  // previous stage's (or previous tile's) fragment reads are done
+            TTRACE(1);
             if (ty == 0) store_a();
             store_b(RBc);
+            TTRACE(2);
             __syncthreads();
+            TTRACE(3);
             if (XS && ty == 0) {
                 // the 8 x 32 tile of this 32-channel chunk (+ halo, zeros outside the image) sits in LDS: its 4 x 16 down-sampled
                 // pixels are 16 reads + 5 packed-fp16 FIRs per thread, and the separate blur-down pass (a full read of the map) goes
@@ -259,6 +270,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                 load_a(0);
                 load_b(RBo, 0, 0);
             }
+            TTRACE(4);
             // ---- MFMA block: KS taps x 2 k16 steps x RW x NJ --------------------------------
 #pragma unroll
             for (int tx = 0; tx < KS; ++tx) {
@@ -278,6 +290,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                     }
                 }
             }
+            TTRACE(5);
             c = nc;
             ty = nty;
         };
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
     }
 }
 
-template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false, bool B2 = false, bool DEEP = false>
+template <int KS, int S, int TH, int NT, bool PERSIST = false, bool TRGB = false, bool SKIP = false, bool XS = false, bool SPL = false, bool B2 = false, bool DEEP = false, bool TR = false>
 static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* name) {
     constexpr int PH = (TH - 1) * S + KS, PW = 31 * S + KS;
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
@@ -539,7 +552,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
     static DevOnce once;                       // (one per template instance)
     if (once.first() && LDS > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>,
+        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
@@ -552,7 +565,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
         static int per_cu_cache = 0;           // occupancy is a property of the kernel + architecture; the CU count is per device
         if (!per_cu_cache) {
             int per_cu = 1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>, 256, LDS);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>, 256, LDS);
             per_cu_cache = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
         }
         resident = glass_cu_count() * per_cu_cache;
@@ -561,7 +574,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     const int n_work = PT8 * NTn;
     const int grid = n_work < resident ? n_work : resident;
     if (p.dry_run) return name;
-    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
+    hipLaunchKernelGGL((conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>), dim3(grid), dim3(256), LDS, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
 }
 
@@ -613,6 +626,30 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
             return nullptr;
         static const bool spl = getenv("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
         if (spl && deep_on == 2 && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,b2,deep>");
+        if (const char* tp = getenv("GLASS_TILED_TRACE")) {      // dev tool: traced instance, stamps of one mid-grid workgroup to a file
+            if (spl && p.Neff % 128 == 0 && !p.dry_run) {
+                unsigned long long* dtr = nullptr;
+                (void)hipMalloc(&dtr, 64 * 8 * 4 * sizeof(unsigned long long));
+                (void)hipMemset(dtr, 0, 64 * 8 * 4 * sizeof(unsigned long long));
+                (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tiled_trace), &dtr, sizeof dtr);
+                const char* nm = launch_inst<3, 2, 4, 128, false, false, true, false, true, false, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,deep,trace>");
+                static unsigned long long hb[64 * 8 * 4];
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(hb, dtr, sizeof hb, hipMemcpyDeviceToHost);
+                (void)hipFree(dtr);
+                if (FILE* f = fopen(tp, "a")) {
+                    fprintf(f, "# %s Cin=%d Cout=%d Hc=%d: stage phase t[wave0..3]; phases 0 top, 1 after barrier, 2 operands stored, 3 after barrier, 4 loads issued, 5 MFMAs done\n", nm, p.Cin, p.Cout, p.Hc);
+                    for (int i = 0; i < 64; ++i)
+                        for (int ph = 0; ph < 6; ++ph) {
+                            fprintf(f, "%d %d", i, ph);
+                            for (int w = 0; w < 4; ++w) fprintf(f, " %llu", hb[(i * 8 + ph) * 4 + w] ? hb[(i * 8 + ph) * 4 + w] - hb[0] : 0ULL);
+                            fprintf(f, "\n");
+                        }
+                    fclose(f);
+                }
+                return nm;
+            }
+        }
         if (spl && deep_on && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,deep>");
         if (spl && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl>");
         if (p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip>");
