@@ -223,8 +223,13 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
             TTRACE(0);
             __syncthreads();  // previous stage's (or previous tile's) fragment reads are done
             TTRACE(1);
+            if (TR) {                         // traced instance only: split "operands landed" from "operands written to LDS"
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TTRACE(6);
+            }
             if (ty == 0) store_a();
             store_b(RBc);
+            if (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             TTRACE(2);
             __syncthreads();
             TTRACE(3);
@@ -624,6 +629,8 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
         if (KS != 3 || S != 2 || p.pad != 0 || !p.skip_w || p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.up ||
             (p.Cout & 7) || p.no_tstore || p.Hc % 4 != 0)
             return nullptr;
+        if (!getenv("GLASS_TILED_TRACE"))
+            if (const char* k = launch_conv_s2(p, st)) return k;        // LDS-DMA ring kernel where its geometry applies
         static const bool spl = getenv("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
         if (spl && deep_on == 2 && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,b2,deep>");
         if (const char* tp = getenv("GLASS_TILED_TRACE")) {      // dev tool: traced instance, stamps of one mid-grid workgroup to a file
@@ -638,9 +645,9 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
                 (void)hipMemcpy(hb, dtr, sizeof hb, hipMemcpyDeviceToHost);
                 (void)hipFree(dtr);
                 if (FILE* f = fopen(tp, "a")) {
-                    fprintf(f, "# %s Cin=%d Cout=%d Hc=%d: stage phase t[wave0..3]; phases 0 top, 1 after barrier, 2 operands stored, 3 after barrier, 4 loads issued, 5 MFMAs done\n", nm, p.Cin, p.Cout, p.Hc);
+                    fprintf(f, "# %s Cin=%d Cout=%d Hc=%d: stage phase t[wave0..3]; phases 0 top, 1 after barrier, 2 operands stored, 3 after barrier, 4 loads issued, 5 MFMAs done, 6 operands landed (between 1 and 2)\n", nm, p.Cin, p.Cout, p.Hc);
                     for (int i = 0; i < 64; ++i)
-                        for (int ph = 0; ph < 6; ++ph) {
+                        for (int ph = 0; ph < 7; ++ph) {
                             fprintf(f, "%d %d", i, ph);
                             for (int w = 0; w < 4; ++w) fprintf(f, " %llu", hb[(i * 8 + ph) * 4 + w] ? hb[(i * 8 + ph) * 4 + w] - hb[0] : 0ULL);
                             fprintf(f, "\n");

@@ -15,6 +15,8 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
 bool conv_stream_applies(const ConvParams& p);   // trgb_yout set: the fused conv + toRGB form
 // LDS-DMA staged 3x3 conv for the MFMA-bound mid-resolution layers (conv_glds.hip); nullptr when unsupported / disabled
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force = false);
+// conv_s2.hip: the D blocks' stride-2 3x3 conv + fused 1x1 skip branch on an LDS-DMA ring (nullptr: not applicable -> conv_tiled)
+const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force = false);
 // second half of the full-resolution discriminator block in one kernel (conv_down.hip):
 //   y = (lrelu(conv3x3 stride 2 (fir_pad2(h)) + b1) * sqrt2 + conv1x1(xs)) / sqrt2, xs = fir_pad1(x)[::2] (32 -> 64 channels);
 // nullptr when the shape does not qualify (caller runs the separate passes)

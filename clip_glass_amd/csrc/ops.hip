@@ -105,7 +105,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     p.y = y;
     OPREQ(p.x && p.w && y, "device allocation failed");
     if (d->skip_x) {
-        OPREQ(d->skip_w && d->impl == 2, "fused skip branch: impl 2 with skip_x and skip_w");
+        OPREQ(d->skip_w && (d->impl == 2 || d->impl == 5), "fused skip branch: impl 2 / 5 with skip_x and skip_w");
         std::vector<_Float16> pks;
         glass_pack_conv(d->skip_w, d->Cout, d->Cin, 1, d->Cin, pks);
         p.skip_w = dv.up16v(pks);
@@ -150,7 +150,9 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         float* wc = dv.alloc<float>((size_t)(cap_c * p.B));
         if (!launch_conv_gemm(p, wa, cap_a, wc, cap_c, 0)) { glass_set_error("im2col + GEMM conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (d->impl == 5) {
-        if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }
+        if (p.skip_x) {
+            if (!launch_conv_s2(p, 0, true)) { glass_set_error("LDS-DMA stride-2 conv: unsupported shape"); return GLASS_ERR_ARG; }
+        } else if (!launch_conv_glds(p, 0, true)) { glass_set_error("LDS-DMA conv: unsupported shape"); return GLASS_ERR_ARG; }
     } else if (!(d->up && launch_upconv_fused(p, 0)) && !launch_conv_stream(p, 0) && !launch_conv_tiled(p, 0) && !launch_conv_direct(p, 0)) {
         glass_set_error("no kernel accepts this convolution");
         return GLASS_ERR_ARG;

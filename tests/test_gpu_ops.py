@@ -126,26 +126,42 @@ def test_conv_stream_fused_torgb(with_skip):
     check("conv_stream<torgb>", got, ref, 2e-5)
 
 
-@pytest.mark.parametrize("B,R,Cin,Cout", [(2, 64, 64, 128), (3, 64, 32, 64), (1, 128, 128, 256)])
-def test_conv_stride2_fused_skip(B, R, Cin, Cout):
-    """conv_tiled<3,2,4,N,skip>: the D block's skip branch (modules.py:1238-1254) as extra K stages after the in-register
-    activation, against the two-pass form (1x1 conv, then the stride-2 conv with it as the residual)."""
+def _stride2_skip_case(B, R, Cin, Cout, impl, label):
     rng = np.random.default_rng(17)
     hb = rng.standard_normal((B, R + 1, R + 1, Cin)).astype(np.float16).astype(np.float32)       # blurred (pad 2) conv0 output
     xs = rng.standard_normal((B, R // 2, R // 2, Cin)).astype(np.float16).astype(np.float32)     # down-sampled block input
     w1 = rng.standard_normal((Cout, Cin, 3, 3)).astype(np.float32)     # un-scaled: the runtime coefficient is applied at packing
     ws = rng.standard_normal((Cout, Cin, 1, 1)).astype(np.float32)
     b1 = rng.standard_normal(Cout).astype(np.float32) * 0.2
-    kw = dict(stride=2, pad=0, bias=b1, act=True, out_scale=2.0 ** -0.5, impl=2)
-    got = ops.conv(hb, w1, skip=(xs, ws), **kw)
+    kw = dict(stride=2, pad=0, bias=b1, act=True, out_scale=2.0 ** -0.5)
+    got = ops.conv(hb, w1, skip=(xs, ws), impl=impl, **kw)
     s = ops.conv(xs, ws, pad=0, impl=2)
-    ref2 = ops.conv(hb, w1, res=s, **kw)
+    ref2 = ops.conv(hb, w1, res=s, impl=2, **kw)
     t = lambda a: torch.tensor(np.ascontiguousarray(a.transpose(0, 3, 1, 2)), dtype=torch.float64)
     w1s = torch.tensor(w1 / math.sqrt(9 * Cin)).half().double(); wss = torch.tensor(ws / math.sqrt(Cin)).half().double()
     y = F.leaky_relu(F.conv2d(t(hb), w1s, torch.tensor(b1, dtype=torch.float64), stride=2), 0.2) * math.sqrt(2)
     ref = ((y + F.conv2d(t(xs), wss)) * 2.0 ** -0.5).numpy().transpose(0, 2, 3, 1)
-    check("stride-2 conv + fused skip vs float64", got, ref, 2e-3)
-    check("stride-2 conv + fused skip vs two passes", got, ref2, 3e-3)
+    check(label + " vs float64", got, ref, 2e-3)
+    check(label + " vs two passes", got, ref2, 3e-3)
+
+
+@pytest.mark.parametrize("B,R,Cin,Cout", [(2, 64, 64, 128), (3, 64, 32, 64), (1, 128, 128, 256)])
+def test_conv_stride2_fused_skip(B, R, Cin, Cout):
+    """conv_tiled<3,2,4,N,skip>: the D block's skip branch (modules.py:1238-1254) as extra K stages after the in-register
+    activation, against float64 and the two-pass form (1x1 conv, then the stride-2 conv with it as the residual)."""
+    _stride2_skip_case(B, R, Cin, Cout, 2, "stride-2 conv + fused skip")
+
+
+@pytest.mark.parametrize("B,R,Cin,Cout", [(2, 64, 64, 128),       # 8 work items: one per workgroup, 2 chunks
+                                          (1, 64, 32, 256),       # one chunk: prologue -> tail with nothing in between
+                                          (1, 128, 128, 256),     # 32 items, 4 chunks
+                                          (37, 64, 96, 384),      # 148 pixel tiles (not a multiple of 8) x 3 n tiles > 256 workgroups: the ring
+                                                                  # runs on across items, uneven item counts per workgroup, 3 chunks
+                                          (3, 256, 64, 128)])     # 4 x 16 tiles per image
+def test_conv_s2_dma_ring(B, R, Cin, Cout):
+    """conv_s2.hip (LDS-DMA ring: row-parity halves, de-interleaved columns, skip branch as the fourth stage of every chunk) against
+    float64 and the two-pass form."""
+    _stride2_skip_case(B, R, Cin, Cout, 5, "conv_s2")
 
 
 @pytest.mark.parametrize("case", ["conv8", "up8", "down17", "skip1x1", "const4"])

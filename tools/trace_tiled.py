@@ -17,11 +17,12 @@ for blk in blocks:
     lines = blk.strip().split("\n")
     print(lines[0][:90])
     a = np.array([[int(v) for v in l.split()] for l in lines[1:]], dtype=np.float64)
-    T = a[:, 2:].reshape(-1, 6, 4)
+    T = a[:, 2:].reshape(-1, 7, 4)
     n = int((T[:, 5, 0] > 0).sum())
     for w_ in range(4):
+        print("  wave", w_, "operand wait=%.0f  LDS writes=%.0f" % ((T[1:n, 6, w_] - T[1:n, 1, w_]).mean(), (T[1:n, 2, w_] - T[1:n, 6, w_]).mean()))
         d = [(T[1:n, ph + 1, w_] - T[1:n, ph, w_]).mean() for ph in range(5)]
         gap = (T[2:n, 0, w_] - T[1:n - 1, 5, w_]).mean()
         print("  wave", w_, " ".join("%s=%.0f" % (nm, v) for nm, v in zip(names, d)), "next=%.0f" % gap, "stage=%.0f cycles over %d stages" % (sum(d) + gap, n - 1))
     for st in range(min(n, 7)):
-        print("   stage", st, "wave0 phases:", " ".join("%.0f" % (T[st, ph, 0] - T[st, 0, 0]) for ph in range(6)))
+        print("   stage", st, "wave0 phases:", " ".join("%.0f" % (T[st, ph, 0] - T[st, 0, 0]) for ph in (0, 1, 6, 2, 3, 4, 5)))
