@@ -25,7 +25,14 @@
 // The input of this layer is never padded (pad 0: a (2 Ho + 1)^2 blurred map), so there is no zero page.
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
+
+// dev tool (GLASS_S2_TRACE=path): shader-clock stamps of the first stages of ONE workgroup in the middle of the grid (TR instance only)
+__device__ unsigned long long* g_s2_trace = nullptr;
+#define S2TRACE(ph) \
+    if (TR && blockIdx.x == gridDim.x / 2 + 3 && (threadIdx.x & 63) == 0 && gst < 96) \
+        g_s2_trace[(gst * 8 + (ph)) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime()
 
 namespace {
 constexpr int NT = 128, NTHR = 512, TH = 8;
@@ -51,6 +58,7 @@ __device__ __forceinline__ int opq(int v) { asm volatile("" : "+v"(v)); return v
 #define S2_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 }  // namespace
 
+template <bool TR, bool IL>
 __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -131,38 +139,39 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
         s.ws = p.skip_w + (long long)it.n0 * p.Cin;
         return s;
     };
-    auto issue_odd = [&](const Src& s, int c) {
-        char* dst = smem + OFF_ODD + wave * 1024;
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (k < na_o) {
-                if (o_src[k] >= 0) dma16(s.hb + o_src[k] + c * 32, dst + k * 8192);
-            }
+    // one DMA instruction (1 KB per wave) of each operand: k-th wave-round of a half / the skip operand / a weight slice
+    auto odd_piece = [&](const Src& s, int c, int k) {
+        if (k < na_o) {
+            if (o_src[k] >= 0) dma16(s.hb + o_src[k] + c * 32, smem + OFF_ODD + wave * 1024 + k * 8192);
+        }
     };
-    auto issue_even = [&](const Src& s, int c) {
-        char* dst = smem + OFF_EVEN + wave * 1024;
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (k < na_e) {
-                if (e_src[k] >= 0) dma16(s.hb + e_src[k] + c * 32, dst + k * 8192);
-            }
+    auto even_piece = [&](const Src& s, int c, int k) {
+        if (k < na_e) {
+            if (e_src[k] >= 0) dma16(s.hb + e_src[k] + c * 32, smem + OFF_EVEN + wave * 1024 + k * 8192);
+        }
     };
-    auto issue_xs = [&](const Src& s, int c) {
-        char* dst = smem + OFF_XS + wave * 1024;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) dma16(s.xs + x_src[k] + c * 32, dst + k * 8192);
-    };
-    // weight slice of stage (chunk c, phase f): f = 0, 1, 2 -> tap row ky = 1, 0, 2 (3 DMAs); f = 3 -> skip weights (1 DMA)
-    auto issue_w = [&](const Src& s, int c, int f, int slot) {
+    auto xs_piece = [&](const Src& s, int c, int k) { dma16(s.xs + x_src[k] + c * 32, smem + OFF_XS + wave * 1024 + k * 8192); };
+    // weight slice of stage (chunk c, phase f): f = 0, 1, 2 -> tap row ky = 1, 0, 2 (3 pieces); f = 3 -> skip weights (1 piece)
+    auto w_piece = [&](const Src& s, int c, int f, int slot, int k) {
         char* dst = smem + OFF_W + slot * W_SLOT + wave * 1024;
         if (f < 3) {
             const int ky = f == 0 ? 1 : (f == 1 ? 0 : 2);
-            const half_t* src = s.w + (long long)ky * 3 * p.Neff * p.Cin + c * 32;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dma16(src + w_src[k], dst + k * 8192);
+            dma16(s.w + (long long)ky * 3 * p.Neff * p.Cin + c * 32 + w_src[k], dst + k * 8192);
         } else {
             dma16(s.ws + ws_src + c * 32, dst);
         }
+    };
+    auto issue_odd = [&](const Src& s, int c) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) odd_piece(s, c, k);
+    };
+    auto issue_even = [&](const Src& s, int c) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) even_piece(s, c, k);
+    };
+    auto issue_w = [&](const Src& s, int c, int f, int slot) {
+#pragma unroll
+        for (int k = 0; k < (f < 3 ? 3 : 1); ++k) w_piece(s, c, f, slot, k);
     };
 
     // bias of every output channel -> LDS once (the n tile changes from item to item; a global load in the loop would make the
@@ -178,6 +187,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
     issue_odd(cs, 0);
     issue_even(cs, 0);
     issue_w(cs, 0, 1, 1);
+    int gst = 0;                                // (trace only) stages run so far
     int slot = 0;                               // weight slot of the stage about to run (stage g lives in slot g % 3)
     const int wr = wave & 3, wn = wave >> 2;
     for (;;) {
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
             const int nc = last_c ? 0 : c + 1;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
+                S2TRACE(0);
                 // s_waitcnt vmcnt(N), N = DMA instructions this wave issued AFTER the last operand of this stage (the counter retires in order):
                 if (f == 0) {                      // even(c) [na_e], W(g + 1) [3] behind odd(c) / W(g)
                     if (na_e == 5) S2_WAIT(8); else S2_WAIT(7);
@@ -212,19 +223,32 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                 } else {                           // W(g + 1) [3] behind the skip weights
                     if (more) S2_WAIT(3); else S2_WAIT(0);
                 }
+                S2TRACE(1);
                 __builtin_amdgcn_s_barrier();      // this stage's operands are visible to every wave; whatever stage g - 1 read is free
+                S2TRACE(2);
                 const int slot2 = slot == 0 ? 2 : slot - 1;          // (g + 2) % 3
-                if (f == 0) {
-                    issue_xs(cs, c);
-                    issue_w(cs, c, 2, slot2);
-                } else if (f == 1) {
-                    if (more) issue_odd(nsrc, nc);
-                    issue_w(cs, c, 3, slot2);
-                } else if (f == 2) {
-                    if (more) issue_w(nsrc, nc, 0, slot2);
-                } else {
-                    if (more) { issue_even(nsrc, nc); issue_w(nsrc, nc, 1, slot2); }
+                // the i-th DMA instruction of this stage (the order fixes the vmcnt counts above):
+                //   f = 0: skip operand(c) [2], W(g + 2) [3]        f = 1: odd(c + 1) [<= 5], skip weights [1]
+                //   f = 2: W(g + 2) [3]                              f = 3: even(c + 1) [<= 5], W(g + 2) [3]
+                auto piece = [&](int i) {
+                    if (f == 0) {
+                        if (i < 2) xs_piece(cs, c, i);
+                        else if (i < 5) w_piece(cs, c, 2, slot2, i - 2);
+                    } else if (f == 1) {
+                        if (i < 5) { if (more) odd_piece(nsrc, nc, i); }
+                        else if (i == 5) w_piece(cs, c, 3, slot2, 0);
+                    } else if (f == 2) {
+                        if (i < 3 && more) w_piece(nsrc, nc, 0, slot2, i);
+                    } else {
+                        if (i < 5) { if (more) even_piece(nsrc, nc, i); }
+                        else if (i < 8 && more) w_piece(nsrc, nc, 1, slot2, i - 5);
+                    }
+                };
+                if (!IL) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) piece(i);
                 }
+                S2TRACE(3);
                 // ---- MFMAs ---------------------------------------------------------------------------------------------------------
                 const int tm = opq(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
                 const char* Ws = smem + OFF_W + slot * W_SLOT;
@@ -242,16 +266,23 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                                 const int row = tx * NT + (wn * 2 + j) * 32 + lr;
                                 wf[j] = *(const h8*)(Ws + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
                             }
+                            h8 xf[2];
 #pragma unroll
                             for (int i = 0; i < 2; ++i) {
                                 const int r = wr * 2 + i;                                    // output row of the tile
                                 const int prow = ky == 1 ? r : r + (ky >> 1);                // row of the half: input row 2 r + ky
                                 const int q = (tx & 1) ? 33 + lr : lr + (tx >> 1);           // de-interleaved column of input column 2 lr + tx
                                 const int P = prow * PXR + q;
-                                const h8 xf = *(const h8*)(As + P * 64 + ((lc ^ ((P >> 2) & 3)) << 4));
-#pragma unroll
-                                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                                xf[i] = *(const h8*)(As + P * 64 + ((lc ^ ((P >> 2) & 3)) << 4));
                             }
+                            if (IL) {               // one DMA instruction per block of 4 MFMAs: its issue cost hides under the MFMAs in flight
+                                piece(tx * 2 + kk);
+                                if (tx == 2 && kk == 1) { piece(6); piece(7); }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(wf[j], xf[i], acc[i][j]);
                         }
                     }
                 } else {
@@ -265,15 +296,24 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                             const int row = (wn * 2 + j) * 32 + lr;
                             wf[j] = *(const h8*)(Ws + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
                         }
+                        h8 xf[2];
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             const int P = (wr * 2 + i) * 32 + lr;
-                            const h8 xf = *(const h8*)(Xs + P * 64 + ((lc ^ ((P >> 2) & 3)) << 4));
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) acs[i][j] = mfma32(wf[j], xf, acs[i][j]);
+                            xf[i] = *(const h8*)(Xs + P * 64 + ((lc ^ ((P >> 2) & 3)) << 4));
                         }
+                        if (IL) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) piece(kk * 4 + i);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) acs[i][j] = mfma32(wf[j], xf[i], acs[i][j]);
                     }
                 }
+                S2TRACE(4);
+                if (TR) ++gst;
                 slot = slot == 2 ? 0 : slot + 1;
             }
         }
@@ -285,6 +325,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
             const int t = opq(threadIdx.x), lane = t & 63, lr = lane & 31, kh = lane >> 5;
             const float* Cc = (const float*)(smem + OFF_C) + n0;
             __builtin_amdgcn_s_barrier();          // every wave is done with the skip operand buffer (its LDS reads have returned)
+            if (TR) { --gst; S2TRACE(5); }
             char* Os = smem + OFF_XS + wave * 2048;
             const ActK ak = act_consts(p.act, p.out_scale);
             const int oyb = ty0 + wr * 2;
@@ -314,12 +355,22 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                 }
             }
         }
+        if (TR) { S2TRACE(6); ++gst; }
         if (!has_next) break;
         id = nid;
         cur = nxt;
         cs = ns;
     }
 }
+
+// Tried and dropped (round 3, same-box A/B on the four D layers; tools/trace_s2.py stamps): a two-stage version — skip + ky 1 /
+// ky 0 + ky 2, weights double-buffered as 32 + 48 KB, the skip operand loaded straight into registers, fragment reads software-pipelined
+// one MFMA block ahead — was 3-6 % SLOWER (3.09 vs 2.92 ms): half the barriers, but one stage of DMA lead instead of two, and the waits
+// at the stage tops grew by what the barriers saved.  Bunching a stage's DMA instructions at its front is worse again (+4 %): eight waves'
+// pieces queue behind each other.  What bounds both: per 32-channel chunk a workgroup moves 166 KB L2 -> LDS (21 DMA instructions per
+// wave, 100-185 cycles of issue each beside MFMAs) and reads 640 KB of fragments back (one ds_read_b128 per MFMA at 2 x 2 register
+// blocking: 2560 LDS cycles) for 5120 MFMA cycles per SIMD — the three pipes are within 2x of each other, so ~45 % of the MFMA rate is
+// what this tile shape gives; a bigger tile does not fit 160 KB of LDS / 256 registers.
 
 const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
     static const bool off = getenv("GLASS_NO_S2DMA") != nullptr;      // A/B knob: the register-staged conv_tiled<3,2,4,128,skip> instead
@@ -338,7 +389,39 @@ const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
     const int grid = n_work < n_cu ? n_work : n_cu;                     // (n_work is a multiple of 8)
     if (p.dry_run) return "conv_s2_kernel";
     static DevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)conv_s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    hipLaunchKernelGGL(conv_s2_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_s2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    }
+    if (const char* tp = getenv("GLASS_S2_TRACE")) {          // dev tool: traced instance, stamps to a file
+        unsigned long long* dtr = nullptr;
+        constexpr int NTR = 96 * 8 * 8;
+        (void)hipMalloc(&dtr, NTR * sizeof(unsigned long long));
+        (void)hipMemset(dtr, 0, NTR * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s2_trace), &dtr, sizeof dtr);
+        hipLaunchKernelGGL((conv_s2_kernel<true, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+        static unsigned long long hb[NTR];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hb, dtr, sizeof hb, hipMemcpyDeviceToHost);
+        (void)hipFree(dtr);
+        if (FILE* f = fopen(tp, "a")) {
+            fprintf(f, "# conv_s2_kernel<trace> Cin=%d Cout=%d Hc=%d B=%d: stage phase t[wave0..7]; phases 0 top, 1 operands landed, 2 after barrier, 3 DMAs issued, 4 MFMAs done, 5 epilogue barrier, 6 epilogue done\n", p.Cin, p.Cout, p.Hc, p.B);
+            for (int i = 0; i < 96; ++i)
+                for (int ph = 0; ph < 7; ++ph) {
+                    fprintf(f, "%d %d", i, ph);
+                    for (int w = 0; w < 8; ++w) fprintf(f, " %llu", hb[(i * 8 + ph) * 8 + w] ? hb[(i * 8 + ph) * 8 + w] - hb[0] : 0ULL);
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
+        return "conv_s2_kernel<trace>";
+    }
+    static const bool no_il = getenv("GLASS_S2_NO_IL") != nullptr;     // A/B knob: every DMA of a stage issued before its MFMAs
+    if (no_il) {
+        hipLaunchKernelGGL((conv_s2_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+        return "conv_s2_kernel<noil>";
+    }
+    hipLaunchKernelGGL((conv_s2_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
     return "conv_s2_kernel";
 }
