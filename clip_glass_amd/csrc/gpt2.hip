@@ -69,22 +69,40 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* A, const flo
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     const int kc = gridDim.z > 1 ? ((K / F32_BK + gridDim.z - 1) / gridDim.z) * F32_BK : K;    // K slice of this block
     const int k_lo = blockIdx.z * kc, k_hi = min(K, k_lo + kc);
-    for (int k0 = k_lo; k0 < k_hi; k0 += F32_BK) {
-        for (int e = t; e < BM * 8; e += 256) {   // stage BM x 32 of A (coalesced along k), zero-filled outside
-            const int row = e >> 3, c4 = (e & 7) * 4;
-            f4 va = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + row < M && k0 + c4 < k_hi) va = *(const f4*)(A + (long long)(m0 + row) * lda + k0 + c4);
+    // the next K step's operand vectors are requested before this step's MFMAs (register prefetch): a step used to start with a full
+    // L2 / HBM round trip in front of 2-4 us of fp32 MFMAs
+    constexpr int NVA = BM * 8 / 256, NVW = BN * 8 / 256;
+    f4 ra[NVA], rw[NVW];
+    auto load = [&](int k0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) As[row][c4 + j] = va[j];
+        for (int i = 0; i < NVA; ++i) {
+            const int e = i * 256 + t, row = e >> 3, c4 = (e & 7) * 4;
+            ra[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (m0 + row < M && k0 + c4 < k_hi) ra[i] = *(const f4*)(A + (long long)(m0 + row) * lda + k0 + c4);
         }
-        for (int e = t; e < BN * 8; e += 256) {
-            const int row = e >> 3, c4 = (e & 7) * 4;
-            f4 vw = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + row < N && k0 + c4 < k_hi) vw = *(const f4*)(W + (long long)(n0 + row) * K + k0 + c4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Ws[row][c4 + j] = vw[j];
+        for (int i = 0; i < NVW; ++i) {
+            const int e = i * 256 + t, row = e >> 3, c4 = (e & 7) * 4;
+            rw[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (n0 + row < N && k0 + c4 < k_hi) rw[i] = *(const f4*)(W + (long long)(n0 + row) * K + k0 + c4);
+        }
+    };
+    load(k_lo);
+    for (int k0 = k_lo; k0 < k_hi; k0 += F32_BK) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) {
+            const int e = i * 256 + t, row = e >> 3, c4 = (e & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) As[row][c4 + j] = ra[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < NVW; ++i) {
+            const int e = i * 256 + t, row = e >> 3, c4 = (e & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Ws[row][c4 + j] = rw[i][j];
         }
         __syncthreads();
+        if (k0 + F32_BK < k_hi) load(k0 + F32_BK);
 #pragma unroll
         for (int kk = 0; kk < F32_BK; kk += 2) {
             float wf[TJ], xf[TI];
@@ -144,9 +162,117 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
     }
     out[oi] = v;
 }
+// ---- single-token steps (M <= 64 rows): weight-streaming form ------------------------------------------------------------------------
+// Round 3 (rocprofv3 of `bench.py --config gpt2`): the decode steps' 4266 launches of gemm_f32_kernel<64,64> averaged 18.6 us — 44 % of
+// the whole C5 step — for 0.4-9 MB of weights each: scalar LDS staging of BOTH operands, two barriers per 32-deep K step, no load in
+// flight across them, and 64 fp32 MFMAs (64 cycles each) in a row per wave and K step.  Here neither operand touches LDS: a wave owns a
+// 32 (rows m) x 32 (columns n) output block over a K part and reads BOTH fragments straight from global memory in MFMA layout — lane
+// (lr, kh) loads 16 bytes = four consecutive k of ITS row (activation row m0 + lr / weight row n0 + lr): k = 8 b + 4 kh + s feeds MFMA
+// step (b, s); the K order of an MFMA is free as long as both operands use the same one.  A 64-deep chunk (8 + 8 loads per lane) is
+// requested one chunk ahead of its 32 MFMAs; no barrier in the K loop.  A workgroup = one 32-column block x (2 row blocks x NK K parts)
+// waves, so the fp32 MFMA work (the floor of these steps: 15.9 GFLOP at 157 TFLOP/s) spreads over every SIMD while the global split-K
+// factor (part[z][M][N], fixed-order sum in splitk_reduce_kernel) stays small; the NK partial blocks meet through LDS in a fixed order.
+// Operands are ordered (a = activations, b = weights): a lane holds ONE column n for rows m = mfma32_row, stores are coalesced along n.
+#define GS_KC 64
+template <int NK>
+__global__ __launch_bounds__(128 * NK) void gemm_f32_stream_kernel(const float* A, const float* W, const float* bias, float* out, int M, int N,
+                                                                   int K, int lda, int ldo, int mode, float* part, int kslice) {
+    __shared__ float Rs[NK > 1 ? NK - 1 : 1][2][16][64];     // partial blocks of K parts 1 .. NK-1
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+    const int mi = wave & 1, kp = wave >> 1;
+    const int n0 = blockIdx.x * 32;
+    const int kpart = kslice / NK, k_lo = blockIdx.y * kslice + kp * kpart, n_ch = kpart / GS_KC;
+    const float* wrow = W + (long long)min(n0 + lr, N - 1) * K + k_lo + 4 * kh;          // rows past N / M re-read the last row (never stored)
+    const float* xrow = A + (long long)min(mi * 32 + lr, M - 1) * lda + k_lo + 4 * kh;
+    f4 wr[2][8], xr[2][8];
+    auto load = [&](int c, int set) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+            xr[set][b] = *(const f4*)(xrow + c * GS_KC + 8 * b);
+        }
+    };
+    f16x acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    load(0, 0);
+    auto chunk = [&](int c, int set) {            // set = c & 1, a compile-time constant at both call sites
+        if (c + 1 < n_ch) load(c + 1, set ^ 1);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[set][b][s2], wr[set][b][s2], acc, 0, 0, 0);   // D[m][n]
+    };
+    for (int c = 0; c < n_ch; c += 2) {
+        chunk(c, 0);
+        if (c + 1 < n_ch) chunk(c + 1, 1);
+    }
+    if (NK > 1) {                                  // K parts 1 .. NK-1 hand their blocks to part 0, which adds them in order
+        if (kp > 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) Rs[kp - 1][mi][q][lane] = acc[q];
+        }
+        __syncthreads();
+        if (kp > 0) return;
+#pragma unroll
+        for (int z = 0; z < NK - 1; ++z)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += Rs[z][mi][q][lane];
+    }
+    const int n = n0 + lr;
+    if (n >= N) return;
+    const float bv = (bias && gridDim.y == 1) ? bias[n] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = mi * 32 + mfma32_row(reg, lane);
+        if (m >= M) continue;
+        if (gridDim.y > 1) {
+            part[((long long)blockIdx.y * M + m) * N + n] = acc[reg];
+            continue;
+        }
+        float v = acc[reg] + bv;
+        const long long oi = (long long)m * ldo + n;
+        if (mode == 1) {
+            const float c = 0.7978845608028654f;  // sqrt(2/pi)
+            v = 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
+        } else if (mode == 2) {
+            v += out[oi];
+        }
+        out[oi] = v;
+    }
+}
+template <int NK>
+static void launch_stream_inst(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
+                               hipStream_t st, float* part, int S) {
+    hipLaunchKernelGGL((gemm_f32_stream_kernel<NK>), dim3((N + 31) / 32, S), dim3(128 * NK), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part,
+                       K / S);
+}
+
 // `part`: scratch for split-K partial sums (nullable = never split); sized by the caller for GPT2_SPLITK_MAX slices of M x N.
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
                      int mode, hipStream_t st, float* part, size_t part_elems) {
+    static const bool no_stream = getenv("GLASS_GPT2_NO_STREAM") != nullptr;      // A/B knob: round 2's gemm_f32_kernel<64,64> for the steps
+    if (M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && !no_stream) {
+        // a workgroup per 32 weight rows; global K split S (small: the partial sums are traffic) x NK K parts inside the workgroup so
+        // that a wave's share is one or two 64-deep chunks; the vocabulary projection (1571 workgroups) is not split globally
+        const int nb = (N + 31) / 32;
+        int S = 1, NK = 1;
+        static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+        for (int c : cand) {
+            if (K % (c * GS_KC) != 0 || (c > 1 && (!part || (size_t)c * M * N > part_elems || nb >= 1024))) continue;
+            S = c;
+            const int ks = K / c;
+            NK = ks % (4 * GS_KC) == 0 ? 4 : (ks % (2 * GS_KC) == 0 ? 2 : 1);
+            if (nb * c >= 200 && ks / NK <= 2 * GS_KC) break;
+        }
+        if (NK == 4) launch_stream_inst<4>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S);
+        else if (NK == 2) launch_stream_inst<2>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S);
+        else launch_stream_inst<1>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S);
+        if (S > 1)
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out,
+                               M, N, ldo, mode);
+        return;
+    }
     if (M <= 64) {
         // single-token steps stream each weight once: what matters is how many workgroups pull on HBM.  N / 64 column tiles
         // alone are 12 workgroups at N = 768: split K until ~256 workgroups are live.
@@ -160,6 +286,10 @@ void launch_gemm_f32(const float* A, const float* W, const float* bias, float* o
         if (S > 1)
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out,
                                M, N, ldo, mode);
+    } else if (((M + 127) / 128) * ((N + 127) / 128) < 200) {
+        // prefill with a narrow output (N = 768: 72 tiles of 128 x 128 for 256 CUs): 64 x 64 tiles fill the chip
+        dim3 g((M + 63) / 64, (N + 63) / 64, 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
     } else {
         dim3 g((M + 127) / 128, (N + 127) / 128, 1);
         hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
