@@ -139,7 +139,7 @@ def bench_gpt2(args):
                config=dict(workload="GPT2: GPT-2-small greedy decode (23-token context, 30 steps, fp32, KV cache, one hipGraph per single-"
                                     "token step) + CLIP ViT-B/32 text tower + cosine, pop=%d; host BPE round trip replaced by a fixed id "
                                     "mapping (no vocabulary files on the box)" % P, pop_per_gpu=P, device=device_info(0)["name"]),
-               roofline=dict(bound="hbm", kernel="gemm_f32_kernel<64,64> (weight streaming, 30 steps)", achieved=gbs, peak=HBM_PEAK_GBS,
+               roofline=dict(bound="hbm", kernel="gemm_f32_stream_kernel / gpt2_head_kernel (weight streaming, 30 steps)", achieved=gbs, peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None, decode_ms_per_population=dec_ms / args.steps,
                              algorithmic_bytes_per_decode=bytes_per_decode))
     print(json.dumps(out))

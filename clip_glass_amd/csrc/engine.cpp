@@ -1525,7 +1525,7 @@ static void gpt2_work_free(glass_engine* e) {
     if (w.exec) hipGraphExecDestroy(w.exec);
     if (w.graph) hipGraphDestroy(w.graph);
     hipFree(w.d_tok); hipFree(w.d_gen); hipFree(w.d_state); hipFree(w.x); hipFree(w.ln); hipFree(w.qkv); hipFree(w.att); hipFree(w.hid);
-    hipFree(w.last); hipFree(w.logits); hipFree(w.kc); hipFree(w.vc); hipFree(w.part);
+    hipFree(w.last); hipFree(w.logits); hipFree(w.kc); hipFree(w.vc); hipFree(w.part); hipFree(w.stats); hipFree(w.pairs);
     w = glass_engine::Gpt2Work();
 }
 
@@ -1561,6 +1561,8 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
         if (err == hipSuccess) err = hipMalloc(&w.kc, (size_t)nl * P * Tmax * D * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.vc, (size_t)nl * P * Tmax * D * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.part, w.part_elems * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.pairs, (size_t)2 * P * ((V + 31) / 32) * sizeof(float));   // (max, index) per (row, 32-column block)
+        if (err == hipSuccess) err = hipMalloc(&w.stats, (size_t)P * (2 + 2 * 32) * sizeof(float));   // + the two-stage arg-max's (value, index) pairs
         if (err != hipSuccess) {
             gpt2_work_free(e);
             glass_set_error(std::string("gpt2_decode: hipMalloc failed: ") + hipGetErrorString(err));
@@ -1570,10 +1572,42 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
     }
     // one transformer pass over `nd` new positions per sequence; step_state != nullptr: single-token step whose past length /
     // step index are read from device memory (the form that is captured into a hipGraph and replayed)
+    // single-token steps, fused form (round 3; A/B knob GLASS_GPT2_NO_FUSE): LayerNorm applied on the activation operand of the next
+    // product from row statistics, products with complete outputs (no split-K reduce launch) except the MLP's second one, whose
+    // split-K slices of the residual products finished together with the residual add and the next statistics: 9 launches per layer
+    // instead of 11 (complete-output products — 72 / 24 / 96 workgroups walking three chunks each — were 21 us against 9 + 4: dropped)
+    static const bool no_fuse = getenv("GLASS_GPT2_NO_FUSE") != nullptr;
+    const bool fuse_ok = !no_fuse && P <= 64 && D % 64 == 0 && D <= 1024;
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
         if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st);
         else launch_gpt2_embed(w.d_tok, e->g_wte, e->g_wpe, M, nd, past, D, w.x, st);
+        if (step_state && fuse_ok) {
+            launch_gpt2_finalize(nullptr, 0, nullptr, w.x, P, D, w.stats, st);
+            for (int l = 0; l < nl; ++l) {
+                const auto& b = e->gblk[l];
+                float* kcl = w.kc + (size_t)l * P * Tmax * D;
+                float* vcl = w.vc + (size_t)l * P * Tmax * D;
+                int S = launch_gemm_f32_step(w.x, b.w_qkv, b.b_qkv, w.qkv, P, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems, w.stats, b.ln1_g, b.ln1_b);
+                if (S > 1) launch_gpt2_reduce(w.part, S, b.b_qkv, w.qkv, P, 3 * D, 3 * D, 0, st);
+                launch_gpt2_attention(w.qkv, kcl, vcl, P, 1, past, Tmax, heads, w.att, st, step_state);
+                S = launch_gemm_f32_step(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
+                launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_o, w.x, P, D, w.stats, st);       // residual + LayerNorm 2 statistics
+                S = launch_gemm_f32_step(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, w.stats, b.ln2_g, b.ln2_b);
+                if (S > 1) launch_gpt2_reduce(w.part, S, b.b_fc, w.hid, P, 4 * D, 4 * D, 1, st);
+                S = launch_gemm_f32_step(w.hid, b.w_pr, b.b_pr, w.x, P, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
+                launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_pr, w.x, P, D, w.stats, st);      // residual + next LayerNorm's statistics
+            }
+            static const bool no_head = getenv("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
+            if (no_head || !launch_gpt2_head(w.x, e->g_wte, P, V, D, D, w.stats, e->g_lnf_g, e->g_lnf_b, nullptr, w.pairs, w.d_gen, w.d_state, st)) {
+                // ln_f fused; the real vocabulary (1571 column blocks) is never split, a small one may be
+                const int S = launch_gemm_f32_step(w.x, e->g_wte, nullptr, w.logits, P, V, D, D, V, 0, st, w.part, w.part_elems, w.stats, e->g_lnf_g, e->g_lnf_b);
+                if (S > 1) launch_gpt2_reduce(w.part, S, nullptr, w.logits, P, V, V, 0, st);
+                launch_argmax(w.logits, P, V, w.d_gen, st, w.d_state, w.stats + 2 * P);
+            }
+            launch_gpt2_advance(w.d_state, st);
+            return;
+        }
         for (int l = 0; l < nl; ++l) {
             const auto& b = e->gblk[l];
             float* kcl = w.kc + (size_t)l * P * Tmax * D;
@@ -1589,7 +1623,7 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
         // ln_f on the last position of each sequence, tied lm_head, greedy pick -> d_gen[step][P]
         launch_layernorm(w.x + (size_t)(nd - 1) * D, (long long)nd * D, P, D, e->g_lnf_g, e->g_lnf_b, nullptr, w.last, st);
         launch_gemm_f32(w.last, e->g_wte, nullptr, w.logits, P, V, D, D, V, 0, st, w.part, w.part_elems);
-        launch_argmax(w.logits, P, V, w.d_gen, st, w.d_state);
+        launch_argmax(w.logits, P, V, w.d_gen, st, w.d_state, w.stats + 2 * P);
         launch_gpt2_advance(w.d_state, st);
     };
     std::vector<int32_t> gen((size_t)P * length);

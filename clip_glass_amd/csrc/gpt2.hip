@@ -174,17 +174,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
 // factor (part[z][M][N], fixed-order sum in splitk_reduce_kernel) stays small; the NK partial blocks meet through LDS in a fixed order.
 // Operands are ordered (a = activations, b = weights): a lane holds ONE column n for rows m = mfma32_row, stores are coalesced along n.
 #define GS_KC 64
-template <int NK>
+// LNX: the activation operand is LayerNorm(A) (model.py:15-28), applied to the fragments in registers: (a - mean[m]) * rstd[m] * g[k] + b[k] with
+// the row statistics from gpt2_finalize_kernel (same arithmetic as layernorm_kernel) and g / b of the workgroup's K slice parked in LDS —
+// the separate LayerNorm launch and its [M][D] round trip are gone.
+// ONE: a wave's K part is a single chunk (every step product but the vocabulary projection): one register set instead of two — ~100
+// VGPRs, so two 512-thread workgroups share a CU and the 288-workgroup grids of the MLP products run in one round.
+template <int NK, bool LNX, bool ONE>
 __global__ __launch_bounds__(128 * NK) void gemm_f32_stream_kernel(const float* A, const float* W, const float* bias, float* out, int M, int N,
-                                                                   int K, int lda, int ldo, int mode, float* part, int kslice) {
+                                                                   int K, int lda, int ldo, int mode, float* part, int kslice,
+                                                                   const float* stats, const float* lng, const float* lnb) {
     __shared__ float Rs[NK > 1 ? NK - 1 : 1][2][16][64];     // partial blocks of K parts 1 .. NK-1
+    __shared__ __attribute__((aligned(16))) float Gs[LNX ? 1024 : 4], Bs[LNX ? 1024 : 4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
     const int mi = wave & 1, kp = wave >> 1;
     const int n0 = blockIdx.x * 32;
     const int kpart = kslice / NK, k_lo = blockIdx.y * kslice + kp * kpart, n_ch = kpart / GS_KC;
     const float* wrow = W + (long long)min(n0 + lr, N - 1) * K + k_lo + 4 * kh;          // rows past N / M re-read the last row (never stored)
     const float* xrow = A + (long long)min(mi * 32 + lr, M - 1) * lda + k_lo + 4 * kh;
-    f4 wr[2][8], xr[2][8];
+    f4 wr[ONE ? 1 : 2][8], xr[ONE ? 1 : 2][8];
     auto load = [&](int c, int set) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -196,16 +203,33 @@ __global__ __launch_bounds__(128 * NK) void gemm_f32_stream_kernel(const float* 
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     load(0, 0);
+    float mu = 0.f, rs = 1.f;
+    if (LNX) {
+        const int m = min(mi * 32 + lr, M - 1);
+        mu = stats[2 * m]; rs = stats[2 * m + 1];
+        for (int i = t; i < kslice; i += 128 * NK) { Gs[i] = lng[blockIdx.y * kslice + i]; Bs[i] = lnb[blockIdx.y * kslice + i]; }
+        __syncthreads();
+    }
     auto chunk = [&](int c, int set) {            // set = c & 1, a compile-time constant at both call sites
-        if (c + 1 < n_ch) load(c + 1, set ^ 1);
+        if (!ONE && c + 1 < n_ch) load(c + 1, ONE ? 0 : set ^ 1);
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = 0; b < 8; ++b) {
+            f4 xv = xr[set][b];
+            if (LNX) {
+                const int kl = kp * kpart + c * GS_KC + 8 * b + 4 * kh;
+                xv = (xv - mu) * rs * *(const f4*)(Gs + kl) + *(const f4*)(Bs + kl);
+            }
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[set][b][s2], wr[set][b][s2], acc, 0, 0, 0);   // D[m][n]
+            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s2], wr[set][b][s2], acc, 0, 0, 0);   // D[m][n]
+        }
     };
-    for (int c = 0; c < n_ch; c += 2) {
-        chunk(c, 0);
-        if (c + 1 < n_ch) chunk(c + 1, 1);
+    if (ONE) {
+        chunk(0, 0);                               // (n_ch == 1: nothing to prefetch)
+    } else {
+        for (int c = 0; c < n_ch; c += 2) {
+            chunk(c, 0);
+            if (c + 1 < n_ch) chunk(c + 1, 1);
+        }
     }
     if (NK > 1) {                                  // K parts 1 .. NK-1 hand their blocks to part 0, which adds them in order
         if (kp > 0) {
@@ -243,11 +267,219 @@ __global__ __launch_bounds__(128 * NK) void gemm_f32_stream_kernel(const float* 
 }
 template <int NK>
 static void launch_stream_inst(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
-                               hipStream_t st, float* part, int S) {
-    hipLaunchKernelGGL((gemm_f32_stream_kernel<NK>), dim3((N + 31) / 32, S), dim3(128 * NK), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part,
-                       K / S);
+                               hipStream_t st, float* part, int S, const float* stats = nullptr, const float* lng = nullptr,
+                               const float* lnb = nullptr) {
+    const bool one = K / S / NK == GS_KC;
+    const dim3 g((N + 31) / 32, S), b(128 * NK);
+#define GS_LAUNCH(LN, ON) hipLaunchKernelGGL((gemm_f32_stream_kernel<NK, LN, ON>), g, b, 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part, K / S, stats, lng, lnb)
+    if (stats) { if (one) GS_LAUNCH(true, true); else GS_LAUNCH(true, false); }
+    else { if (one) GS_LAUNCH(false, true); else GS_LAUNCH(false, false); }
+#undef GS_LAUNCH
 }
 
+// x[m][:] += bias + sum_s part[s][m][:] (split-K slices in a fixed order; part == nullptr: x as it is), then the row's LayerNorm statistics
+// {mean, rstd} for the NEXT matrix product's fused LayerNorm (two-pass mean / variance as ln_row, kernels_clip.hip) — one workgroup per
+// row.  D <= 1024.
+__global__ __launch_bounds__(256) void gpt2_finalize_kernel(const float* part, int S, const float* bias, float* x, int M, int D, float* stats) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float* xr = x + (long long)row * D;
+    float v[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = t + 256 * k < D ? xr[t + 256 * k] : 0.f; a[k] = 0.f; }
+    if (part) {
+        int z = 0;
+        for (; z + 4 <= S; z += 4) {                  // four slices' loads in flight together; per element the slices add in order
+            float pv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pv[u][k] = t + 256 * k < D ? part[((long long)(z + u) * M + row) * D + t + 256 * k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] += pv[u][k];
+        }
+        for (; z < S; ++z)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += t + 256 * k < D ? part[((long long)z * M + row) * D + t + 256 * k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = t + 256 * k;
+            if (i < D) {
+                v[k] = v[k] + (a[k] + (bias ? bias[i] : 0.f));          // (splitk_reduce_kernel's order: slices, + bias, + residual)
+                xr[i] = v[k];
+            }
+        }
+    }
+    auto block_sum = [&](float q) {                   // fixed order: lanes (xor tree), then waves 0..3
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = q;
+        __syncthreads();
+        return ((red[0] + red[1]) + red[2]) + red[3];
+    };
+    const float mean = block_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = t + 256 * k < D ? v[k] - mean : 0.f; q += d * d; }
+    const float var = block_sum(q) / (float)D;
+    if (t == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(var + 1e-5f); }
+}
+void launch_gpt2_finalize(const float* part, int S, const float* bias, float* x, int M, int D, float* stats, hipStream_t st) {
+    hipLaunchKernelGGL(gpt2_finalize_kernel, dim3(M), dim3(256), 0, st, part, S, bias, x, M, D, stats);
+}
+
+// ---- vocabulary projection of a single-token step: LayerNorm and the greedy pick's first stage fused -----------------------------------
+// logits[m][n] = ln_f(x)[m] . wte[n] for M <= 64 rows and V = 50257 columns is the one product of a step with real arithmetic (4.9 GFLOP:
+// 31 us of fp32 MFMA at the peak) — gemm_f32_stream_kernel ran it at 123 us: each of its 1571 workgroups re-read the activation
+// fragments (300 MB out of L2).  Here a workgroup's waves own one 32-column block each and SHARE the activation chunk through LDS (64 k x
+// 64 rows, transposed, LayerNorm applied on the way in, double-buffered, one barrier per chunk); weight fragments stream straight from
+// global memory as in gemm_f32_stream_kernel, one 64-deep chunk ahead; both row blocks per wave (64 MFMAs per chunk).  Each wave then
+// reduces every row's 32 columns to (max, lowest index) — stage 1 of the arg-max (sample.py:28-34, greedy) — and stores that pair per
+// (row, column block) instead of the logits (logits != nullptr: they are written too).
+// (A persistent form with the activation fragments resident in registers — 96 + 64 + 16 VGPRs live — spilled 130-180 registers.)
+#define HD_NW 4
+#define HD_LD 65
+__global__ __launch_bounds__(64 * HD_NW) void gpt2_head_kernel(const float* A, const float* W, int M, int N, int K, int lda, const float* stats,
+                                                              const float* lng, const float* lnb, float* logits, float* pv, int* pi, int NB) {
+    __shared__ float Xs[2][GS_KC][HD_LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
+    const int nb = blockIdx.x * HD_NW + wave, n_ch = K / GS_KC;
+    const float* wrow = W + (long long)min(nb * 32 + lr, N - 1) * K + 4 * kh;      // rows past N re-read row N - 1 (masked below)
+    constexpr int XV = 1024 / (64 * HD_NW);                  // float4 loads per thread per chunk: (row, 16-byte piece of the row's 256 bytes)
+    f4 xr[XV];
+    float mu[XV], rs[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int m = min((i * 64 * HD_NW + t) >> 4, M - 1);
+        mu[i] = stats[2 * m]; rs[i] = stats[2 * m + 1];
+    }
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = i * 64 * HD_NW + t, m = min(v >> 4, M - 1), k = c * GS_KC + (v & 15) * 4;
+            xr[i] = (*(const f4*)(A + (long long)m * lda + k) - mu[i]) * rs[i] * *(const f4*)(lng + k) + *(const f4*)(lnb + k);
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = i * 64 * HD_NW + t, m = v >> 4, kq = v & 15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Xs[buf][kq * 4 + j][m] = xr[i][j];
+        }
+    };
+    f4 wr[2][8];
+    auto load_w = [&](int c, int set) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+    };
+    f16x acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    load_x(0);
+    load_w(0, 0);
+    store_x(0);
+    auto chunk = [&](int c, int set) {            // set = c & 1, a compile-time constant at both call sites
+        __syncthreads();                          // chunk c's activations are in Xs[set]; everyone is done with Xs[set ^ 1]
+        if (c + 1 < n_ch) { load_x(c + 1); load_w(c + 1, set ^ 1); }
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const int k = 8 * b + 4 * kh + s2;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xs[set][k][i * 32 + lr], wr[set][b][s2], acc[i], 0, 0, 0);   // D[m][n]
+            }
+        if (c + 1 < n_ch) store_x(set ^ 1);
+    };
+    for (int c = 0; c < n_ch; c += 2) {
+        chunk(c, 0);
+        if (c + 1 < n_ch) chunk(c + 1, 1);
+    }
+    if (nb >= NB) return;
+    const int n = nb * 32 + lr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = i * 32 + mfma32_row(reg, lane);
+            if (logits && n < N && m < M) logits[(long long)m * N + n] = acc[i][reg];
+            float best = n < N ? acc[i][reg] : -INFINITY;
+            int idx = n;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {            // across the 32 columns of this row (the lanes of one kh half)
+                const float v2 = __shfl_xor(best, o);
+                const int i2 = __shfl_xor(idx, o);
+                if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+            }
+            if (lr == 0 && m < M) { pv[(long long)m * NB + nb] = best; pi[(long long)m * NB + nb] = idx; }
+        }
+}
+// stage 2: one workgroup per row over its NB (value, index) pairs -> out[step * rows + row]
+__global__ __launch_bounds__(256) void argmax_pairs_kernel(const float* pv, const int* pi, int NB, int* out, const int* step_dev) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < NB; i += 256) {
+        const float v = pv[(long long)blockIdx.x * NB + i];
+        const int j = pi[(long long)blockIdx.x * NB + i];
+        if (v > best || (v == best && j < idx)) { best = v; idx = j; }
+    }
+    bv[threadIdx.x] = best;
+    bi[threadIdx.x] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float v2 = bv[threadIdx.x + o];
+            const int i2 = bi[threadIdx.x + o];
+            if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) { bv[threadIdx.x] = v2; bi[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(step_dev ? (long long)step_dev[1] * gridDim.x : 0) + blockIdx.x] = bi[0];
+}
+// false: shape not covered (caller: generic product + launch_argmax).  pairs: scratch of 2 * M * ceil(N / 32) words.
+bool launch_gpt2_head(const float* A, const float* W, int M, int N, int K, int lda, const float* stats, const float* lng, const float* lnb,
+                      float* logits, float* pairs, int* out, const int* step_dev, hipStream_t st) {
+    if (M > 64 || K % GS_KC != 0 || lda % 4 != 0 || !pairs || N < 4096) return false;
+    const int NB = (N + 31) / 32;
+    int* pi = (int*)(pairs + (size_t)M * NB);
+    hipLaunchKernelGGL(gpt2_head_kernel, dim3((NB + HD_NW - 1) / HD_NW), dim3(64 * HD_NW), 0, st, A, W, M, N, K, lda, stats, lng, lnb, logits, pairs, pi, NB);
+    hipLaunchKernelGGL(argmax_pairs_kernel, dim3(M), dim3(256), 0, st, pairs, pi, NB, out, step_dev);
+    return true;
+}
+
+// A single-token-step product of the fused step (engine.cpp): launch_gemm_f32's split policy, but the caller finishes the slices — returns
+// the global split S: S == 1: bias / mode were applied by the kernel; S > 1: raw sums are in `part` (splitk_reduce_kernel via
+// launch_gpt2_reduce, or gpt2_finalize_kernel for the residual products).  stats != nullptr: LayerNorm fused on the activation operand
+// (K <= 1024).  Returns 0 when the shape does not fit (caller: unfused path).
+int launch_gemm_f32_step(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
+                         hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb) {
+    if (M > 64 || K % GS_KC != 0 || lda % 4 != 0 || (stats && K > 1024)) return 0;
+    const int nb = (N + 31) / 32;
+    int S = 1, NK = 1;
+    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int c : cand) {
+        if (K % (c * GS_KC) != 0 || (c > 1 && (!part || (size_t)c * M * N > part_elems || nb >= 1024))) continue;
+        S = c;
+        const int ks = K / c;
+        NK = ks % (4 * GS_KC) == 0 ? 4 : (ks % (2 * GS_KC) == 0 ? 2 : 1);
+        if (nb * c >= 200 && ks / NK <= 2 * GS_KC) break;
+    }
+    if (NK == 4) launch_stream_inst<4>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
+    else if (NK == 2) launch_stream_inst<2>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
+    else launch_stream_inst<1>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
+    return S;
+}
+void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out, int M, int N, int ldo, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out, M, N, ldo, mode);
+}
 // `part`: scratch for split-K partial sums (nullable = never split); sized by the caller for GPT2_SPLITK_MAX slices of M x N.
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
                      int mode, hipStream_t st, float* part, size_t part_elems) {
@@ -371,16 +603,10 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
 // ---- greedy pick (sample.py:28-34 with sample=False): arg-max of softmax(top_k(logits / T)) == arg-max of the
 // logits, lowest index on exact ties (torch.topk returns the first maximum) ------------------------------------
 // step_dev != nullptr: row r's pick goes to out[step * gridDim.x + r] with step = step_dev[1] (graph replay)
-__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N, int* out, const int* step_dev) {
-    __shared__ float bv[256];
-    __shared__ int bi[256];
-    const float* r = logits + (long long)blockIdx.x * N;
-    float best = -INFINITY;
-    int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < N; i += 256) {
-        const float v = r[i];
-        if (v > best) { best = v; idx = i; }
-    }
+// Two stages (round 3: one workgroup per row scanned 200 KB on its own, 56 us): stage 1 = ARGMAX_SEG segments per row -> (value, index)
+// pairs, stage 2 = one wave per row over the pairs.
+#define ARGMAX_SEG 32
+__device__ __forceinline__ void argmax_block(float best, int idx, float* bv, int* bi) {      // 256 threads -> bv[0], bi[0]
     bv[threadIdx.x] = best;
     bi[threadIdx.x] = idx;
     __syncthreads();
@@ -392,8 +618,53 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N,
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void argmax_seg_kernel(const float* logits, int N, float* pv, int* pi) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int row = blockIdx.x / ARGMAX_SEG, seg = blockIdx.x % ARGMAX_SEG;
+    const int per = (N + ARGMAX_SEG - 1) / ARGMAX_SEG, lo = seg * per, hi = min(N, lo + per);
+    const float* r = logits + (long long)row * N;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = r[i];
+        if (v > best) { best = v; idx = i; }
+    }
+    argmax_block(best, idx, bv, bi);
+    if (threadIdx.x == 0) { pv[blockIdx.x] = bv[0]; pi[blockIdx.x] = bi[0]; }
+}
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* pv, const int* pi, int* out, const int* step_dev) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float best = lane < ARGMAX_SEG ? pv[row * ARGMAX_SEG + lane] : -INFINITY;
+    int idx = lane < ARGMAX_SEG ? pi[row * ARGMAX_SEG + lane] : 0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v2 = __shfl_xor(best, o);
+        const int i2 = __shfl_xor(idx, o);
+        if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+    }
+    if (lane == 0) out[(step_dev ? (long long)step_dev[1] * gridDim.x : 0) + row] = idx;
+}
+__global__ __launch_bounds__(256) void argmax_kernel(const float* logits, int N, int* out, const int* step_dev) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const float* r = logits + (long long)blockIdx.x * N;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = r[i];
+        if (v > best) { best = v; idx = i; }
+    }
+    argmax_block(best, idx, bv, bi);
     if (threadIdx.x == 0) out[(step_dev ? (long long)step_dev[1] * gridDim.x : 0) + blockIdx.x] = bi[0];
 }
-void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev) {
+// scratch: rows * ARGMAX_SEG floats + as many ints (nullptr: the one-stage kernel)
+void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev, float* scratch) {
+    if (scratch && N >= 8192) {
+        int* pi = (int*)(scratch + (size_t)rows * ARGMAX_SEG);
+        hipLaunchKernelGGL(argmax_seg_kernel, dim3(rows * ARGMAX_SEG), dim3(256), 0, st, logits, N, scratch, pi);
+        hipLaunchKernelGGL(argmax_final_kernel, dim3(rows), dim3(64), 0, st, scratch, pi, out, step_dev);
+        return;
+    }
     hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, st, logits, N, out, step_dev);
 }

@@ -104,10 +104,17 @@ void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int r
 // part / part_elems: split-K scratch for the single-token (M <= 64) steps (nullptr = never split)
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
                      int mode, hipStream_t st, float* part = nullptr, size_t part_elems = 0);
+// fused single-token step (round 3): products with LayerNorm on the activation operand / complete outputs, and the residual + statistics pass
+int launch_gemm_f32_step(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
+                         hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb);
+bool launch_gpt2_head(const float* A, const float* W, int M, int N, int K, int lda, const float* stats, const float* lng, const float* lnb,
+                      float* logits, float* pairs, int* out, const int* step_dev, hipStream_t st);
+void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out, int M, int N, int ldo, int mode, hipStream_t st);
+void launch_gpt2_finalize(const float* part, int S, const float* bias, float* x, int M, int D, float* stats, hipStream_t st);
 // past_dev / step_dev: device-resident step state {past length, step index} for the captured single-token step
 void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd, int past, int Tmax, int heads,
                            float* out, hipStream_t st, const int* past_dev = nullptr);
-void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr);
+void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr, float* scratch = nullptr);
 void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st);
 void launch_gpt2_advance(int* state, hipStream_t st);
 // NCHW fp32 image [n][3][S][S] -> CLIP patch matrix [n*G*G][3*ps*ps] fp16
