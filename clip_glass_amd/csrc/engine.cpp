@@ -1578,6 +1578,7 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
     // instead of 11 (complete-output products — 72 / 24 / 96 workgroups walking three chunks each — were 21 us against 9 + 4: dropped)
     static const bool no_fuse = getenv("GLASS_GPT2_NO_FUSE") != nullptr;
     const bool fuse_ok = !no_fuse && P <= 64 && D % 64 == 0 && D <= 1024;
+    static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
         if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st);
@@ -1589,8 +1590,12 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
                 float* kcl = w.kc + (size_t)l * P * Tmax * D;
                 float* vcl = w.vc + (size_t)l * P * Tmax * D;
                 int S = launch_gemm_f32_step(w.x, b.w_qkv, b.b_qkv, w.qkv, P, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems, w.stats, b.ln1_g, b.ln1_b);
-                if (S > 1) launch_gpt2_reduce(w.part, S, b.b_qkv, w.qkv, P, 3 * D, 3 * D, 0, st);
-                launch_gpt2_attention(w.qkv, kcl, vcl, P, 1, past, Tmax, heads, w.att, st, step_state);
+                if (Tmax <= 64 && !no_attn_step) {      // one wave per (sequence, head); it sums the product's slices itself
+                    launch_gpt2_attention_step(w.qkv, S > 1 ? w.part : nullptr, S, b.b_qkv, kcl, vcl, P, Tmax, heads, w.att, st, step_state);
+                } else {
+                    if (S > 1) launch_gpt2_reduce(w.part, S, b.b_qkv, w.qkv, P, 3 * D, 3 * D, 0, st);
+                    launch_gpt2_attention(w.qkv, kcl, vcl, P, 1, past, Tmax, heads, w.att, st, step_state);
+                }
                 S = launch_gemm_f32_step(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
                 launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_o, w.x, P, D, w.stats, st);       // residual + LayerNorm 2 statistics
                 S = launch_gemm_f32_step(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, w.stats, b.ln2_g, b.ln2_b);

@@ -600,6 +600,84 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
     hipLaunchKernelGGL(gpt2_attention_kernel, dim3(P * heads), dim3(256), lds, st, qkv, kc, vc, nd, past, Tmax, heads, out, past_dev);
 }
 
+// Single-token step (nd = 1, history <= 64 positions): ONE WAVE per (sequence, head), and the split-K slices of the qkv product are
+// summed here (part / S / bias as in splitk_reduce_kernel; part == nullptr: qkv holds finished values) — the general kernel above spent
+// 10 us on five barriers and scalar cache loads, plus 4.6 us for the reduce launch in front of it.  Lane = feature d for q / k / v and
+// the output, lane = key position j for the scores (each lane reads one 256-byte key row); q and the probabilities cross lanes through
+// LDS; the value rows are read coalesced.  Sum orders as in gpt2_attention_kernel.
+__global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* qkv, const float* part, int S, const float* bias, float* kc, float* vc,
+                                                                  int P, int Tmax, int heads, float* out, const int* past_dev) {
+    __shared__ __attribute__((aligned(16))) float qs[4][64], ks[4][64], ps[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= P * heads) return;                    // (no workgroup barrier below: waves are independent)
+    const int past = *past_dev, ns = past + 1;
+    const int D = heads * 64, seq = item / heads, h = item - seq * heads;
+    float r[3];
+#pragma unroll
+    for (int w3 = 0; w3 < 3; ++w3) {
+        const int c = w3 * D + h * 64 + lane;
+        if (part) {
+            float a = 0.f;
+            for (int z = 0; z < S; ++z) a += part[((long long)z * P + seq) * 3 * D + c];
+            r[w3] = a + (bias ? bias[c] : 0.f);
+        } else {
+            r[w3] = qkv[(long long)seq * 3 * D + c];
+        }
+    }
+    kc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[1];
+    vc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[2];
+    qs[wave][lane] = r[0];
+    ks[wave][lane] = r[1];
+    __builtin_amdgcn_wave_barrier();                  // LDS is in order per wave
+    float sc = -INFINITY;
+    if (lane < ns) {
+        float a = 0.f;
+        if (lane == past) {
+#pragma unroll 16
+            for (int d = 0; d < 64; ++d) a += qs[wave][d] * ks[wave][d];
+        } else {
+            const float* kr = kc + ((long long)seq * Tmax + lane) * D + h * 64;
+            f4 kk[16];
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) kk[d4] = *(const f4*)(kr + 4 * d4);
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                const f4 qq = *(const f4*)(&qs[wave][4 * d4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a += qq[j] * kk[d4][j];
+            }
+        }
+        sc = a * 0.125f;
+    }
+    float m = sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e2 = lane < ns ? expf(sc - m) : 0.f;
+    float z = e2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+    ps[wave][lane] = e2 / z;
+    __builtin_amdgcn_wave_barrier();
+    const float* vr = vc + (long long)seq * Tmax * D + h * 64 + lane;
+    float a = 0.f;
+    int j = 0;
+    for (; j + 4 <= past; j += 4) {                   // four value rows in flight; the sum runs in key order
+        float vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = vr[(long long)(j + u) * D];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a += ps[wave][j + u] * vv[u];
+    }
+    for (; j < past; ++j) a += ps[wave][j] * vr[(long long)j * D];
+    a += ps[wave][past] * r[2];
+    out[(long long)seq * D + h * 64 + lane] = a;
+}
+void launch_gpt2_attention_step(const float* qkv, const float* part, int S, const float* bias, float* kc, float* vc, int P, int Tmax, int heads,
+                                float* out, hipStream_t st, const int* past_dev) {
+    hipLaunchKernelGGL(gpt2_attention_step_kernel, dim3((P * heads + 3) / 4), dim3(256), 0, st, qkv, part, S, bias, kc, vc, P, Tmax, heads, out, past_dev);
+}
+
 // ---- greedy pick (sample.py:28-34 with sample=False): arg-max of softmax(top_k(logits / T)) == arg-max of the
 // logits, lowest index on exact ties (torch.topk returns the first maximum) ------------------------------------
 // step_dev != nullptr: row r's pick goes to out[step * gridDim.x + r] with step = step_dev[1] (graph replay)

@@ -114,6 +114,8 @@ void launch_gpt2_finalize(const float* part, int S, const float* bias, float* x,
 // past_dev / step_dev: device-resident step state {past length, step index} for the captured single-token step
 void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd, int past, int Tmax, int heads,
                            float* out, hipStream_t st, const int* past_dev = nullptr);
+void launch_gpt2_attention_step(const float* qkv, const float* part, int S, const float* bias, float* kc, float* vc, int P, int Tmax, int heads,
+                                float* out, hipStream_t st, const int* past_dev);
 void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr, float* scratch = nullptr);
 void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st);
 void launch_gpt2_advance(int* state, hipStream_t st);
