@@ -629,6 +629,7 @@ static int alloc_buffers(glass_engine* e) {
     if (c.use_discriminator && c.n_blocks > 0) {
         if ((rc = dev_alloc(e, &e->d_dfin, (size_t)P * 16 * c.channels[0]))) return rc;
         if ((rc = dev_alloc(e, &e->d_dh, (size_t)P * c.channels[0]))) return rc;
+        if ((rc = dev_alloc(e, &e->d_dh_part, (size_t)16 * P * c.channels[0]))) return rc;    // split-K slices of D's first dense layer
     }
     {   // descriptor table of the demodulation problems (one launch for all layers)
         std::vector<DenseDesc> dd;
@@ -1169,7 +1170,26 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     memset(&g, 0, sizeof g);
     g.a = e->d_dfin; g.w = e->d_dense0_w; g.M = P; g.N = CL; g.K = 16 * CL; g.bias = e->d_dense0_b; g.mode = 4;
     g.out32 = e->d_dh; g.ldo = CL;
-    run_gemm(e, g, "D.dense0");
+    // M = P rows, K = 16 CL = 8192: the 128 x 64 tiles are 8 workgroups walking 128 K steps each (97 us for 0.5 GFLOP).  Split K into 16
+    // slices (blockIdx.z) with raw partial sums, finished in a fixed order with bias + activation: 128+ workgroups, 8 steps each.
+    static const bool no_d0_split = getenv("GLASS_NO_DENSE0_SPLIT") != nullptr;   // A/B knob
+    const int S0 = 16;
+    if (!no_d0_split && e->d_dh_part && g.K % (S0 * 64) == 0 && P <= e->cfg.max_pop) {
+        GemmParams q = g;
+        q.ld = g.K; q.K = g.K / S0; q.batch = S0; q.a_bs = q.K; q.w_bs = q.K; q.o_bs = (long long)P * CL;
+        q.bias = nullptr; q.mode = 3; q.out32 = e->d_dh_part;
+        Prof pr(e, "D.dense0", 2.0 * P * (double)g.K * CL, 2.0 * (double)g.K * CL);
+        const char* k = launch_gemm_tiled(q, e->cur);
+        if (k) {
+            launch_splitk_finish(e->d_dh_part, S0, q.o_bs, g.bias, e->d_dh, P, CL, 4, e->cur);
+            if (pr.on) pr.pe.name = std::string("D.dense0@") + k + "+splitk_finish";
+        } else {
+            pr.on = false;
+            run_gemm(e, g, "D.dense0");
+        }
+    } else {
+        run_gemm(e, g, "D.dense0");
+    }
     {
         Prof pr(e, "D.dense1", 2.0 * P * CL, 0);
         launch_dense(e->d_dh, CL, P, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis, 1, 0, 0, nullptr, 0, e->cur);

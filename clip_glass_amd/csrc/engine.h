@@ -172,7 +172,7 @@ struct glass_engine {
     float* d_img = nullptr;
     half_t *d_patches = nullptr, *d_ln16 = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_hid = nullptr;
     float *d_pe = nullptr, *d_x = nullptr, *d_cls = nullptr, *d_feat = nullptr, *d_sim = nullptr, *d_dis = nullptr,
-          *d_F = nullptr, *d_dh = nullptr;
+          *d_F = nullptr, *d_dh = nullptr, *d_dh_part = nullptr;
     half_t* d_dfin = nullptr;
     float* h_pinned = nullptr;
     size_t h_pinned_bytes = 0;
