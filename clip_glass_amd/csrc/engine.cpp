@@ -1180,16 +1180,14 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
         q.bias = nullptr; q.mode = 3; q.out32 = e->d_dh_part;
         Prof pr(e, "D.dense0", 2.0 * P * (double)g.K * CL, 2.0 * (double)g.K * CL);
         const char* k = launch_gemm_tiled(q, e->cur);
-        if (k) {
-            launch_splitk_finish(e->d_dh_part, S0, q.o_bs, g.bias, e->d_dh, P, CL, 4, e->cur);
-            if (pr.on) pr.pe.name = std::string("D.dense0@") + k + "+splitk_finish";
-        } else {
-            pr.on = false;
-            run_gemm(e, g, "D.dense0");
+        if (k) {    // finish + the second dense layer (CL -> 1) in one launch
+            launch_dense01_finish(e->d_dh_part, S0, q.o_bs, g.bias, e->d_dense1_wt, e->d_dense1_b, e->d_dis, P, CL, e->cur);
+            if (pr.on) pr.pe.name = std::string("D.dense0+1@") + k + "+dense01_finish";
+            return;
         }
-    } else {
-        run_gemm(e, g, "D.dense0");
+        pr.on = false;
     }
+    run_gemm(e, g, "D.dense0");
     {
         Prof pr(e, "D.dense1", 2.0 * P * CL, 0);
         launch_dense(e->d_dh, CL, P, CL, e->d_dense1_wt, 1, e->d_dense1_b, e->d_dis, 1, 0, 0, nullptr, 0, e->cur);

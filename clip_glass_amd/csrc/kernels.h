@@ -30,6 +30,8 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);
 void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipStream_t st);
 // out[p][n] = epi( sum_k f(x[p][k]) * wt[k][n] + bias[n] ); in_sq: f = square;
 // mode 0 none, 1 lrelu*sqrt2, 2 rsqrt(v + eps_row[p*eps_stride])
+void launch_dense01_finish(const float* part, int S, long long slab, const float* bias0, const float* w1, const float* b1, float* out, int P, int N,
+                           hipStream_t st);
 void launch_splitk_finish(const float* part, int S, long long slab, const float* bias, float* out, int M, int N, int mode, hipStream_t st);
 void launch_dense_splitk(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias, float* out, int ldo,
                          int mode, hipStream_t st);   // K % 64 == 0, K <= 768: the mapping-network layers

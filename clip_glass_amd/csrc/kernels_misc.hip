@@ -248,6 +248,29 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* part, i
     v += bias ? bias[e % N] : 0.f;
     out[e] = mode == 4 ? lrelu_sqrt2(v) : v;
 }
+// D's head in one launch (stylegan2/models.py:1339-1350: dense CL -> CL + lrelu, dense CL -> 1): row p of the first layer is finished from
+// its split-K slices (bias, lrelu * sqrt2) and goes straight into the second layer's dot product — one workgroup per candidate, block sum
+// in a fixed order (lanes xor tree, then waves 0..3); the separate N = 1 dense launch walked K = 512 in one chain per thread (37 us).
+__global__ __launch_bounds__(256) void dense01_finish_kernel(const float* part, int S, long long slab, const float* bias0, const float* w1,
+                                                             const float* b1, float* out, int N) {
+    __shared__ float red[4];
+    const int p = blockIdx.x, t = threadIdx.x;
+    float acc = 0.f;
+    for (int n = t; n < N; n += 256) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += part[(long long)z * slab + (long long)p * N + n];
+        v = lrelu_sqrt2(v + (bias0 ? bias0[n] : 0.f));
+        acc += v * w1[n];
+    }
+    acc = wave_sum(acc);
+    if ((t & 63) == 0) red[t >> 6] = acc;
+    __syncthreads();
+    if (t == 0) out[p] = ((red[0] + red[1]) + (red[2] + red[3])) + (b1 ? b1[0] : 0.f);
+}
+void launch_dense01_finish(const float* part, int S, long long slab, const float* bias0, const float* w1, const float* b1, float* out, int P, int N,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(dense01_finish_kernel, dim3(P), dim3(256), 0, st, part, S, slab, bias0, w1, b1, out, N);
+}
 void launch_splitk_finish(const float* part, int S, long long slab, const float* bias, float* out, int M, int N, int mode, hipStream_t st) {
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, S, slab, bias, out, M * N, N, mode);
 }
@@ -734,9 +757,70 @@ __global__ __launch_bounds__(256) void mbstd_kernel(const half_t* x, int hw, int
         out[((long long)s * hw + pix) * Cpad + C + cc] = (half_t)(cc == 0 ? stdv : 0.f);
     }
 }
+// Vector form (C and Cpad multiples of 8, group <= 8): a thread owns eight channels of one pixel for the whole group — one 16-byte load per
+// group member, all in flight together (the scalar form walked 32 x group two-byte loads per thread: 59 us for 0.5 MB).  Sums in the same
+// order per element; the block sum of the per-element deviations runs lanes -> waves in a fixed order.
+__global__ __launch_bounds__(1024) void mbstd_vec_kernel(const half_t* x, int hw, int C, int Cpad, int batch_size, int group, float eps,
+                                                        half_t* out) {
+    __shared__ float red[16];
+    const int nsub = batch_size / group;
+    const int mb = blockIdx.x / nsub, j = blockIdx.x % nsub;
+    const int n = hw * C, c8n = C >> 3;
+    float sum = 0.f;
+    for (int e8 = threadIdx.x; e8 < hw * c8n; e8 += 1024) {
+        const int pix = e8 / c8n, c8 = e8 - pix * c8n;
+        h8 v[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (g < group) v[g] = *(const h8*)(x + (long long)(mb * batch_size + j + g * nsub) * n + (long long)e8 * 8);
+        float mean[8], var[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float m = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (g < group) m += (float)v[g][q];
+            mean[q] = m / (float)group;
+            var[q] = 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (g < group) {
+                h8 o;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = (float)v[g][q] - mean[q];
+                    var[q] += d * d;
+                    o[q] = (half_t)d;
+                }
+                *(h8*)(out + ((long long)(mb * batch_size + j + g * nsub) * hw + pix) * Cpad + c8 * 8) = o;
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += sqrtf(var[q] / (float)group + eps);
+    }
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float stdv = tot / (float)n;
+    for (int e = threadIdx.x; e < group * hw * (Cpad - C); e += 1024) {
+        const int cc = e % (Cpad - C);
+        const int pix = (e / (Cpad - C)) % hw;
+        const int g = e / ((Cpad - C) * hw);
+        const int s = mb * batch_size + j + g * nsub;
+        out[((long long)s * hw + pix) * Cpad + C + cc] = (half_t)(cc == 0 ? stdv : 0.f);
+    }
+}
 void launch_mbstd(const half_t* x, int B, int hw, int C, int Cpad, int batch_size, int group, float eps,
                   half_t* out, hipStream_t st) {
     const int nsub = batch_size / group;
+    static const bool scalar = getenv("GLASS_MBSTD_SCALAR") != nullptr;      // A/B knob
+    if ((C & 7) == 0 && (Cpad & 7) == 0 && group <= 8 && !scalar) {
+        hipLaunchKernelGGL(mbstd_vec_kernel, dim3((B / batch_size) * nsub), dim3(1024), 0, st, x, hw, C, Cpad, batch_size, group, eps, out);
+        return;
+    }
     hipLaunchKernelGGL(mbstd_kernel, dim3((B / batch_size) * nsub), dim3(256), 0, st, x, hw, C, Cpad, batch_size,
                        group, eps, out);
 }
