@@ -169,5 +169,5 @@ struct GemmParams {
     int batch;              // 0/1: single problem; >1: blockIdx.z walks problems a_bs / w_bs / o_bs elements apart
     long long a_bs, w_bs, o_bs;
     int ld;                 // 0: rows of a and w are K long.  > 0: their row stride (a K slice of longer rows: split-K as `batch` slices,
-                            // a_bs = w_bs = K, raw partial sums to out32 + z * o_bs; gemm_tiled only, not with kpt)
+                            // a_bs = w_bs = K, raw partial sums to out32 + z * o_bs; gemm_tiled only.  With kpt: w_bs = 0, slice z starts at k = z * K of the tap walk)
 };

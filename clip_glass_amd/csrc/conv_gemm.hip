@@ -28,8 +28,14 @@ __global__ __launch_bounds__(256) void conv_im2col_kernel(ConvParams p, half_t* 
     const int iy = oy * p.stride + ty - p.pad, ix = ox * p.stride + tx - p.pad;
     h8 a = {0, 0, 0, 0, 0, 0, 0, 0};
     if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-        a = *(const h8*)(p.x + (long long)b * p.x_bstride + ((long long)iy * p.W + ix) * p.Cin + c8 * 8);
-        if (p.sn) {      // (half)(x * s): conv_direct's rounding
+        // (in_up: the input is read through a nearest x2 upsample — H, W are the upsampled dims)
+        a = *(const h8*)(p.x + (long long)b * p.x_bstride + ((long long)(iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + c8 * 8);
+        if (p.pre_shift) {   // relu(x * s + shift) for in-bounds pixels (BigGAN batch norm + ReLU ahead of the conv): conv_direct's rounding
+            const float* s = p.sn + (long long)b * p.sn_stride + c8 * 8;
+            const float* t = p.pre_shift + (long long)b * p.sn_stride + c8 * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (half_t)fmaxf((float)a[j] * s[j] + t[j], 0.f);
+        } else if (p.sn) {      // (half)(x * s): conv_direct's rounding
             const float* s = p.sn + (long long)b * p.sn_stride + c8 * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) a[j] = (half_t)((float)a[j] * s[j]);
@@ -39,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_im2col_kernel(ConvParams p, half_t* 
 }
 
 // y = epilogue(C[m][n]) for 4 consecutive n per thread — conv_direct.hip's epilogue contract
-__global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const float* C, long long n_quad) {
+__global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const float* C, long long n_quad, int S, long long slab) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_quad) return;
     const int nq = p.Neff >> 2;
@@ -54,7 +60,8 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
         py = 2 * py + (ph >> 1);
         px = 2 * px + (ph & 1);
     }
-    const f4 c = *(const f4*)(C + m * p.Neff + n);
+    f4 c = *(const f4*)(C + m * p.Neff + n);
+    for (int z = 1; z < S; ++z) c += *(const f4*)(C + z * slab + m * p.Neff + n);      // split-K slices, fixed order
     const float nz = p.noise ? p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px] : 0.f;
     const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
     h4 r = {0, 0, 0, 0};
@@ -82,7 +89,8 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
 // cap_a / cap_c: scratch capacity PER CANDIDATE (halfs of A, floats of C); the buffers hold p.B candidates
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
     static const bool off = getenv("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
-    if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.pre_shift || p.in_up || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
+    if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
+    if (p.pre_shift && !p.sn) return nullptr;
     if (p.xs_out || p.post_scale16) return nullptr;   // by-products / output transforms this path does not implement: refuse, never ignore
     if ((p.KS != 1 && p.KS != 3) || p.Cin % 64 != 0 || p.Neff % 64 != 0 || (p.Cout & 3) || (p.res_cs & 3)) return nullptr;
     const long long M = (long long)p.B * p.Hc * p.Wc, K = (long long)p.KS * p.KS * p.Cin;
@@ -95,7 +103,22 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
     g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]; (kpt: any M is accepted —
                                                                       // the kernel choice must not depend on the candidate count)
     g.mode = 3; g.out32 = ws_c; g.ldo = p.Neff;
-    if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
-    hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n_quad + 255) / 256)), dim3(256), 0, st, p, ws_c, n_quad);
+    // split-K (round 3): a 4 x 4 / 8 x 8 grid per candidate is 16 / 64 rows — at 64 candidates the product has 64 / 256 tiles walking
+    // 72 K steps each.  S slices (a function of the per-candidate geometry only, like every choice here) of raw sums, added in a fixed
+    // order by the finishing pass; the scratch holds them while S x grid x Neff fits its per-candidate capacity.
+    static const bool no_split = getenv("GLASS_CONV_GEMM_NO_SPLIT") != nullptr;   // A/B knob
+    int S = 1;
+    if (!no_split && p.KS == 3) {
+        const int px = p.Hc * p.Wc;
+        S = px <= 16 ? 4 : (px <= 64 ? 2 : 1);
+        while (S > 1 && (K % (64LL * S) != 0 || (long long)S * px * p.Neff > cap_c)) S >>= 1;
+    }
+    const long long slab = M * p.Neff;
+    if (S > 1) { g.ld = (int)K; g.K = (int)(K / S); g.batch = S; g.a_bs = g.K; g.w_bs = 0; g.o_bs = slab; }
+    if (!launch_gemm_tiled(g, st)) {
+        if (S > 1) { S = 1; g.ld = 0; g.K = (int)K; g.batch = 0; g.a_bs = g.o_bs = 0; }
+        if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
+    }
+    hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n_quad + 255) / 256)), dim3(256), 0, st, p, ws_c, n_quad, S, slab);
     return "conv_gemm(im2col+gemm_tiled+finish)";
 }

@@ -561,6 +561,14 @@ static int alloc_buffers(glass_engine* e) {
             if ((rc = dev_alloc(e, &e->ws_a2, (size_t)(e->cap_a * P)))) return rc;
             if ((rc = dev_alloc(e, &e->ws_c2, (size_t)(e->cap_c * P)))) return rc;
         }
+    } else if (e->cfg.generator == GLASS_GEN_BIGGAN_DEEP && !getenv("GLASS_BG_NO_CONV_GEMM")) {
+        // BigGAN-deep's 4 x 4 .. 16 x 16 layers (3 x 3 on ch * 4 = 512 channels, 1 x 1 up to ch * 16 outputs) on the same path (round 3:
+        // they ran on conv_direct at 64 - 220 TFLOP/s); the walk over the population is chunked, so the scratch holds one chunk
+        const int cmax = 4 * e->cfg.bg_ch;
+        e->cap_a = 256LL * 9 * cmax;
+        e->cap_c = 256LL * 4 * cmax;
+        if ((rc = dev_alloc(e, &e->ws_a, (size_t)(e->cap_a * P)))) return rc;
+        if ((rc = dev_alloc(e, &e->ws_c, (size_t)(e->cap_c * P)))) return rc;
     }
     if ((rc = dev_alloc(e, &e->d_epsrow, (size_t)P * e->n_style))) return rc;
     if ((rc = dev_alloc(e, &e->d_dscale, (size_t)P * e->D_total))) return rc;

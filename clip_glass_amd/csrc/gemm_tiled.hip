@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
             ra[k] = *(const h8*)(p.a + (long long)row * (p.ld ? p.ld : p.K) + k0 + part * 8);
         }
         const int rs = p.kpt ? p.kpt : (p.ld ? p.ld : p.K);      // weight row stride; a conv weight is walked tap by tap
-        const half_t* wk = p.kpt ? p.w + (long long)(k0 / p.kpt) * p.w_tap_stride + (k0 % p.kpt) : p.w + k0;   // uniform
+        const int kw = k0 + ((p.kpt && p.ld) ? (int)blockIdx.z * p.K : 0);   // split-K over a packed conv weight: this slice's first k
+        const half_t* wk = p.kpt ? p.w + (long long)(kw / p.kpt) * p.w_tap_stride + (kw % p.kpt) : p.w + k0;   // uniform
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int row = (t >> 3) + 32 * k;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
 }
 
 const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
-    if ((p.ld && p.kpt) || p.K % 64 != 0 || p.ldo % 4 != 0 || (p.M < 64 && !p.kpt) || (p.kpt && p.kpt % 64 != 0)) return nullptr;
+    if (p.K % 64 != 0 || p.ldo % 4 != 0 || (p.M < 64 && !p.kpt) || (p.kpt && p.kpt % 64 != 0)) return nullptr;
     const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
     // 128-wide n tiles under-fill the chip on the N = 768 CLIP linears (25 x 6 = 150 workgroups for 256 CUs): take 64-wide
     // tiles whenever the 128-wide grid has fewer workgroups than CUs
