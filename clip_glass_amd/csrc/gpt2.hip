@@ -463,18 +463,43 @@ int launch_gemm_f32_step(const float* A, const float* W, const float* bias, floa
                          hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb) {
     if (M > 64 || K % GS_KC != 0 || lda % 4 != 0 || (stats && K > 1024)) return 0;
     const int nb = (N + 31) / 32;
-    int S = 1, NK = 1;
-    static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    for (int c : cand) {
-        if (K % (c * GS_KC) != 0 || (c > 1 && (!part || (size_t)c * M * N > part_elems || nb >= 1024))) continue;
-        S = c;
-        const int ks = K / c;
-        NK = ks % (4 * GS_KC) == 0 ? 4 : (ks % (2 * GS_KC) == 0 ? 2 : 1);
-        if (nb * c >= 200 && ks / NK <= 2 * GS_KC) break;
+    // K = C chunks of 64 = S global slices x NK parts inside a workgroup (one chunk per wave).  Of the factorizations with NK in
+    // {1, 2, 4, 6} take the one with the most workgroups that still fit the chip in ONE round (nb * S <= CUs: 288 workgroups on 256 CUs
+    // ran the MLP products at 14 us against 9.7 us for the 216 of the qkv product), fewest slices among equals; a product too small to
+    // fill the CUs either way takes the most slices its scratch allows.
+    static const bool old_rule = getenv("GLASS_GPT2_OLD_SPLIT") != nullptr;     // A/B knob
+    const int C = K / GS_KC, n_cu = glass_cu_count();
+    int S = 0, NK = 1;
+    if (!old_rule && nb < 1024) {
+        static const int nks[] = {6, 4, 2, 1};          // (8 parts = 1024 threads = a 128-VGPR budget: spills)
+        int best_wg = -1;
+        for (int nk : nks) {
+            if (C % nk != 0) continue;
+            const int sl = C / nk;
+            if (sl > 1 && (!part || (size_t)sl * M * N > part_elems || sl > 16)) continue;
+            const int wg = nb * sl;
+            const bool fits = wg <= n_cu;
+            const int score = fits ? wg : -wg;              // prefer fitting grids, then the larger one; non-fitting: the smaller
+            if (S == 0 || score > best_wg) { best_wg = score; S = sl; NK = nk; }
+        }
     }
-    if (NK == 4) launch_stream_inst<4>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
-    else if (NK == 2) launch_stream_inst<2>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
-    else launch_stream_inst<1>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb);
+    if (S == 0) {      // the vocabulary projection (never split globally), shapes the rule above does not cover, and the A/B knob
+        S = 1; NK = 1;
+        static const int cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+        for (int c : cand) {
+            if (K % (c * GS_KC) != 0 || (c > 1 && (!part || (size_t)c * M * N > part_elems || nb >= 1024))) continue;
+            S = c;
+            const int ks = K / c;
+            NK = ks % (4 * GS_KC) == 0 ? 4 : (ks % (2 * GS_KC) == 0 ? 2 : 1);
+            if (nb * c >= 200 && ks / NK <= 2 * GS_KC) break;
+        }
+    }
+    switch (NK) {
+        case 6: launch_stream_inst<6>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb); break;
+        case 4: launch_stream_inst<4>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb); break;
+        case 2: launch_stream_inst<2>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb); break;
+        default: launch_stream_inst<1>(A, W, bias, out, M, N, K, lda, ldo, mode, st, part, S, stats, lng, lnb); break;
+    }
     return S;
 }
 void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out, int M, int N, int ldo, int mode, hipStream_t st) {
