@@ -1607,10 +1607,9 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
     static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
-        if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st);
+        if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st, fuse_ok ? w.stats : nullptr);
         else launch_gpt2_embed(w.d_tok, e->g_wte, e->g_wpe, M, nd, past, D, w.x, st);
-        if (step_state && fuse_ok) {
-            launch_gpt2_finalize(nullptr, 0, nullptr, w.x, P, D, w.stats, st);
+        if (step_state && fuse_ok) {      // (the embedding kernel left the first layer's LayerNorm statistics)
             for (int l = 0; l < nl; ++l) {
                 const auto& b = e->gblk[l];
                 float* kcl = w.kc + (size_t)l * P * Tmax * D;

@@ -20,15 +20,42 @@ __global__ void gpt2_embed_kernel(const int* tok, const float* wte, const float*
 }
 // single-token decode step inside a hipGraph: the step's state lives in device memory (state[0] = past length, state[1] = step
 // index), so ONE captured graph serves every step.  Tokens of the previous step are read from gen[(step - 1) * P + row].
-__global__ void gpt2_embed_step_kernel(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x) {
-    const int row = blockIdx.x;
+// stats != nullptr (fused step, D <= 1024): also the row's LayerNorm statistics {mean, rstd} for the first layer's fused LayerNorm — the
+// arithmetic of gpt2_finalize_kernel with 256 threads (two-pass mean / variance, lanes xor tree then waves 0..3).
+__global__ __launch_bounds__(256) void gpt2_embed_step_kernel(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D,
+                                                              float* x, float* stats) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int past = state[0], step = state[1];
     const float* te = wte + (long long)gen[(long long)(step - 1) * P + row] * D;
     const float* pe = wpe + (long long)past * D;
-    for (int i = threadIdx.x; i < D; i += blockDim.x) x[(long long)row * D + i] = te[i] + pe[i];
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!stats) {
+        for (int i = t; i < D; i += 256) x[(long long)row * D + i] = te[i] + pe[i];
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t + 256 * k;
+        if (i < D) { v[k] = te[i] + pe[i]; x[(long long)row * D + i] = v[k]; }
+    }
+    auto block_sum = [&](float q) {
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = q;
+        __syncthreads();
+        return ((red[0] + red[1]) + red[2]) + red[3];
+    };
+    const float mean = block_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = t + 256 * k < D ? v[k] - mean : 0.f; q += d * d; }
+    const float var = block_sum(q) / (float)D;
+    if (t == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(var + 1e-5f); }
 }
-void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st) {
-    hipLaunchKernelGGL(gpt2_embed_step_kernel, dim3(P), dim3(128), 0, st, gen, state, P, wte, wpe, D, x);
+void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st,
+                            float* stats) {
+    hipLaunchKernelGGL(gpt2_embed_step_kernel, dim3(P), dim3(256), 0, st, gen, state, P, wte, wpe, D, x, D <= 1024 ? stats : nullptr);
 }
 __global__ void gpt2_advance_kernel(int* state) {
     state[0] += 1;

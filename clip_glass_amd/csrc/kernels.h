@@ -120,7 +120,8 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
 void launch_gpt2_attention_step(const float* qkv, const float* part, int S, const float* bias, float* kc, float* vc, int P, int Tmax, int heads,
                                 float* out, hipStream_t st, const int* past_dev);
 void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr, float* scratch = nullptr);
-void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st);
+void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st,
+                            float* stats = nullptr);
 void launch_gpt2_advance(int* state, hipStream_t st);
 // NCHW fp32 image [n][3][S][S] -> CLIP patch matrix [n*G*G][3*ps*ps] fp16
 void launch_image_patches(const float* img, int n, int S, int ps, half_t* patches, hipStream_t st);
