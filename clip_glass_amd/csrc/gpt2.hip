@@ -178,7 +178,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
     if (e >= (long long)M * N) return;
     const int m = (int)(e / N), n = (int)(e - (long long)m * N);
     float v = 0.f;
-    for (int z = 0; z < S; ++z) v += part[((long long)z * M + m) * N + n];     // fixed order
+    for (int z0 = 0; z0 < S; z0 += 4) {        // four slices' loads in flight together; added in slice order
+        float pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pv[u] = z0 + u < S ? part[((long long)(z0 + u) * M + m) * N + n] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v += pv[u];
+    }
     v += bias ? bias[n] : 0.f;
     const long long oi = (long long)m * ldo + n;
     if (mode == 1) {
@@ -666,16 +672,25 @@ __global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* q
     const int past = *past_dev, ns = past + 1;
     const int D = heads * 64, seq = item / heads, h = item - seq * heads;
     float r[3];
+    if (part) {      // slices in groups of four: their 12 loads are in flight together (a loop of dependent single loads was 9 round trips)
+        float a[3] = {0.f, 0.f, 0.f};
+        for (int z0 = 0; z0 < S; z0 += 4) {
+            float pv[4][3];
 #pragma unroll
-    for (int w3 = 0; w3 < 3; ++w3) {
-        const int c = w3 * D + h * 64 + lane;
-        if (part) {
-            float a = 0.f;
-            for (int z = 0; z < S; ++z) a += part[((long long)z * P + seq) * 3 * D + c];
-            r[w3] = a + (bias ? bias[c] : 0.f);
-        } else {
-            r[w3] = qkv[(long long)seq * 3 * D + c];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w3 = 0; w3 < 3; ++w3)
+                    pv[u][w3] = z0 + u < S ? part[((long long)(z0 + u) * P + seq) * 3 * D + w3 * D + h * 64 + lane] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w3 = 0; w3 < 3; ++w3) a[w3] += pv[u][w3];          // (slice order per element; + 0 for the slices past S)
         }
+#pragma unroll
+        for (int w3 = 0; w3 < 3; ++w3) r[w3] = a[w3] + (bias ? bias[w3 * D + h * 64 + lane] : 0.f);
+    } else {
+#pragma unroll
+        for (int w3 = 0; w3 < 3; ++w3) r[w3] = qkv[(long long)seq * 3 * D + w3 * D + h * 64 + lane];
     }
     kc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[1];
     vc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[2];
@@ -713,15 +728,13 @@ __global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* q
     __builtin_amdgcn_wave_barrier();
     const float* vr = vc + (long long)seq * Tmax * D + h * 64 + lane;
     float a = 0.f;
-    int j = 0;
-    for (; j + 4 <= past; j += 4) {                   // four value rows in flight; the sum runs in key order
-        float vv[4];
+    for (int j0 = 0; j0 < past; j0 += 16) {           // sixteen value rows in flight (clamped row, zero weight past the history); key order
+        float vv[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vv[u] = vr[(long long)(j + u) * D];
+        for (int u = 0; u < 16; ++u) vv[u] = vr[(long long)min(j0 + u, past - 1) * D];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) a += ps[wave][j + u] * vv[u];
+        for (int u = 0; u < 16; ++u) a += (j0 + u < past ? ps[wave][j0 + u] : 0.f) * vv[u];
     }
-    for (; j < past; ++j) a += ps[wave][j] * vr[(long long)j * D];
     a += ps[wave][past] * r[2];
     out[(long long)seq * D + h * 64 + lane] = a;
 }
