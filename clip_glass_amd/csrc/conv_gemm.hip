@@ -61,7 +61,13 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
         px = 2 * px + (ph & 1);
     }
     f4 c = *(const f4*)(C + m * p.Neff + n);
-    for (int z = 1; z < S; ++z) c += *(const f4*)(C + z * slab + m * p.Neff + n);      // split-K slices, fixed order
+    if (S > 1) {                               // split-K slices (S <= 4): loaded together, added in slice order
+        f4 cz[3];
+#pragma unroll
+        for (int z = 1; z < 4; ++z) cz[z - 1] = z < S ? *(const f4*)(C + z * slab + m * p.Neff + n) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int z = 1; z < 4; ++z) c += cz[z - 1];
+    }
     const float nz = p.noise ? p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + py) * p.Wo + px] : 0.f;
     const long long oidx = (((long long)b * p.Ho + py) * p.Wo + px) * p.Cout + o;
     h4 r = {0, 0, 0, 0};

@@ -258,7 +258,13 @@ __global__ __launch_bounds__(256) void dense01_finish_kernel(const float* part, 
     float acc = 0.f;
     for (int n = t; n < N; n += 256) {
         float v = 0.f;
-        for (int z = 0; z < S; ++z) v += part[(long long)z * slab + (long long)p * N + n];
+        for (int z0 = 0; z0 < S; z0 += 8) {      // eight slices' loads in flight together, added in slice order
+            float pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pv[u] = z0 + u < S ? part[(long long)(z0 + u) * slab + (long long)p * N + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += pv[u];
+        }
         v = lrelu_sqrt2(v + (bias0 ? bias0[n] : 0.f));
         acc += v * w1[n];
     }
