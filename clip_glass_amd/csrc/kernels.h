@@ -32,7 +32,6 @@ void launch_pixelnorm(const float* z, float* out, int P, int L, float eps, hipSt
 // mode 0 none, 1 lrelu*sqrt2, 2 rsqrt(v + eps_row[p*eps_stride])
 void launch_dense01_finish(const float* part, int S, long long slab, const float* bias0, const float* w1, const float* b1, float* out, int P, int N,
                            hipStream_t st);
-void launch_splitk_finish(const float* part, int S, long long slab, const float* bias, float* out, int M, int N, int mode, hipStream_t st);
 void launch_dense_splitk(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias, float* out, int ldo,
                          int mode, hipStream_t st);   // K % 64 == 0, K <= 768: the mapping-network layers
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,

@@ -238,16 +238,6 @@ bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, c
     else hipLaunchKernelGGL(mapping_fused_kernel<2>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
     return true;
 }
-// out[m][n] = f(bias[n] + sum_z part[z][m][n]) — the fixed-order finish of a split-K product (mode 4: lrelu * sqrt2, else identity)
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* part, int S, long long slab, const float* bias, float* out, int MN, int N,
-                                                            int mode) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= MN) return;
-    float v = 0.f;
-    for (int z = 0; z < S; ++z) v += part[(long long)z * slab + e];
-    v += bias ? bias[e % N] : 0.f;
-    out[e] = mode == 4 ? lrelu_sqrt2(v) : v;
-}
 // D's head in one launch (stylegan2/models.py:1339-1350: dense CL -> CL + lrelu, dense CL -> 1): row p of the first layer is finished from
 // its split-K slices (bias, lrelu * sqrt2) and goes straight into the second layer's dot product — one workgroup per candidate, block sum
 // in a fixed order (lanes xor tree, then waves 0..3); the separate N = 1 dense launch walked K = 512 in one chain per thread (37 us).
@@ -276,9 +266,6 @@ __global__ __launch_bounds__(256) void dense01_finish_kernel(const float* part, 
 void launch_dense01_finish(const float* part, int S, long long slab, const float* bias0, const float* w1, const float* b1, float* out, int P, int N,
                            hipStream_t st) {
     hipLaunchKernelGGL(dense01_finish_kernel, dim3(P), dim3(256), 0, st, part, S, slab, bias0, w1, b1, out, N);
-}
-void launch_splitk_finish(const float* part, int S, long long slab, const float* bias, float* out, int M, int N, int mode, hipStream_t st) {
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, part, S, slab, bias, out, M * N, N, mode);
 }
 void launch_dense(const float* x, int ldx, int P, int K, const float* wt, int N, const float* bias,
                   float* out, int ldo, int in_sq, int mode, const float* eps_row, int eps_stride,
