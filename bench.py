@@ -139,11 +139,41 @@ def bench_gpt2(args):
                config=dict(workload="GPT2: GPT-2-small greedy decode (23-token context, 30 steps, fp32, KV cache, one hipGraph per single-"
                                     "token step) + CLIP ViT-B/32 text tower + cosine, pop=%d; host BPE round trip replaced by a fixed id "
                                     "mapping (no vocabulary files on the box)" % P, pop_per_gpu=P, device=device_info(0)["name"]),
+               gpu_active_s=dec_ms * 1e-3,      # device time of the decodes (hipEvents; the text tower's launches are not in it)
                roofline=dict(bound="hbm", kernel="gemm_f32_stream_kernel / gpt2_head_kernel (weight streaming, 30 steps)", achieved=gbs, peak=HBM_PEAK_GBS,
                              unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None, decode_ms_per_population=dec_ms / args.steps,
                              algorithmic_bytes_per_decode=bytes_per_decode))
     print(json.dumps(out))
     eng.close()
+
+
+def run_legs(args):
+    """`bench.py --config biggan512` and `--config gpt2` as child processes (fresh engines, --leg-steps timed steps each); their one-line
+    JSON results, trimmed to what identifies and prices the leg."""
+    import subprocess
+    legs = {}
+    for name, extra in (("biggan512", ["--warmup", "2", "--no-cpu-baseline"]), ("gpt2", ["--warmup", "1"])):
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.leg_steps), "--no-legs"] + extra,
+                               capture_output=True, text=True, timeout=600)
+            line = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+            if r.returncode != 0 or not line:
+                legs[name] = dict(error=(r.stderr or r.stdout)[-400:], returncode=r.returncode)
+                continue
+            d = json.loads(line[-1])
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "gpu_active_s")
+            leg = {k: d[k] for k in keep if k in d}
+            leg["config"] = d["config"]
+            rf = d.get("roofline", {})
+            leg["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms",
+                                                  "whole_pass_frac_of_mfma_peak", "whole_pass_tflops", "decode_ms_per_population",
+                                                  "algorithmic_bytes_per_decode") if k in rf}
+            leg["leg_wall_s"] = time.time() - t0
+            legs[name] = leg
+        except Exception as ex:       # a leg must never take the headline line down with it
+            legs[name] = dict(error=repr(ex)[:400])
+    return legs
 
 
 def main():
@@ -157,6 +187,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-pop", type=int, default=BATCH, help="candidates in the CPU baseline sample (multiple of 4; 64 = the whole headline population, ~4 min)")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--no-legs", action="store_true", help="headline only: skip the biggan512 / gpt2 legs attached to the default line")
+    ap.add_argument("--leg-steps", type=int, default=5)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -285,8 +317,10 @@ def main():
     eng.profile()
     sync()
     t0 = time.perf_counter()
+    gpu_ms = 0.0
     for s in range(args.steps):
         F_all = ev.evaluate_local(population(1000 * rank + 100 + s, P), generation=100 + s)
+        gpu_ms += eng.last_gpu_ms()         # hipEvent pair around the whole pass on the engine's main stream (engine.cpp run_pass)
         for r in eng.profile():
             a = prof.setdefault(r["name"], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
             for k in a:
@@ -383,9 +417,17 @@ def main():
                    scaling="weak", vs_baseline=None, dtype="f16", data="synthetic",
                    config=dict(workload=workload, pop_per_gpu=P, global_pop=P * world, batch_size=BATCH, parallelism="population-shard x%d" % world,
                                device="%(name)s, %(cus)d CUs" % device_info(local_rank), hbm_gib=round(device_info(local_rank)["hbm_bytes"] / 2 ** 30)),
-                   roofline=roofline)
+                   roofline=roofline,
+                   # device time of the timed region = sum over its steps of the hipEvent interval around each pass (H2D of the latents
+                   # ... D2H of F): checkable against `ms_per_step` even when an smi sampler misses the ~1 s window
+                   gpu_active_s=gpu_ms * 1e-3, gpu_active_frac_of_timed_region=gpu_ms * 1e-3 / dt)
         if world == 1 and not args.no_cpu_baseline and not biggan:
             out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH))
+        if world == 1 and args.config == "ffhq" and not args.no_legs and dist is None:
+            # the other single-GPU configs of BASELINE.json (configs[2] DeepMindBigGAN512, configs[4] GPT2) as short legs of the
+            # same driver-run line, each with its own roofline; the headline engine is closed first
+            eng.close()
+            out["legs"] = run_legs(args)
         if os.environ.get("GLASS_BENCH_DETAIL"):
             with open(os.environ["GLASS_BENCH_DETAIL"], "w") as f:
                 wk = {}

@@ -337,6 +337,7 @@ void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
     GemmParams q;
     memset(&q, 0, sizeof q);   // logits = theta . phi^T  (fp32 out)
     q.a = g.a_theta; q.w = g.a_phi; q.M = hw; q.N = hq; q.K = c8; q.mode = 3; q.out32 = g.a_S; q.ldo = hq;
+    q.cand_batch = 1;
     q.batch = B; q.a_bs = (long long)hw * c8; q.w_bs = (long long)hq * c8; q.o_bs = (long long)hw * hq;
     {
         Prof pr(e, "bg.attn.logits", 2.0 * B * hw * (double)hq * c8, B * (2.0 * hw * c8 + 2.0 * hq * c8 + 4.0 * hw * hq));
@@ -350,6 +351,7 @@ void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
     }
     memset(&q, 0, sizeof q);   // attn_g = P . g^T
     q.a = g.a_P; q.w = g.a_gT; q.M = hw; q.N = c2; q.K = hq; q.mode = 0; q.out16 = g.a_O; q.ldo = c2;
+    q.cand_batch = 1;
     q.batch = B; q.a_bs = (long long)hw * hq; q.w_bs = (long long)c2 * hq; q.o_bs = (long long)hw * c2;
     {
         Prof pr(e, "bg.attn.values", 2.0 * B * hw * (double)hq * c2, B * (2.0 * hw * hq + 2.0 * hq * c2 + 2.0 * hw * c2));

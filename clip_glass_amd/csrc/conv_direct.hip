@@ -170,14 +170,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
     if (p.w_bstride != 0) return nullptr;  // per-sample weights are a tiled / up-conv-only path: refuse, the caller reports it
     const long long M = (long long)p.B * p.Hc * p.Wc;
-    if (p.Neff > 64 && ((M + 127) / 128) * ((p.Neff + 127) / 128) >= 256) {   // enough 128 x 128 blocks to fill the chip: row-parallel
+    // instance choice at the NOMINAL population (common.h): the row-parallel and the split-K forms sum in different orders
+    const long long Mn = (long long)GLASS_NOMINAL_POP * p.Hc * p.Wc;
+    if (p.Neff > 64 && ((Mn + 127) / 128) * ((p.Neff + 127) / 128) >= 256) {   // enough 128 x 128 blocks to fill the chip: row-parallel
         hipLaunchKernelGGL((conv_direct_kernel<4, false>), dim3((unsigned)((M + 127) / 128), (p.Neff + 127) / 128), dim3(256), 0,
                            st, p);
         return "conv_direct_kernel<4,rows>";
     }
     const unsigned gx = (unsigned)((M + 31) / 32);
     // wide n tiles re-use the activation fragment; narrow ones give small problems more blocks
-    if (p.Neff > 64 && (long long)gx * ((p.Neff + 127) / 128) >= 512) {
+    if (p.Neff > 64 && ((Mn + 31) / 32) * ((p.Neff + 127) / 128) >= 512) {
         hipLaunchKernelGGL((conv_direct_kernel<4, true>), dim3(gx, (p.Neff + 127) / 128), dim3(256), 0, st, p);
         return "conv_direct_kernel<4>";
     }

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_kernel(DownParams p, int til
 
 bool conv_down_supported(int R, int Cin, int Cout) {
     static const bool off = getenv("GLASS_NO_DOWN") != nullptr;   // A/B knob
-    return !off && R % 64 == 0 && R >= 64 && Cin == CIN && Cout == NT && (long long)R * R * Cin < (1LL << 31);
+    return !off && glass_lds_fits(LDS_BYTES) && R % 64 == 0 && R >= 64 && Cin == CIN && Cout == NT && (long long)R * R * Cin < (1LL << 31);
 }
 
 // Returns the kernel symbol, or nullptr when the block does not qualify (caller runs the separate passes).
@@ -333,7 +333,10 @@ const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1
     p.trace = nullptr;
     static const bool row_walk = getenv("GLASS_ROW_WALK") != nullptr;
     p.row_walk = row_walk ? 1 : 0;
-    const char* trace_path = getenv("GLASS_DOWN_TRACE");     // dev tool: per-phase shader-clock timestamps of workgroup 0
+    const char* trace_path = nullptr;
+#ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): per-phase shader-clock timestamps of workgroup 0; synchronises, single engine only
+    trace_path = getenv("GLASS_DOWN_TRACE");
+#endif
     if (trace_path) (void)hipMalloc(&p.trace, 64 * 8 * 4 * sizeof(unsigned long long));
     if (p.trace) (void)hipMemsetAsync(p.trace, 0, 64 * 8 * 4 * sizeof(unsigned long long), st);
     const int Ro = R / 2, tiles_x = Ro / 32, tiles_y = Ro / TH;

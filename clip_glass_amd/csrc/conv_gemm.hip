@@ -109,6 +109,7 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
     g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]; (kpt: any M is accepted —
                                                                       // the kernel choice must not depend on the candidate count)
     g.mode = 3; g.out32 = ws_c; g.ldo = p.Neff;
+    g.cand_rows = p.Hc * p.Wc;
     // split-K (round 3): a 4 x 4 / 8 x 8 grid per candidate is 16 / 64 rows — at 64 candidates the product has 64 / 256 tiles walking
     // 72 K steps each.  S slices (a function of the per-candidate geometry only, like every choice here) of raw sums, added in a fixed
     // order by the finishing pass; the scratch holds them while S x grid x Neff fits its per-candidate capacity.

@@ -641,7 +641,10 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
     }
-    if (TW == 32 && !no_persist && (p.Cin & 63) == 0 && PT8 * NTn >= 2 * n_cu) {   // ring parity needs an even chunk count
+    // (>= 2 work items per CU at the NOMINAL population, common.h: this branch also decides whether the blur-down by-product exists,
+    // so it must be a function of the layer geometry only)
+    const long long work_nominal = (long long)GLASS_NOMINAL_POP * tiles_x * tiles_y * NTn;
+    if (TW == 32 && !no_persist && (p.Cin & 63) == 0 && work_nominal >= 2 * n_cu) {   // ring parity needs an even chunk count
         // (reported under the symbol that runs, so that the per-kernel profile lines up with rocprofv3's kernel names)
         const char* pname = (p.xs_out && !TRGB) ? "conv_gldsp_kernel<false,true>" : (TRGB ? "conv_gldsp_kernel<true>" : "conv_gldsp_kernel<false>");
         if (p.dry_run) return pname;
@@ -660,6 +663,7 @@ const char* launch_conv_glds(const ConvParams& p0, hipStream_t st, bool force) {
     static const int dbg = getenv("GLASS_GLDS_DBG") ? atoi(getenv("GLASS_GLDS_DBG")) : 0;    // timing experiments only (wrong results)
     if (dbg) p.no_tstore = dbg;
     static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
+    if (!glass_lds_fits(Geo<32>::LDS_BYTES) || !glass_lds_fits(Geo<16>::LDS_BYTES)) return nullptr;
     if ((!on && !force) || p.up || (p.xs_out && (p.sn || p.trgb_yout || p.Wc % 32 != 0)) || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;

@@ -380,20 +380,26 @@ const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
     if (p.H != 2 * p.Hc + 1 || p.W != 2 * p.Wc + 1 || p.Ho != p.Hc || p.Wo != p.Wc || p.w_bstride != 0) return nullptr;
     if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Neff * p.Cin >= (1LL << 31) || (long long)p.Ho * p.Wo * p.Cin >= (1LL << 31)) return nullptr;
+    if (!glass_lds_fits(LDS_BYTES)) return nullptr;          // 162 880 B: conv_tiled<3,2,..,skip> where the device offers less
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int n_work = ((PT + 7) & ~7) * NTn;
     const int n_cu = glass_cu_count() - glass_cu_count() % 8;          // a workgroup keeps its XCD (id % 8) across items
-    if (n_work < n_cu && !force) return nullptr;                        // too small to fill the chip with one workgroup per CU
+    // too small to fill the chip with one workgroup per CU — judged at the nominal population (common.h), so that a layer runs on the
+    // same kernel whatever the size of this launch
+    if ((long long)GLASS_NOMINAL_POP * tiles_x * tiles_y * NTn < n_cu && !force) return nullptr;
     const int grid = n_work < n_cu ? n_work : n_cu;                     // (n_work is a multiple of 8)
     if (p.dry_run) return "conv_s2_kernel";
     static DevOnce once;
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#ifdef GLASS_DEV_TRACE
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#endif
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     }
+#ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps to a file; synchronises, single engine only
     if (const char* tp = getenv("GLASS_S2_TRACE")) {          // dev tool: traced instance, stamps to a file
         unsigned long long* dtr = nullptr;
         constexpr int NTR = 96 * 8 * 8;
@@ -417,6 +423,7 @@ const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
         }
         return "conv_s2_kernel<trace>";
     }
+#endif
     static const bool no_il = getenv("GLASS_S2_NO_IL") != nullptr;     // A/B knob: every DMA of a stage issued before its MFMAs
     if (no_il) {
         hipLaunchKernelGGL((conv_s2_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);

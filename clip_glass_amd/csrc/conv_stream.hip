@@ -457,6 +457,7 @@ static int stream_slots() {
 bool conv_stream_applies(const ConvParams& p) {
     static const bool off = getenv("GLASS_NO_STREAM") != nullptr;   // experiment knob
     const bool trgb = p.trgb_yout != nullptr;
+    if (!glass_lds_fits(LDS_BYTES)) return false;
     if (off || p.up || p.xs_out || p.y32 || (!p.y && !trgb) || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return false;
     const bool frgb = p.rgb_y != nullptr;
     if (frgb && (!p.rgb_w || !p.rgb_b || (!p.rgb_x_out && !p.rgb_xs_out) || p.sn || trgb)) return false;
@@ -465,8 +466,10 @@ bool conv_stream_applies(const ConvParams& p) {
     if (p.in_up || (frgb && p.shift)) return false;
     if (p.Wc % 32 != 0 || p.Hc % TH != 0 || p.W >= 256 * 32 || (!frgb && p.x_bstride == 0 && p.B > 1)) return false;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return false;
-    const int PT = p.B * (p.Wc / 32) * (p.Hc / TH);
-    return PT >= stream_slots() * 6;           // streaming only pays with many tiles per workgroup
+    // streaming only pays with many tiles per workgroup — judged at the nominal population (common.h), not at this launch's B:
+    // the choice between this kernel and conv_tiled (different epilogue rounding) must not depend on chunking or sharding
+    const long long PT_nominal = (long long)GLASS_NOMINAL_POP * (p.Wc / 32) * (p.Hc / TH);
+    return PT_nominal >= (long long)stream_slots() * 6;
 }
 
 const char* launch_conv_stream(const ConvParams& p0, hipStream_t st) {
@@ -483,6 +486,7 @@ const char* launch_conv_stream(const ConvParams& p0, hipStream_t st) {
     const int per_block = (PT + slots - 1) / slots;
     const int grid = (PT + per_block - 1) / per_block;
     const char* name = frgb ? "conv_stream_kernel<fromrgb>" : trgb ? "conv_stream_kernel<torgb>" : "conv_stream_kernel";
+#ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, one launch, timestamps to a file; synchronises, single engine only
     if (const char* trace_path = getenv("GLASS_STREAM_TRACE")) {       // dev tool: traced instance, one launch, timestamps to a file
         unsigned long long* dtr = nullptr;
         (void)hipMalloc(&dtr, 64 * 8 * 4 * sizeof(unsigned long long));
@@ -511,6 +515,7 @@ const char* launch_conv_stream(const ConvParams& p0, hipStream_t st) {
         }
         return name;
     }
+#endif
     if (frgb) hipLaunchKernelGGL((conv_stream_kernel<true, false, false>), dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);
     else if (trgb) hipLaunchKernelGGL((conv_stream_kernel<false, true, false>), dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);
     else hipLaunchKernelGGL((conv_stream_kernel<false, false, false>), dim3(grid), dim3(256), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_block);

@@ -555,6 +555,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     constexpr int A_BYTES = ((PH * PW * ROWB + 15) / 16) * 16;
     constexpr int LDS_K = A_BYTES + KS * NT * ROWB, LDS_O = 4 * (SPL ? TH / 2 : TH / 4) * 32 * ((SPL ? NT / 64 : NT / 32) * 64 + 16);   // K-loop images | epilogue image
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
+    if (!glass_lds_fits(LDS)) return nullptr;
     static DevOnce once;                       // (one per template instance)
     if (once.first() && LDS > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>,
@@ -629,10 +630,16 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
         if (KS != 3 || S != 2 || p.pad != 0 || !p.skip_w || p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.up ||
             (p.Cout & 7) || p.no_tstore || p.Hc % 4 != 0)
             return nullptr;
-        if (!getenv("GLASS_TILED_TRACE"))
+#ifdef GLASS_DEV_TRACE
+        static const bool tiled_trace = getenv("GLASS_TILED_TRACE") != nullptr;
+#else
+        constexpr bool tiled_trace = false;
+#endif
+        if (!tiled_trace)
             if (const char* k = launch_conv_s2(p, st)) return k;        // LDS-DMA ring kernel where its geometry applies
         static const bool spl = getenv("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
         if (spl && deep_on == 2 && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,b2,deep>");
+#ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps of one mid-grid workgroup to a file; synchronises, single engine only
         if (const char* tp = getenv("GLASS_TILED_TRACE")) {      // dev tool: traced instance, stamps of one mid-grid workgroup to a file
             if (spl && p.Neff % 128 == 0 && !p.dry_run) {
                 unsigned long long* dtr = nullptr;
@@ -657,6 +664,7 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
                 return nm;
             }
         }
+#endif
         if (spl && deep_on && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,deep>");
         if (spl && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl>");
         if (p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip>");

@@ -771,6 +771,10 @@ void collect_profile(glass_engine* e) {
 }
 
 void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes) {
+    if (!(p.out_scale > 0.f)) {   // the epilogues fold the scale into the activation constants, max(v k1, v k2) (common.h act_apply): s > 0 only
+        if (e->launch_error.empty()) e->launch_error = std::string("out_scale must be positive: ") + tag;
+        return;
+    }
     Prof pr(e, tag, flops, bytes);
     const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
     if (!k) k = launch_conv_stream(p, e->cur);
@@ -1177,7 +1181,7 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     GemmParams g;
     memset(&g, 0, sizeof g);
     g.a = e->d_dfin; g.w = e->d_dense0_w; g.M = P; g.N = CL; g.K = 16 * CL; g.bias = e->d_dense0_b; g.mode = 4;
-    g.out32 = e->d_dh; g.ldo = CL;
+    g.out32 = e->d_dh; g.ldo = CL; g.cand_rows = 1;
     // M = P rows, K = 16 CL = 8192: the 128 x 64 tiles are 8 workgroups walking 128 K steps each (97 us for 0.5 GFLOP).  Split K into 16
     // slices (blockIdx.z) with raw partial sums, finished in a fixed order with bias + activation: 128+ workgroups, 8 steps each.
     static const bool no_d0_split = getenv("GLASS_NO_DENSE0_SPLIT") != nullptr;   // A/B knob
@@ -1207,7 +1211,7 @@ void run_clip(glass_engine* e, int P) {
     const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, M = P * T;
     GemmParams g;
     memset(&g, 0, sizeof g);
-    g.a = e->d_patches; g.w = e->c_patch_w; g.M = P * G * G; g.N = W; g.K = 3 * ps * ps; g.mode = 3; g.out32 = e->d_pe; g.ldo = W;
+    g.a = e->d_patches; g.w = e->c_patch_w; g.M = P * G * G; g.N = W; g.K = 3 * ps * ps; g.mode = 3; g.out32 = e->d_pe; g.ldo = W; g.cand_rows = G * G;
     run_gemm(e, g, "clip.patch_embed");
     {
         Prof pr(e, "clip.embed_lnpre", 0, 8.0 * M * W);
@@ -1219,24 +1223,24 @@ void run_clip(glass_engine* e, int P) {
             launch_layernorm(e->d_x, W, M, W, b.ln1_g, b.ln1_b, e->d_ln16, nullptr, e->cur);
         }
         memset(&g, 0, sizeof g);
-        g.a = e->d_ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = e->d_qkv; g.ldo = 3 * W;
+        g.a = e->d_ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = e->d_qkv; g.ldo = 3 * W; g.cand_rows = T;
         run_gemm(e, g, "clip.qkv");
         {
             Prof pr(e, "clip.attention", 4.0 * P * c.clip_heads * (double)T * T * 64, 8.0 * M * W);
             launch_attention(e->d_qkv, P, T, c.clip_heads, 64, 0, e->d_attn, e->cur);
         }
         memset(&g, 0, sizeof g);
-        g.a = e->d_attn; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = e->d_x; g.ldo = W;
+        g.a = e->d_attn; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = e->d_x; g.ldo = W; g.cand_rows = T;
         run_gemm(e, g, "clip.attn_out");
         {
             Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
             launch_layernorm(e->d_x, W, M, W, b.ln2_g, b.ln2_b, e->d_ln16, nullptr, e->cur);
         }
         memset(&g, 0, sizeof g);
-        g.a = e->d_ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = e->d_hid; g.ldo = 4 * W;
+        g.a = e->d_ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = e->d_hid; g.ldo = 4 * W; g.cand_rows = T;
         run_gemm(e, g, "clip.mlp_fc");
         memset(&g, 0, sizeof g);
-        g.a = e->d_hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = e->d_x; g.ldo = W;
+        g.a = e->d_hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = e->d_x; g.ldo = W; g.cand_rows = T;
         run_gemm(e, g, "clip.mlp_proj");
     }
     {
@@ -1260,6 +1264,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     REQUIRE(e->cfg.n_blocks > 0 || biggan, GLASS_ERR_STATE, "this engine was created without a GAN (n_blocks = 0)");
     if (out_F) REQUIRE(e->has_target, GLASS_ERR_STATE, "set_target() first");
     GLASS_HIP(hipSetDevice(c.device));
+    e->launch_error.clear();      // (a pass that returned early through GLASS_HIP must not leave its message to the next one)
     const int L = c.latent_size;
     memcpy(e->h_pinned, latents, (size_t)P * L * sizeof(float));
     GLASS_HIP(hipEventRecord(e->ev0, e->cur));
@@ -1301,7 +1306,8 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     }
     // device-generated noise planes depend on nothing but (seed, generation, minibatch, layer): their 17 short launches run on the
     // second stream next to the mapping network / style / demodulation chain instead of ahead of it
-    const bool noise_ov = e->clip_overlap && c.noise_mode == 1 && !getenv("GLASS_NO_NOISE_OVERLAP");
+    static const bool no_noise_ov = getenv("GLASS_NO_NOISE_OVERLAP") != nullptr;      // A/B knob, read once
+    const bool noise_ov = e->clip_overlap && c.noise_mode == 1 && !no_noise_ov;
     int rc;
     if (noise_ov) {
         e->cur = e->stream_d;
@@ -1491,18 +1497,18 @@ extern "C" int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, 
     for (auto& b : e->tblk) {
         launch_layernorm(x, W, M, W, b.ln1_g, b.ln1_b, ln16, nullptr, st);
         memset(&g, 0, sizeof g);
-        g.a = ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = qkv; g.ldo = 3 * W;
+        g.a = ln16; g.w = b.w_qkv; g.M = M; g.N = 3 * W; g.K = W; g.bias = b.b_qkv; g.mode = 0; g.out16 = qkv; g.ldo = 3 * W; g.cand_rows = ctx;
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
         launch_attention(qkv, n_texts, ctx, heads, 64, 1, att, st);
         memset(&g, 0, sizeof g);
-        g.a = att; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = x; g.ldo = W;
+        g.a = att; g.w = b.w_out; g.M = M; g.N = W; g.K = W; g.bias = b.b_out; g.mode = 2; g.out32 = x; g.ldo = W; g.cand_rows = ctx;
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
         launch_layernorm(x, W, M, W, b.ln2_g, b.ln2_b, ln16, nullptr, st);
         memset(&g, 0, sizeof g);
-        g.a = ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = hid; g.ldo = 4 * W;
+        g.a = ln16; g.w = b.w_fc; g.M = M; g.N = 4 * W; g.K = W; g.bias = b.b_fc; g.mode = 1; g.out16 = hid; g.ldo = 4 * W; g.cand_rows = ctx;
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
         memset(&g, 0, sizeof g);
-        g.a = hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = x; g.ldo = W;
+        g.a = hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = x; g.ldo = W; g.cand_rows = ctx;
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
     }
     for (int n = 0; n < n_texts; ++n)   // ln_final on the EOT row of each text only (row-wise op)
@@ -1555,8 +1561,26 @@ static void gpt2_work_free(glass_engine* e) {
     w = glass_engine::Gpt2Work();
 }
 
+static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P, int32_t nctx, int32_t length, int32_t* out_tokens);
+
+// Sequences are independent, and the single-token step kernels hold at most 64 rows: a longer population is decoded in row groups of
+// 64, each through exactly the launches a 64-row call makes — a row's tokens do not depend on how many rows the call (or a shard) holds.
 extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context, int32_t P, int32_t nctx, int32_t length,
                                         int32_t* out_tokens) {
+    REQUIRE(e && context && out_tokens && P > 0 && nctx > 0 && length > 0, GLASS_ERR_ARG, "bad argument");
+    float total_ms = 0.f;
+    for (int g0 = 0; g0 < P; g0 += 64) {
+        const int rc = gpt2_decode_group(e, context + (size_t)g0 * nctx, std::min(64, P - g0), nctx, length,
+                                         out_tokens + (size_t)g0 * (nctx + length));
+        if (rc) return rc;
+        total_ms += e->gwork.last_ms;
+    }
+    e->gwork.last_ms = total_ms;
+    e->last_ms = total_ms;
+    return GLASS_OK;
+}
+
+static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P, int32_t nctx, int32_t length, int32_t* out_tokens) {
     REQUIRE(e && context && out_tokens && P > 0 && nctx > 0 && length > 0, GLASS_ERR_ARG, "bad argument");
     REQUIRE(e->finalized, GLASS_ERR_STATE, "finalize() first");
     REQUIRE(e->g_wte != nullptr, GLASS_ERR_STATE, "GPT-2 weights were not loaded (gpt2.transformer.*)");
@@ -1603,7 +1627,9 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
     // split-K slices of the residual products finished together with the residual add and the next statistics: 9 launches per layer
     // instead of 11 (complete-output products — 72 / 24 / 96 workgroups walking three chunks each — were 21 us against 9 + 4: dropped)
     static const bool no_fuse = getenv("GLASS_GPT2_NO_FUSE") != nullptr;
-    const bool fuse_ok = !no_fuse && P <= 64 && D % 64 == 0 && D <= 1024;
+    // (the launcher's own shape conditions, asked through the launcher's predicate: a product it refuses returns 0 slices and nothing written)
+    const bool fuse_ok = !no_fuse && gemm_f32_step_supported(P, D, D, true) && gemm_f32_step_supported(P, 4 * D, 4 * D, false);
+    bool step_refused = false;
     static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
@@ -1615,6 +1641,7 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
                 float* kcl = w.kc + (size_t)l * P * Tmax * D;
                 float* vcl = w.vc + (size_t)l * P * Tmax * D;
                 int S = launch_gemm_f32_step(w.x, b.w_qkv, b.b_qkv, w.qkv, P, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems, w.stats, b.ln1_g, b.ln1_b);
+                step_refused |= S == 0;
                 if (Tmax <= 64 && !no_attn_step) {      // one wave per (sequence, head); it sums the product's slices itself
                     launch_gpt2_attention_step(w.qkv, S > 1 ? w.part : nullptr, S, b.b_qkv, kcl, vcl, P, Tmax, heads, w.att, st, step_state);
                 } else {
@@ -1622,16 +1649,20 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
                     launch_gpt2_attention(w.qkv, kcl, vcl, P, 1, past, Tmax, heads, w.att, st, step_state);
                 }
                 S = launch_gemm_f32_step(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
+                step_refused |= S == 0;
                 launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_o, w.x, P, D, w.stats, st);       // residual + LayerNorm 2 statistics
                 S = launch_gemm_f32_step(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, w.stats, b.ln2_g, b.ln2_b);
+                step_refused |= S == 0;
                 if (S > 1) launch_gpt2_reduce(w.part, S, b.b_fc, w.hid, P, 4 * D, 4 * D, 1, st);
                 S = launch_gemm_f32_step(w.hid, b.w_pr, b.b_pr, w.x, P, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
+                step_refused |= S == 0;
                 launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_pr, w.x, P, D, w.stats, st);      // residual + next LayerNorm's statistics
             }
             static const bool no_head = getenv("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
             if (no_head || !launch_gpt2_head(w.x, e->g_wte, P, V, D, D, w.stats, e->g_lnf_g, e->g_lnf_b, nullptr, w.pairs, w.d_gen, w.d_state, st)) {
                 // ln_f fused; the real vocabulary (1571 column blocks) is never split, a small one may be
                 const int S = launch_gemm_f32_step(w.x, e->g_wte, nullptr, w.logits, P, V, D, D, V, 0, st, w.part, w.part_elems, w.stats, e->g_lnf_g, e->g_lnf_b);
+                step_refused |= S == 0;
                 if (S > 1) launch_gpt2_reduce(w.part, S, nullptr, w.logits, P, V, V, 0, st);
                 launch_argmax(w.logits, P, V, w.d_gen, st, w.d_state, w.stats + 2 * P);
             }
@@ -1643,12 +1674,12 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
             float* kcl = w.kc + (size_t)l * P * Tmax * D;
             float* vcl = w.vc + (size_t)l * P * Tmax * D;
             launch_layernorm(w.x, D, M, D, b.ln1_g, b.ln1_b, nullptr, w.ln, st);
-            launch_gemm_f32(w.ln, b.w_qkv, b.b_qkv, w.qkv, M, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems);
+            launch_gemm_f32(w.ln, b.w_qkv, b.b_qkv, w.qkv, M, 3 * D, D, D, 3 * D, 0, st, w.part, w.part_elems, nd > 1);
             launch_gpt2_attention(w.qkv, kcl, vcl, P, nd, past, Tmax, heads, w.att, st, step_state);
-            launch_gemm_f32(w.att, b.w_o, b.b_o, w.x, M, D, D, D, D, 2, st, w.part, w.part_elems);
+            launch_gemm_f32(w.att, b.w_o, b.b_o, w.x, M, D, D, D, D, 2, st, w.part, w.part_elems, nd > 1);
             launch_layernorm(w.x, D, M, D, b.ln2_g, b.ln2_b, nullptr, w.ln, st);
-            launch_gemm_f32(w.ln, b.w_fc, b.b_fc, w.hid, M, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems);
-            launch_gemm_f32(w.hid, b.w_pr, b.b_pr, w.x, M, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems);
+            launch_gemm_f32(w.ln, b.w_fc, b.b_fc, w.hid, M, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, nd > 1);
+            launch_gemm_f32(w.hid, b.w_pr, b.b_pr, w.x, M, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems, nd > 1);
         }
         // ln_f on the last position of each sequence, tied lm_head, greedy pick -> d_gen[step][P]
         launch_layernorm(w.x + (size_t)(nd - 1) * D, (long long)nd * D, P, D, e->g_lnf_g, e->g_lnf_b, nullptr, w.last, st);
@@ -1695,6 +1726,11 @@ extern "C" int glass_engine_gpt2_decode(glass_engine* e, const int32_t* context,
         gpt2_work_free(e);
         glass_set_error(std::string("gpt2_decode failed: ") + hipGetErrorString(err));
         return GLASS_ERR_HIP;
+    }
+    if (step_refused) {        // fuse_ok and the launcher disagreed about a shape: buffers were consumed unwritten — never a silent result
+        gpt2_work_free(e);
+        glass_set_error("gpt2_decode: a fused step product refused its shape (launch_gemm_f32_step returned 0)");
+        return GLASS_ERR_STATE;
     }
     (void)hipEventElapsedTime(&w.last_ms, e->ev0, e->ev1);
     e->last_ms = w.last_ms;

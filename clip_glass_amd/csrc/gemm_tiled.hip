@@ -145,7 +145,11 @@ const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     // 128-wide n tiles under-fill the chip on the N = 768 CLIP linears (25 x 6 = 150 workgroups for 256 CUs): take 64-wide
     // tiles whenever the 128-wide grid has fewer workgroups than CUs
     static const bool wide_only = getenv("GLASS_GEMM_BN128") != nullptr;   // A/B knob
-    const bool fills = (long long)gx * (p.N / 128) * gz >= 256;
+    // (evaluated at the nominal population where the caller says how M / the batch scale with it — the instances are bit-identical
+    // per output element, the rule just never looks at the launch size)
+    const long long gx_n = p.cand_rows ? ((long long)p.cand_rows * GLASS_NOMINAL_POP + 127) / 128 : gx;
+    const long long gz_n = p.cand_batch ? GLASS_NOMINAL_POP : gz;
+    const bool fills = gx_n * (p.N / 128) * gz_n >= 256;
     if (p.N % 128 == 0 && (fills || wide_only)) {
         hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<128>";

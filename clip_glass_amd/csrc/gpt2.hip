@@ -492,9 +492,12 @@ bool launch_gpt2_head(const float* A, const float* W, int M, int N, int K, int l
 // the global split S: S == 1: bias / mode were applied by the kernel; S > 1: raw sums are in `part` (splitk_reduce_kernel via
 // launch_gpt2_reduce, or gpt2_finalize_kernel for the residual products).  stats != nullptr: LayerNorm fused on the activation operand
 // (K <= 1024).  Returns 0 when the shape does not fit (caller: unfused path).
+bool gemm_f32_step_supported(int M, int K, int lda, bool ln_fused) {
+    return M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && !(ln_fused && K > 1024);
+}
 int launch_gemm_f32_step(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
                          hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb) {
-    if (M > 64 || K % GS_KC != 0 || lda % 4 != 0 || (stats && K > 1024)) return 0;
+    if (!gemm_f32_step_supported(M, K, lda, stats != nullptr)) return 0;
     const int nb = (N + 31) / 32;
     // K = C chunks of 64 = S global slices x NK parts inside a workgroup (one chunk per wave).  Of the factorizations with NK in
     // {1, 2, 4, 6} take the one with the most workgroups that still fit the chip in ONE round (nb * S <= CUs: 288 workgroups on 256 CUs
@@ -540,9 +543,9 @@ void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out,
 }
 // `part`: scratch for split-K partial sums (nullable = never split); sized by the caller for GPT2_SPLITK_MAX slices of M x N.
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
-                     int mode, hipStream_t st, float* part, size_t part_elems) {
+                     int mode, hipStream_t st, float* part, size_t part_elems, bool prefill) {
     static const bool no_stream = getenv("GLASS_GPT2_NO_STREAM") != nullptr;      // A/B knob: round 2's gemm_f32_kernel<64,64> for the steps
-    if (M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && !no_stream) {
+    if (!prefill && M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && !no_stream) {
         // a workgroup per 32 weight rows; global K split S (small: the partial sums are traffic) x NK K parts inside the workgroup so
         // that a wave's share is one or two 64-deep chunks; the vocabulary projection (1571 workgroups) is not split globally
         const int nb = (N + 31) / 32;
@@ -563,7 +566,7 @@ void launch_gemm_f32(const float* A, const float* W, const float* bias, float* o
                                M, N, ldo, mode);
         return;
     }
-    if (M <= 64) {
+    if (!prefill && M <= 64) {
         // single-token steps stream each weight once: what matters is how many workgroups pull on HBM.  N / 64 column tiles
         // alone are 12 workgroups at N = 768: split K until ~256 workgroups are live.
         const int tiles = (N + 63) / 64;

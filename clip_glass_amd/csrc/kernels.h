@@ -104,8 +104,11 @@ void launch_bg_rgb_tanh(const half_t* x, int B, long long hw, int C, float* y, h
 void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
                        hipStream_t st);
 // part / part_elems: split-K scratch for the single-token (M <= 64) steps (nullptr = never split)
+// prefill: the rows are P sequences x nd > 1 positions — always the tiled kernels, so that the kernel (and with it the summation order)
+// a sequence's prefill runs on does not depend on how many sequences the launch holds
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
-                     int mode, hipStream_t st, float* part = nullptr, size_t part_elems = 0);
+                     int mode, hipStream_t st, float* part = nullptr, size_t part_elems = 0, bool prefill = false);
+bool gemm_f32_step_supported(int M, int K, int lda, bool ln_fused);   // launch_gemm_f32_step's shape conditions
 // fused single-token step (round 3): products with LayerNorm on the activation operand / complete outputs, and the residual + statistics pass
 int launch_gemm_f32_step(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
                          hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb);

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(1024) void mapping_fused_kernel(const float* z, flo
 bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, const float* const* wt, const float* const* b, int n_layers,
                           hipStream_t st) {
     if ((L != 256 && L != 512) || n_layers < 1 || n_layers > 8) return false;
+    if (!glass_lds_fits((int)((4 + 64) * L * sizeof(float)))) return false;     // 136 KB at L = 512: per-layer path where the opt-in is smaller
     MapDesc d;
     d.n = n_layers;
     for (int i = 0; i < n_layers; ++i) { d.wt[i] = wt[i]; d.b[i] = b[i]; }

@@ -65,6 +65,7 @@ int finish() {
 extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     OPREQ(d && d->x && d->w && d->y, "null argument");
     OPREQ(d->Cin % 16 == 0, "Cin must be a multiple of 16");
+    OPREQ(d->out_scale > 0.f, "out_scale must be positive (the epilogues fold it into the activation constants: max(v k1, v k2))");
     GLASS_HIP(hipSetDevice(device));
     Dev dv;
     ConvParams p;

@@ -731,6 +731,7 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
     if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
     constexpr int LDS = U_LDS;
+    if (!glass_lds_fits(LDS)) return nullptr;                 // (the caller falls through to upfir_kernel / the folded form)
     static DevOnce once;
     if (once.first()) {
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -803,6 +804,7 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
 
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     constexpr int LDS = 64 * 1024;  // T tile (16*64*32*2 B); staging (31.5 KB) lives inside it
+    if (!glass_lds_fits(LDS)) return nullptr;
     static DevOnce once;
     if (once.first()) (void)hipFuncSetAttribute((const void*)upfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     const int tiles_y = (p.Ho + 11) / 12, tiles_x = (p.Wo + 59) / 60;

@@ -154,7 +154,8 @@ class Generator:
         self.engine.set_target(self.text_features[0])
         if sharded:
             from .parallel import ShardedEvaluator
-            self.sharder = ShardedEvaluator(self.engine, dist, dist.get_rank(), dist.get_world_size(), config.batch_size)
+            self.sharder = ShardedEvaluator(self.engine, dist, dist.get_rank(), dist.get_world_size(), config.batch_size,
+                                            device=device)
 
     def clip_similarity_texts(self, texts):
         """generator.py:52-59 (img2txt branch): tokenize -> encode_text -> cosine vs the target image feature;

@@ -21,14 +21,11 @@ class StyleGAN2LatentSpace:
 
     __call__ = forward
 
-    def state_dict(self):       # run.py:101 (the reference's nn.Module holds z as a plain tensor: its state_dict is empty;
-        return {"z": self.z}    # the tokens are kept here so ls_result is usable)
-
     def population(self):
         return self.z
 
-    def state_dict(self):                                           # run.py:101 torch.save(ls.state_dict())
-        return {"z": self.z}
+    def state_dict(self):       # run.py:101 torch.save(ls.state_dict()) (the reference's nn.Module holds z as a plain tensor: its
+        return {"z": self.z}    # state_dict is empty; the latents are kept here so ls_result is usable)
 
 
 class DeepMindBigGANLatentSpace:
@@ -64,7 +61,7 @@ class DeepMindBigGANLatentSpace:
 
 
 class GPT2LatentSpace:
-    """latent.py:44-58 — config C5; the GPT-2 engine path is a later §8 row."""
+    """latent.py:44-58 — config C5: rows of token ids (the first dim_z tokens of every GPT-2 context, models.py:45-62)."""
 
     def __init__(self, config):
         self.config = config

@@ -6,9 +6,9 @@ population is cut into contiguous blocks that are multiples of batch_size; weigh
 the target feature are replicated; the only collective on the data path is ONE
 all-gather of the [P_local, n_obj] float32 fitness rows per generation (512 B per rank
 at 64 x 2 — latency-bound on xGMI).  Noise is a pure function of (seed, generation,
-GLOBAL minibatch index, layer), so the OPERANDS of every candidate do not depend on the sharding; a few kernel dispatchers
-look at the launch size (conv_stream's tile count, gemm_tiled's tile choice), so a sharded run reproduces the single-GPU
-result to fp16 rounding (-sim within 1e-3 relative, the north-star bar), and the same shard call twice bit for bit.
+GLOBAL minibatch index, layer) and every kernel dispatcher decides on the layer geometry alone (launch-size thresholds are
+evaluated at a nominal population, csrc/common.h), so a sharded run reproduces the single-GPU rows BIT FOR BIT
+(tests/test_gpu_engine.py: test_pop512_as_eight_shards_of_64, test_full_size_offset_shards).
 """
 import numpy as np
 
@@ -27,8 +27,19 @@ def shard_bounds(P, world, batch_size):
 
 
 class ShardedEvaluator:
-    def __init__(self, engine, dist, rank, world, batch_size):
+    def __init__(self, engine, dist, rank, world, batch_size, device=None):
+        """device: the GPU this rank's engine runs on (default: the engine's own).  The RCCL gather tensors are staged THERE — not on
+        torch's current device, which is cuda:0 on every rank unless the launcher called torch.cuda.set_device (a duplicate-GPU
+        error or a hang in the collective otherwise)."""
         self.engine, self.dist, self.rank, self.world, self.batch_size = engine, dist, rank, world, batch_size
+        if device is None:
+            device = getattr(getattr(engine, "cfg", None), "device", 0)
+        self.device = int(device)
+
+    def gather_device(self):
+        """torch device of the all-gather staging tensors: this rank's GPU under nccl (= RCCL), host memory under gloo."""
+        import torch
+        return torch.device("cuda", self.device) if self.dist.get_backend() == "nccl" else torch.device("cpu")
 
     def evaluate_local(self, x_local, generation=0, noise=None):
         """Weak-scaling form: every rank brings its own P_local rows; returns all ranks' F [P_local*world, n_obj]."""
@@ -49,7 +60,7 @@ class ShardedEvaluator:
         if self.dist is None or self.world == 1:
             return F
         import torch
-        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        dev = self.gather_device()
         n_obj = F.shape[1]
         if sizes is None or len(set(sizes)) == 1:
             t = torch.from_numpy(np.ascontiguousarray(F)).to(dev)

@@ -38,11 +38,16 @@ class GenerationProblem(Problem):
 
     def _evaluate(self, x, out, *args, **kwargs):
         ls = self.config.latent(self.config)
+        x = np.asarray(x)
+        P = x.shape[0]
+        if self.config.task == "txt2img" and P % self.config.batch_size:
+            # The reference asserts P % batch_size == 0 inside generate (models.py:112) — and pymoo's duplicate elimination
+            # (run.py:65) can shrink generation 0 below pop_size, which kills the reference run.  SURVEY 8a note 8: pad instead.
+            # The last row is repeated up to the next minibatch boundary and the padding rows' fitness is dropped; the real rows of
+            # that last minibatch share its noise plane / minibatch-stddev group with the copies.
+            x = np.concatenate([x, np.repeat(x[-1:], (-P) % self.config.batch_size, axis=0)])
         ls.set_from_population(x)
-        P = np.asarray(x).shape[0]
-        if self.config.task == "txt2img":
-            assert P % self.config.batch_size == 0      # models.py:112 (reference asserts inside generate)
-        F = self.generator.evaluate(ls)
+        F = self.generator.evaluate(ls)[:P]
         if self.config.problem_args["n_obj"] == 2 and self.config.use_discriminator:
             out["F"] = F                                # column_stack((-sim, hinge)) (problem.py:25)
         else:

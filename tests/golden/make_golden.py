@@ -12,6 +12,7 @@ weights/latents/noise are regenerated from (seed, name) by clip_glass_amd/synth.
   mid_modules.npz  : G / D / CLIP modules called directly, 64 px "mid" architecture,
                      per-minibatch noise planes.
   ffhq_modules.npz : the true 1024 px config-f + ViT-B/32 architecture, P=4.
+  clip_text_full.npz : CLIP.encode_text at the real text geometry (512 x 12 x 8 heads, ctx 77), 8 reference-tokenized rows.
 """
 import argparse
 import os
@@ -135,6 +136,33 @@ def gpt2_case(seed=2, P=8):
                 tokens=np.asarray(out, dtype=np.int64), last_logits=logits[:, -1, :64].numpy())
 
 
+TEXT_CASE_VISUAL = (128, 2, 8, 32, 512)      # build_model needs a visual tower; the text fixture only uses a small one
+TEXT_CASE_TEXTS = ["a wolf at night with the moon in the background",          # run.py:22 default target
+                   "the picture of a dog sitting on the grass",               # img2txt-style outputs (config.py:27 init_text)
+                   "the picture of", "a", "an astronaut riding a horse in the style of van gogh, highly detailed",
+                   "two cats", "the picture of the picture of the picture of a a a", "moon"]
+
+
+def text_case(seed=0):
+    """CLIP.encode_text (clip/model.py:307-320: token + positional embedding, 12 causal blocks of width 512 / 8 heads,
+    ln_final, EOT row @ text_projection) at the real ViT-B/32 text geometry, ctx 77, on eight rows tokenized by the
+    reference's own clip.tokenize (clip.py:125-138) — the img2txt config's in-loop leg (generator.py:52-59)."""
+    sd = synth.make_state(synth.clip_visual_spec(*TEXT_CASE_VISUAL), seed)
+    sd.update(synth.make_state(synth.clip_text_spec(), seed))
+    R = rh.load_reference()
+    model = rh.build_ref_clip(sd)
+    tokens = R["clip_clip"].tokenize(TEXT_CASE_TEXTS)
+    with torch.no_grad():
+        feats = model.encode_text(tokens)
+    return dict(seed=seed, tokens=tokens.numpy().astype(np.int64), features=feats.numpy().astype(np.float32),
+                texts=np.array(TEXT_CASE_TEXTS))
+
+
+def r4_cases():
+    np.savez_compressed(os.path.join(HERE, "clip_text_full.npz"), **text_case())
+    print("clip_text_full.npz")
+
+
 def r3_cases():
     # BASELINE.json configs[0]: StyleGAN2_ffhq_nod, pop = 8, through the reference's own problem.py at the true 1024 px size
     np.savez_compressed(os.path.join(HERE, "ffhq_nod_problem.npz"),
@@ -151,9 +179,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-ffhq", action="store_true")
     ap.add_argument("--only-ffhq", action="store_true")
+    ap.add_argument("--only-r4", action="store_true", help="round-4 addition only: full-size CLIP text tower case")
     ap.add_argument("--only-r3", action="store_true", help="round-3 additions only: full-size C1 problem case, church / car geometry")
     args = ap.parse_args()
     assert rh.available(), "needs /root/reference"
+    if args.only_r4:
+        r4_cases()
+        return
     if args.only_r3:
         r3_cases()
         return
@@ -169,6 +201,7 @@ def main():
     print("mid_modules.npz")
     np.savez_compressed(os.path.join(HERE, "mini_modules.npz"), **modules_case("mini", 8, 4, 0, 11, 2))
     print("mini_modules.npz")
+    r4_cases()
     if not args.skip_ffhq:
         r3_cases()
         # P = 8: two minibatches = two shared noise planes per layer and two mbstd groups (SURVEY 8a notes 4-5)

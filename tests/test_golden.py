@@ -116,7 +116,76 @@ def test_clip_tokenizer_known_answer_in_fixture():
     assert g["tokens"][:12].tolist() == [49406, 320, 5916, 536, 930, 593, 518, 3293, 530, 518, 5994, 49407]
 
 
+TEXT_VISUAL = (128, 2, 2, 8, 32, 512)        # make_golden.TEXT_CASE_VISUAL as an engine `clip` tuple (width, layers, heads, patch, res, embed)
+
+
+def _text_state(seed):
+    sd = synth.make_state(synth.clip_visual_spec(TEXT_VISUAL[0], TEXT_VISUAL[1], TEXT_VISUAL[3], TEXT_VISUAL[4], TEXT_VISUAL[5]), seed)
+    sd.update(synth.make_state(synth.clip_text_spec(), seed))
+    return sd
+
+
+def test_oracle_reproduces_reference_text_tower_full_size():
+    """CLIP.encode_text (clip/model.py:307-320) at the real ViT-B/32 text geometry (width 512, 12 layers, 8 heads, ctx 77): the
+    oracle's restatement vs features the reference's own build_model(...).encode_text produced for eight rows tokenized by the
+    reference's clip.tokenize (tests/golden/clip_text_full.npz) — config C5's in-loop CLIP leg (generator.py:52-59)."""
+    from oracle import clip_ref
+    g = _load("clip_text_full.npz")
+    assert g["tokens"].shape == (8, 77) and g["features"].shape == (8, 512)
+    assert g["tokens"][0, :12].tolist() == [49406, 320, 5916, 536, 930, 593, 518, 3293, 530, 518, 5994, 49407]
+    ref = clip_ref.encode_text(_t(_text_state(int(g["seed"]))), torch.tensor(g["tokens"])).numpy()
+    np.testing.assert_allclose(ref, g["features"], rtol=2e-3, atol=2e-4 * np.abs(g["features"]).max())
+
+
+def test_clip_tokenizer_reproduces_text_fixture_tokens():
+    """Own BPE (clip_glass_amd/tokenizer.py) on the fixture's eight texts == the ids the reference tokenizer wrote into it."""
+    bpe = "/root/reference/assets/bpe_simple_vocab_16e6.txt.gz"
+    if not os.path.exists(bpe):
+        pytest.skip("reference BPE asset not present")
+    from clip_glass_amd.tokenizer import ClipTokenizer
+    g = _load("clip_text_full.npz")
+    ids = ClipTokenizer(bpe).tokenize([str(t) for t in g["texts"]])
+    np.testing.assert_array_equal(ids, g["tokens"])
+
+
 # ------------------------------- HIP engine (GPU) -----------------------------------------
+@pytest.mark.gpu
+def test_engine_text_tower_full_size_matches_reference_fixture():
+    """glass_engine_encode_text at the real text geometry (512 x 12 x 8 heads, ctx 77) vs the reference-generated fixture and
+    the oracle, at 8 rows and at the C5 population (P = 64 = the 8 rows repeated in a scrambled order: every row must come out
+    bitwise as in the 8-row call), then Generator.clip_similarity_texts (generator.py:52-59) over those 64 rows against the
+    cosine of the REFERENCE's features: 1e-3 relative (north_star)."""
+    from clip_glass_amd.engine import Engine
+    from clip_glass_amd.generator import Generator
+    from oracle import clip_ref
+    g = _load("clip_text_full.npz")
+    sd = _text_state(int(g["seed"]))
+    e = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1, max_pop=64, clip=TEXT_VISUAL,
+               noise_mode=0)
+    e.load_state(sd)
+    e.finalize()
+    tokens = g["tokens"].astype(np.int64)
+    got8 = e.encode_text(tokens)
+    check("text tower (512 x 12, ctx 77) vs reference fixture", got8, g["features"], 3e-3)
+    ora = clip_ref.encode_text(_t(sd), torch.tensor(tokens)).numpy()
+    check("text tower (512 x 12, ctx 77) vs oracle", got8, ora, 3e-3)
+    order = np.random.RandomState(3).permutation(64) % 8
+    got64 = e.encode_text(tokens[order])
+    np.testing.assert_array_equal(got64, got8[order])
+    # the img2txt scoring leg at P = 64 through the host mirror: a stub tokenizer hands the fixture's ids over
+    img = synth.make_target(g["features"])              # an "image feature" close to the population's text features
+    gen = Generator.__new__(Generator)
+    gen.engine, gen.image_features = e, img[None].astype(np.float32)
+    gen.tokenizer = type("Tok", (), {"tokenize": staticmethod(lambda texts: tokens[order])})()
+    sim = gen.clip_similarity_texts(["row %d" % i for i in order])
+    rf = g["features"][order].astype(np.float64)
+    ref_sim = (rf @ img.astype(np.float64)) / np.maximum(np.linalg.norm(rf, axis=1) * np.linalg.norm(img.astype(np.float64)), 1e-8)
+    rel = np.abs(sim - ref_sim) / np.abs(ref_sim)
+    diag("[golden] full-size text tower P=64: sim rel err vs reference features %.3e (sims %.3f..%.3f)" % (rel.max(), ref_sim.min(), ref_sim.max()))
+    assert sim.shape == (64,) and rel.max() < 1e-3
+    e.close()
+
+
 @pytest.mark.gpu
 def test_engine_matches_reference_problem_evaluate():
     g = _load("mini_problem.npz")

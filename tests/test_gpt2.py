@@ -103,6 +103,28 @@ def test_engine_gpt2_decode_matches_oracle(geo, P, n_ctx, length):
     assert n_seq_ok >= P - 1
 
 
+@pytest.mark.gpu
+def test_engine_gpt2_decode_rows_do_not_depend_on_the_launch():
+    """A sequence's tokens are a function of its own context only: P = 72 in one call (decoded as row groups of 64 + 8) equals the
+    same rows decoded as shards of 8 / 64 / 72 rows in any grouping — prefill products never take the M <= 64 split-K path, the
+    single-token step products pick their split from (N, K) alone."""
+    import glass_models as M
+    from clip_glass_amd.engine import Engine
+    geo = dict(n_embd=256, n_layer=3, vocab=5000)
+    sd = synth.make_state(synth.gpt2_spec(**geo, n_positions=64), 2)
+    clip = M.CONFIGS["mini"]["clip"]
+    sd.update(synth.make_state(synth.clip_visual_spec(clip[0], clip[1], clip[3], clip[4], clip[5]), 0))
+    e = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1, max_pop=72, clip=clip, noise_mode=0)
+    e.load_state(sd)
+    e.finalize()
+    ctx = _ctx(4, 72, 23, geo["vocab"])
+    whole = e.gpt2_decode(ctx, 12)
+    assert whole.shape == (72, 35)
+    for lo, hi in ((0, 8), (8, 72), (0, 64), (64, 72), (3, 5)):
+        np.testing.assert_array_equal(e.gpt2_decode(ctx[lo:hi], 12), whole[lo:hi])
+    e.close()
+
+
 def _synthetic_vocabs(tmp):
     """Tiny BPE assets in the reference's file formats (gpt2/encoder.py:107-115, clip/simple_tokenizer.py:66-72) so the
     img2txt path runs where the reference's data files are absent (the GPU box)."""

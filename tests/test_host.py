@@ -127,7 +127,7 @@ def test_generation_problem_contract_with_stub_generator(monkeypatch):
 
         def evaluate(self, ls):
             (z,) = ls()
-            assert z.dtype == np.float32
+            assert z.dtype == np.float32 and z.shape[0] % self.config.batch_size == 0
             return np.stack([-z[:, 0], np.maximum(1 - z[:, 1], 0)], axis=1).astype(np.float32)
     monkeypatch.setattr(problem, "Generator", FakeGen)
     for name, n_obj in (("StyleGAN2_ffhq_d", 2), ("StyleGAN2_ffhq_nod", 1)):
@@ -140,8 +140,12 @@ def test_generation_problem_contract_with_stub_generator(monkeypatch):
         p._evaluate(x, out)
         assert out["F"].shape == ((8, 2) if n_obj == 2 else (8,)) and out["F"].dtype == np.float32
         assert out["G"].shape == (8,) and not out["G"].any()
-        with pytest.raises(AssertionError):
-            p._evaluate(x[:6], {})                # P % batch_size != 0 (models.py:112)
+        # P % batch_size != 0: the reference asserts (models.py:112); SURVEY 8a note 8 asks to pad instead (pymoo's duplicate
+        # elimination can shrink generation 0): the last row is repeated to the minibatch boundary, its copies' F dropped
+        out6 = {}
+        p._evaluate(x[:6], out6)
+        assert out6["F"].shape == ((6, 2) if n_obj == 2 else (6,)) and out6["G"].shape == (6,)
+        np.testing.assert_array_equal(out6["F"], out["F"][:6])
 
 
 def test_kernel_arithmetic_emulated_on_cpu():
@@ -206,6 +210,24 @@ def test_population_sharding_two_process_gloo():
         x5 = synth.latents(1, 20, 8).astype(np.float32)
         np.testing.assert_allclose(Fr[:, 1], x5[:, 1], rtol=1e-6)
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_sharded_gather_tensors_live_on_the_engine_device():
+    """under nccl (= RCCL) the all-gather staging tensors must sit on THIS rank's GPU (the engine's device), not on
+    torch's current device (cuda:0 on every rank when the caller never called torch.cuda.set_device); gloo stages on the host."""
+    import torch
+
+    class FakeDist:
+        def __init__(self, backend):
+            self.backend = backend
+
+        def get_backend(self):
+            return self.backend
+    eng = types.SimpleNamespace(cfg=types.SimpleNamespace(n_obj=2, device=5))
+    ev = parallel.ShardedEvaluator(eng, FakeDist("nccl"), 5, 8, 4)
+    assert ev.gather_device() == torch.device("cuda", 5)
+    assert parallel.ShardedEvaluator(eng, FakeDist("nccl"), 5, 8, 4, device=3).gather_device() == torch.device("cuda", 3)
+    assert parallel.ShardedEvaluator(eng, FakeDist("gloo"), 5, 8, 4).gather_device() == torch.device("cpu")
 
 
 def _gloo_problem_worker(rank, world, port, q):
