@@ -1,0 +1,381 @@
+// conv_d0.hip — the discriminator's WHOLE full-resolution block in one kernel (gfx950):
+//     y (3-channel skip image, fp32) -> biggan denorm(norm(y)) -> fromRGB 1x1 (3 -> 32) + bias + lrelu*sqrt2          = x
+//     x -> conv3x3 (32 -> 32) + bias + lrelu*sqrt2                                                                    = h
+//     h -> FIR 4x4 (pad 2) -> conv3x3 stride 2 (32 -> 64) + bias + lrelu*sqrt2 \
+//     x -> FIR 4x4 (pad 1) -> ::2 -> conv1x1 (32 -> 64)                        +-> (a + b) / sqrt2                     = out
+// (stylegan2/models.py:1125-1143, 1193-1230; modules.py:1204-1254 ConvDownLayer, 1587-1601 DiscriminatorConvBlock.forward;
+// utils.py:14-21).  Round 2/3 ran this block as two kernels — conv_stream<fromrgb> (x on the fly, h and FIR(x)[::2] to HBM) and
+// conv_down (h and the skip input back from HBM): 4.3 GB of h written and read again per 64-candidate population, a full
+// store epilogue and a full staging prologue per 64-byte pixel in kernels that are bound by instruction issue, 4.3 ms.  Here only
+// the 12-byte-per-pixel image comes in and the 128-byte-per-pixel block output goes out; x and h exist in LDS only.
+//
+// Geometry.  A step produces 4 output rows x 30 output columns (of the R/2 grid).  It needs h rows 8k-2 .. 8k+9 and columns
+// 60tx-2 .. 60tx+61 (a 12 x 64 window: 64 columns = two 32-pixel MFMA blocks per row, which is what fixes the tile width at 30),
+// and for those the fromRGB map x on rows 8k-1 .. 8k+10 x columns 60tx-3 .. 60tx+62 (the patch F, 12 x 66 pixels).  Steps walk DOWN a
+// tile column, so 4 of the 12 window rows are carried from the previous step: a step computes 8 new h rows.  A workgroup's range
+// starts (and every column starts) with a PRIMING step that only computes the carried rows.
+//
+// One 512-thread workgroup per CU, ALL weights in registers: a wave owns one new h row (conv0: one 32-channel n block, 18 weight
+// fragments = 72 VGPRs) and later one (output row, 32-channel n half) of the stride-2 conv (18 + 2 fragments = 80 VGPRs).  D's
+// weights are the same for every candidate, so the fragments are loaded once per workgroup lifetime and the MFMA loops read ONE
+// LDS fragment (the pixels) per MFMA — the LDS-fed ceiling of conv_stream / conv_down was 1.5 reads per MFMA.
+//
+// Phases of a step (4 workgroup barriers):
+//   P1  image values (prefetched one step ahead, 1-2 pixels per thread) -> fromRGB -> F (zero outside the image: conv0's padding)
+//   P2  skip-branch input: FIR (pad 1) + ::2 of F for the step's 4 x 30 output pixels -> XS image (MFMA B fragments of the skip conv)
+//   P3  conv0: wave w = new h row 8k+2+w, 2 blocks x 18 MFMAs; bias + lrelu in packed fp16 exactly as conv_stream did it; h is zeroed
+//       outside the image (the FIR's padding); the row goes through the wave's own row image and the HORIZONTAL FIR runs wave-locally
+//       (LDS is in order per wave: no workgroup barrier), de-interleaved (even | odd blurred columns) into the 12-row ring HB
+//   P4  vertical FIR over the ring -> operand image A of the stride-2 conv (9 rows; aliases F)
+//   P5  stride-2 conv: wave (row r, n half): 18 MFMAs; bias + lrelu in the accumulators; + 2 skip MFMAs (the skip rows carry the
+//       merge's 1/sqrt2, the activation's sqrt2 cancels against it); transposition through the wave's row image; 16-byte stores.
+// Index-level CPU emulation of the whole scheme (patch / ring / priming / masks / fragment addresses): tests/emu_ops.py dblock0
+// (tests/test_host.py::test_dblock0_index_emulation).
+#include "common.h"
+#include "kernels.h"
+#include <stdlib.h>
+
+namespace {
+constexpr int NTHR = 512, TW = 30, FP = 68, FR = 12, FC = 66;
+constexpr int F_BYTES = FR * FP * 64;                 // 52224: fromRGB patch; the operand image A (9 x 4096) aliases it
+constexpr int ROWB = 64 * 64;                         // one 64-slot row of 64-byte pixels
+constexpr int OFF_RT = F_BYTES;                       // per-wave row image (8 x 4096)
+constexpr int OFF_HB = OFF_RT + 8 * ROWB;             // ring of 12 horizontally blurred, de-interleaved h rows
+constexpr int OFF_XS = OFF_HB + 12 * ROWB;            // skip-branch input [4 rows][32 px][32 ch]
+constexpr int OFF_C = OFF_XS + 4 * 32 * 64;           // bias0 [32] f32, bias1 [64] f32, fromRGB rows [4][32] f16
+constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4 + 128 * 2;   // 142976
+static_assert(9 * ROWB <= F_BYTES, "operand image aliases the patch");
+
+// patch image: pixel (pr, pc) at row pr * FP + pc, 16-byte chunk XOR-swizzled by the COLUMN only (conv_stream.hip's layout)
+__device__ __forceinline__ int swa(int pr, int pc, int chunk) { return ((pr * FP + pc) << 6) + ((chunk ^ ((pc >> 2) & 3)) << 4); }
+// dense 64-byte rows, chunk XOR-swizzled by the row / slot (conflict-free 32-lane fragment walks)
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 6) + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// row image for the horizontal FIR: column rotated inside its aligned group of 4 (conv_down.hip's vaddr: stride-4 sliding-window
+// reads and stride-1 writes both conflict-free)
+__device__ __forceinline__ int vrot(int col, int cg) { return (((col & ~3) | ((col + (col >> 2)) & 3)) << 6) + (cg << 4); }
+__device__ __forceinline__ h8 fir4(h8 a, h8 b, h8 c, h8 d) {   // [1,3,3,1]/8, packed fp16
+    return (a + d) * (half_t)0.125f + (b + c) * (half_t)0.375f;
+}
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+}  // namespace
+
+struct D0Params {
+    const float* rgb_y;   // [B][3][R][R] skip image
+    const float* rgb_w;   // [32][3] fromRGB weights (runtime coefficient applied)
+    const float* rgb_b;   // [32]
+    const half_t* w0;     // [9][32][32]
+    const float* b0;      // [32]
+    const half_t* w1;     // [9][64][32]
+    const half_t* ws;     // [64][32]
+    const float* b1;      // [64]
+    half_t* y;            // [B][R/2][R/2][64]
+    int B, R;
+};
+
+__global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_x, int tiles_y, int n_steps, int per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Cb0 = (float*)(smem + OFF_C);
+    float* Cb1 = Cb0 + 32;
+    half_t* Cf = (half_t*)(Cb1 + 64);
+    const int R = p.R, Ro = R >> 1;
+    const int first = blockIdx.x * per_block;
+    const int last = min(first + per_block, n_steps);
+    if (first >= last) return;
+    const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- resident constants (LDS) and weight fragments (registers) -----------------------------------------------------------------
+    h8 W0f[9][2], W1f[9][2], Wsf[2];
+    {
+        const int t = threadIdx.x;
+        if (t < 32) {
+            Cf[t] = (half_t)(p.rgb_w[t * 3] * GLASS_SQRT2);
+            Cf[32 + t] = (half_t)(p.rgb_w[t * 3 + 1] * GLASS_SQRT2);
+            Cf[64 + t] = (half_t)(p.rgb_w[t * 3 + 2] * GLASS_SQRT2);
+            Cf[96 + t] = (half_t)(p.rgb_b[t] * GLASS_SQRT2);
+            Cb0[t] = p.b0[t];
+        }
+        if (t < 64) Cb1[t] = p.b1[t];
+        // lane (n = lr, k half kh) holds W[tap][n][kk * 16 + kh * 8 .. + 7]: the A operand of mfma32 (common.h)
+        const int lr = t & 31, kh = (t >> 5) & 1, nh = (t >> 6) & 1;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                W0f[tap][kk] = *(const h8*)(p.w0 + ((long long)tap * 32 + lr) * 32 + kk * 16 + kh * 8);
+                W1f[tap][kk] = *(const h8*)(p.w1 + ((long long)tap * 64 + nh * 32 + lr) * 32 + kk * 16 + kh * 8);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // (lrelu(a + b1) * sqrt2 + skip) / sqrt2 = lrelu(a + b1) + skip / sqrt2: the skip rows carry the 1/sqrt2 (conv_down.hip)
+            const h8 w = *(const h8*)(p.ws + ((long long)nh * 32 + lr) * 32 + kk * 16 + kh * 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Wsf[kk][q] = (half_t)((float)w[q] * 0.70710678118654752440f);
+        }
+    }
+
+    // ---- the walk: steps (b, tx, k), k fastest (down a tile column); a priming item (k - 1, no output) opens every range / column ---
+    struct Item { int b, tx, k, prime; };
+    const int tpi = tiles_x * tiles_y;
+    int it = first;
+    int cb = uni(first / tpi);
+    int ctx, ck;
+    {
+        const int rem = first - cb * tpi;
+        ctx = uni(rem / tiles_y);
+        ck = uni(rem - ctx * tiles_y);
+    }
+    bool need_prime = true;
+    auto next_item = [&]() {
+        Item r;
+        if (need_prime) {
+            r.b = cb; r.tx = ctx; r.k = ck - 1; r.prime = 1;
+            need_prime = false;
+            return r;
+        }
+        r.b = cb; r.tx = ctx; r.k = ck; r.prime = 0;
+        ++it;
+        if (++ck == tiles_y) {
+            ck = 0;
+            need_prime = true;
+            if (++ctx == tiles_x) { ctx = 0; ++cb; }
+        }
+        return r;
+    };
+
+    // image values of an item's patch: pixels t and 512 + t (< 792) of the 12 x 66 patch; unconditional loads at clamped coordinates
+    // (the zero padding is a mask applied when the pixel is written to LDS)
+    float yv[2][3];
+    auto load_image = [&](const Item& c) {
+        const int t = opaque(threadIdx.x);
+        const int y0 = 8 * c.k - 1, x0 = 60 * c.tx - 3;
+        const long long hw = (long long)R * R;
+        const float* yb = p.rgb_y + (long long)c.b * 3 * hw;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int px = min(t + 512 * u, FR * FC - 1);
+            const int fr = px / FC, fc = px - fr * FC;
+            const int iy = min(max(y0 + fr, 0), R - 1), ix = min(max(x0 + fc, 0), R - 1);
+            const int off = iy * R + ix;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) yv[u][ch] = yb[ch * hw + off];
+        }
+    };
+
+    auto step = [&](const Item& c, const Item& nx) {
+        const int b = c.b, tx = c.tx, k = c.k;
+        const int y0 = 8 * k - 1, x0 = 60 * tx - 3;
+        __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
+        // ---- P1: fromRGB of this thread's pixel(s) -> F ----------------------------------------------------------------------------
+        {
+            const int t = opaque(threadIdx.x);
+            half_t hc[2][3];
+            int lrow[2], key[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int px = min(t + 512 * u, FR * FC - 1);
+                const int fr = px / FC, fc = px - fr * FC;
+                const int iy = y0 + fr, ix = x0 + fc;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+                    hc[u][ch] = (half_t)(fminf(fmaxf((yv[u][ch] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
+                ok[u] = (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
+                lrow[u] = (fr * FP + fc) << 6;
+                key[u] = (fc >> 2) & 3;
+            }
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+                const h8 f0 = *(const h8*)(Cf + part * 8), f1 = *(const h8*)(Cf + 32 + part * 8), f2 = *(const h8*)(Cf + 64 + part * 8),
+                         f3 = *(const h8*)(Cf + 96 + part * 8);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const h8 z = f0 * hc[u][0] + f1 * hc[u][1] + f2 * hc[u][2] + f3;                        // v_pk_fma_f16
+                    const h8 a = __builtin_elementwise_max(z, z * (half_t)0.2f);
+                    if (u == 0 || t < FR * FC - 512) *(h8*)(smem + lrow[u] + ((part ^ key[u]) << 4)) = ok[u] ? a : zero;
+                }
+            }
+        }
+        load_image(nx);        // the next item's image values travel during this item's MFMA phases
+        __syncthreads();       // B1: patch complete
+        const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
+        char* RT = smem + OFF_RT + wave * ROWB;
+        // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, this wave's output row, chunk nh * 2 + kh ---------------
+        if (!c.prime) {
+            const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + kh;
+            const int fc0 = min(2 * lr + 2, FC - 4);
+            h8 hr[4];
+#pragma unroll
+            for (int jy = 0; jy < 4; ++jy) {
+                const int pr = 2 * r + jy;
+                const h8 a0 = *(const h8*)(smem + swa(pr, fc0, ch)), a1 = *(const h8*)(smem + swa(pr, fc0 + 1, ch)),
+                         a2 = *(const h8*)(smem + swa(pr, fc0 + 2, ch)), a3 = *(const h8*)(smem + swa(pr, fc0 + 3, ch));
+                hr[jy] = fir4(a0, a1, a2, a3);
+            }
+            *(h8*)(smem + OFF_XS + swz(r * 32 + lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
+        }
+        // ---- P3: conv0 of new h row 8k + 2 + wave -> row image -> horizontal FIR -> ring -------------------------------------------------
+        {
+            const int yh = 8 * k + 2 + wave;                                           // uniform per wave
+            char* ring = smem + OFF_HB + ((yh + 14) % 12) * ROWB;                      // slot of h row y: (y + 2) mod 12
+            const int jj = lane >> 2, cgl = lane & 3;
+            if ((unsigned)yh >= (unsigned)R) {                                         // outside the image: the FIR's zero padding
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cbk = 4 * jj + i;
+                    if (cbk <= 60) *(h8*)(ring + swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl)) = zero;
+                }
+            } else {
+                f16x acc[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int blk = 0; blk < 2; ++blk) {
+                                const h8 xf = *(const h8*)(smem + swa(wave + 2 + ky, blk * 32 + lr + kx, kk * 2 + kh));
+                                acc[blk] = mfma32(W0f[ky * 3 + kx][kk], xf, acc[blk]);
+                            }
+                // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
+                const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const int col = blk * 32 + lr;
+                    const bool colok = (unsigned)(60 * tx - 2 + col) < (unsigned)R;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f4 bb = *(const f4*)(Cb0 + 8 * g + 4 * kh);
+                        h4 v;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = (half_t)(acc[blk][g * 4 + q] + bb[q]);
+                        h4 hq = __builtin_elementwise_max(v * k1, v * k2);
+                        if (!colok) hq = h4{0, 0, 0, 0};
+                        *(h4*)(RT + vrot(col, g) + kh * 8) = hq;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                h8 v[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const int col = 4 * jj + q;
+                    v[q] = *(const h8*)(RT + vrot(min(col, 63), cgl));
+                    if (col > 63) v[q] = zero;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cbk = 4 * jj + i;
+                    if (cbk <= 60) *(h8*)(ring + swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl)) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (c.prime) return;
+        __syncthreads();       // B2: ring complete; every wave is done reading F
+        // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 8 = blurred rows 8k .. 8k + 8) -----------------------------------
+        {
+            const int t = opaque(threadIdx.x);
+            if (t < 488) {
+                const int half = t >= 244 ? 1 : 0, e = t - 244 * half;
+                const int off = swz(e >> 2, e & 3);
+                const int base = uni((8 * k + 24) % 12);                                // ring slot of window row 0 (h row 8k - 2)
+                const int i0 = half * 5;
+                h8 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int s = base + min(i0 + i, 11);
+                    s = s >= 12 ? s - 12 : s;
+                    v[i] = *(const h8*)(smem + OFF_HB + s * ROWB + off);
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (j < 4 || !half) *(h8*)(smem + (i0 + j) * ROWB + off) = fir4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+            }
+        }
+        __syncthreads();       // B3: operand image complete
+        // ---- P5: stride-2 conv + skip, wave = (output row 4k + r, n half nh) ----------------------------------------------------------------
+        {
+            const int r = wave >> 1, nh = wave & 1;
+            f16x acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const h8 xf = *(const h8*)(smem + (2 * r + ky) * ROWB + swz((kx == 1 ? 31 : (kx >> 1)) + lr, kk * 2 + kh));
+                        acc = mfma32(W1f[ky * 3 + kx][kk], xf, acc);
+                    }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f4 bb = *(const f4*)(Cb1 + nh * 32 + 8 * g + 4 * kh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = acc[g * 4 + q] + bb[q];
+                    acc[g * 4 + q] = fmaxf(v, 0.2f * v);        // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + swz(r * 32 + lr, kk * 2 + kh)), acc);
+            // transposition through the wave's row image (32 px x 64 B), then 16-byte stores in row order
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (half_t)acc[g * 4 + q];
+                *(h4*)(RT + swz(lr, g) + kh * 8) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int orow = 4 * k + r;
+            half_t* yrow = p.y + (((long long)b * Ro + orow) * Ro + 30 * tx) * 64 + nh * 32;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
+                const h8 d = *(const h8*)(RT + swz(pix, chv));
+                if (pix < TW && 30 * tx + pix < Ro && orow < Ro) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    __syncthreads();           // constants staged
+    Item cur = next_item();
+    load_image(cur);
+    for (;;) {
+        const bool more = it < last;
+        const Item nxt = more ? next_item() : cur;
+        step(cur, nxt);
+        if (!more) break;
+        cur = nxt;
+    }
+}
+
+bool dblock0_supported(int R, int Cin, int Cout) {
+    static const bool off = getenv("GLASS_NO_D0_FUSE") != nullptr;   // A/B knob: conv_stream<fromrgb> + conv_down instead
+    return !off && glass_lds_fits(LDS_BYTES) && R % 8 == 0 && R >= 16 && Cin == 32 && Cout == 64 && 3LL * R * R < (1LL << 31);
+}
+
+// Returns the kernel symbol, or nullptr when the block does not qualify (caller runs the two-kernel form).
+const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* rgb_b, const half_t* w0, const float* b0, const half_t* w1,
+                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st) {
+    if (!dblock0_supported(R, Cin, Cout)) return nullptr;
+    D0Params p;
+    p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
+    const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 8;
+    const long long n_steps = (long long)B * tiles_x * tiles_y;
+    if (n_steps >= (1LL << 30)) return nullptr;
+    static DevOnce once;
+    if (once.first()) (void)hipFuncSetAttribute((const void*)dblock0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    const int slots = glass_cu_count();           // one 512-thread workgroup per CU (143 KB of LDS)
+    const int per_block = (int)((n_steps + slots - 1) / slots);
+    const int grid = (int)((n_steps + per_block - 1) / per_block);
+    hipLaunchKernelGGL(dblock0_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
+    return "dblock0_kernel";
+}

@@ -1068,6 +1068,19 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
         p.bias = d.b0; p.act = 1; p.y = Hb;
         bool fused_rgb = false, have_xs = false;
+        if (i == 0 && rgb_y) {       // the whole block from the skip image in one kernel (conv_d0.hip): neither x nor h reaches HBM
+            snprintf(tag, sizeof tag, "D.block0.r%d.%dx%dx%d", r, d.cin, d.cin, d.cout);
+            const double px = (double)B * r * r, px2 = (double)B * r2 * r2;
+            Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin) + 2.0 * px2 * 10.0 * d.cin * d.cout, px * 12.0 + px2 * 2.0 * d.cout);
+            const char* k = launch_dblock0(rgb_y, e->d_frgb_w, e->d_frgb_b, d.w0, d.b0, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur);
+            if (k) {
+                if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                if (e->profiling) e->tag_kernel[tag] = k;
+                std::swap(X, O);
+                continue;
+            }
+            pr.on = false;
+        }
         const bool fuse_down = conv_down_supported(r, d.cin, d.cout);   // blur + skip + stride-2 conv + merge as one kernel
         if (i == 0 && rgb_y) {
             static const bool no_fuse = getenv("GLASS_NO_FRGB_FUSE") != nullptr;   // A/B knob

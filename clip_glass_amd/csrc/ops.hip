@@ -260,6 +260,42 @@ extern "C" int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_
     return down16(y, dy, (size_t)B * Ro * Ro * Cout);
 }
 
+extern "C" int glass_op_dblock0(int32_t device, int32_t B, int32_t R, int32_t impl, const float* y, const float* frgb_w, const float* frgb_b,
+                                const float* w0, const float* b0, const float* w1, const float* wskip, const float* b1, float* out) {
+    OPREQ(y && frgb_w && frgb_b && w0 && b0 && w1 && wskip && b1 && out && B > 0 && R > 0, "bad argument");
+    GLASS_HIP(hipSetDevice(device));
+    Dev dv;
+    const int Cin = 32, Cout = 64, Ro = R / 2;
+    float* dy = dv.up32(y, (size_t)B * 3 * R * R);
+    float* dfw = dv.up32(frgb_w, Cin * 3); float* dfb = dv.up32(frgb_b, Cin);
+    std::vector<_Float16> pk;
+    glass_pack_conv(w0, Cin, Cin, 3, Cin, pk);
+    half_t* dw0 = dv.up16v(pk);
+    glass_pack_conv(w1, Cout, Cin, 3, Cin, pk);
+    half_t* dw1 = dv.up16v(pk);
+    glass_pack_conv(wskip, Cout, Cin, 1, Cin, pk);
+    half_t* dws = dv.up16v(pk);
+    float* db0 = dv.up32(b0, Cin); float* db1 = dv.up32(b1, Cout);
+    half_t* dout = dv.alloc<half_t>((size_t)B * Ro * Ro * Cout);
+    OPREQ(dy && dw0 && dw1 && dws && dout, "device allocation failed");
+    if (impl == 0) {          // conv_d0.hip: the whole block in one kernel
+        OPREQ(launch_dblock0(dy, dfw, dfb, dw0, db0, dw1, dws, db1, dout, B, R, Cin, Cout, 0) != nullptr, "dblock0: unsupported shape");
+    } else {                  // the two-kernel form it replaces: conv_stream<fromrgb> (h + the skip input to HBM) + conv_down
+        half_t* dh = dv.alloc<half_t>((size_t)B * R * R * Cin);
+        half_t* dxs = dv.alloc<half_t>((size_t)B * Ro * Ro * Cin);
+        OPREQ(dh && dxs, "device allocation failed");
+        ConvParams p = conv_defaults();
+        p.x = dh; p.x_bstride = (long long)R * R * Cin; p.B = B; p.H = p.W = R; p.Cin = Cin; p.Hc = p.Wc = R; p.KS = 3; p.pad = 1;
+        p.w = dw0; p.Cout = p.Neff = Cin; p.Ho = p.Wo = R; p.bias = db0; p.act = 1; p.y = dh;
+        p.rgb_y = dy; p.rgb_w = dfw; p.rgb_b = dfb; p.rgb_xs_out = dxs;
+        OPREQ(launch_conv_stream(p, 0) != nullptr, "dblock0 (two-kernel form): conv_stream<fromrgb> does not take this shape");
+        OPREQ(launch_conv_down(dh, dxs, dw1, dws, db1, dout, B, R, Cin, Cout, 0) != nullptr, "dblock0 (two-kernel form): conv_down does not take this shape");
+    }
+    int rc = finish();
+    if (rc) return rc;
+    return down16(out, dout, (size_t)B * Ro * Ro * Cout);
+}
+
 extern "C" int glass_op_fromrgb(int32_t device, int32_t B, int32_t R, int32_t Cout, const float* y, const float* w,
                                 const float* bias, float* out) {
     OPREQ(y && w && bias && out && Cout % 8 == 0, "bad argument");

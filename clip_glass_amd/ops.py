@@ -147,6 +147,19 @@ def dblock_down(h, x, w1, wskip, b1, device=0):
     return out
 
 
+def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, impl=0, device=0):
+    """The discriminator's whole full-resolution block (conv_d0.hip): y [B,3,R,R] -> [B,R/2,R/2,64].  impl 1: the two-kernel form."""
+    lib = load_library()
+    y, frgb_w, frgb_b, w0, b0, w1, wskip, b1 = (_f32(a) for a in (y, frgb_w, frgb_b, w0, b0, w1, wskip, b1))
+    B, _, R, _ = y.shape
+    out = np.empty((B, R // 2, R // 2, 64), dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.glass_op_dblock0.argtypes = [C.c_int32] * 4 + [fp] * 9
+    _check(lib, lib.glass_op_dblock0(device, B, R, impl, _fp(y), _fp(frgb_w), _fp(frgb_b), _fp(w0), _fp(b0), _fp(w1), _fp(wskip),
+                                     _fp(b1), _fp(out)))
+    return out
+
+
 def fromrgb(y, w, bias, device=0):
     lib = load_library()
     y, w, bias = _f32(y), _f32(w), _f32(bias)

@@ -60,6 +60,12 @@ int glass_op_blur(int32_t device, int32_t mode /*0: pad2 stride1, 1: pad1 + ::2*
  * h, x [B,R,R,Cin]; w1 [Cout,Cin,3,3], wskip [Cout,Cin,1,1] (reference layouts, un-scaled); y [B,R/2,R/2,Cout] */
 int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_t Cin, int32_t Cout, const float* h, const float* x,
                          const float* w1, const float* wskip, const float* b1, float* y);
+/* the discriminator's whole full-resolution block (conv_d0.hip; stylegan2/models.py:1125-1143, modules.py:1204-1254, 1587-1601):
+ * y [B,3,R,R] skip image -> denorm(norm(y)) -> fromRGB (3 -> 32) -> conv3x3 (32 -> 32) -> FIR pad 2 -> conv3x3 stride 2 (32 -> 64),
+ * + conv1x1 of FIR pad 1 [::2] of the fromRGB map, merged / sqrt2.  frgb_w [32,3] scaled; w0 [32,32,3,3], w1 [64,32,3,3],
+ * wskip [64,32,1,1] reference layouts, un-scaled; out [B,R/2,R/2,64].  impl 0: the fused kernel; 1: conv_stream<fromrgb> + conv_down */
+int glass_op_dblock0(int32_t device, int32_t B, int32_t R, int32_t impl, const float* y, const float* frgb_w, const float* frgb_b,
+                     const float* w0, const float* b0, const float* w1, const float* wskip, const float* b1, float* out);
 int glass_op_fromrgb(int32_t device, int32_t B, int32_t R, int32_t Cout, const float* y /*[B,3,R,R]*/,
                      const float* w /*[Cout,3] scaled*/, const float* bias, float* out /*[B,R,R,Cout]*/);
 int glass_op_mbstd(int32_t device, int32_t B, int32_t hw, int32_t C, int32_t Cpad, int32_t batch_size, int32_t group,

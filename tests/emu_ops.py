@@ -473,3 +473,191 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
                             written[img, oy, ox] += 1
     assert (written == 1).all(), "every output pixel is written exactly once (%d .. %d)" % (written.min(), written.max())
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# conv_d0.hip / dblock0_kernel emulated at the level of its INDEX MATH: 4 x 30 output tiles walked down tile columns, the fromRGB
+# patch F (12 x 66 px, pitch 68, column-keyed chunk swizzle), conv0 per wave = one new h row (2 x 32 px blocks) with the weight
+# fragments in registers, wave-local horizontal FIR through the per-wave row image into the 12-row ring of de-interleaved rows,
+# vertical FIR into the operand image (aliases F), stride-2 conv per (row, n half) wave + skip MFMAs from the XS image, priming
+# steps at every range / column start.  Constants and address functions mirror the kernel's namespace.
+_D0 = dict(TW=30, TH=4, HW=64, FP=68, FR=12)
+_D0_OFF_F, _D0_OFF_RT, _D0_OFF_HB, _D0_OFF_XS = 0, 52224, 52224 + 32768, 52224 + 32768 + 49152
+_D0_LDS = _D0_OFF_XS + 8192
+
+
+def _d0_swa(pr, pc, chunk):
+    return ((pr * 68 + pc) << 6) + ((chunk ^ ((pc >> 2) & 3)) << 4)
+
+
+def _d0_swz(row, chunk):
+    return (row << 6) + ((chunk ^ ((row >> 2) & 3)) << 4)
+
+
+def _d0_slot(slot, lc):
+    return (slot << 6) + ((lc ^ ((slot >> 2) & 3)) << 4)
+
+
+def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
+    """y [B,3,R,R] skip image; frgb_w [32,3] scaled; w0 [32,32,3,3], w1 [64,32,3,3], wskip [64,32,1,1] reference layouts.
+    Returns [B,R/2,R/2,64] float32.  n_wg: number of emulated workgroups (contiguous step ranges -> priming mid-column)."""
+    f16, f32 = np.float16, np.float32
+    y = np.asarray(y, f32)
+    B, _, R, _ = y.shape
+    assert R % 8 == 0
+    Ro = R // 2
+    tiles_x, tiles_y = (Ro + 29) // 30, R // 8
+    pk0 = real_ops.host_pack_conv(w0, False).astype(f16)        # [9][32][32]
+    pk1 = real_ops.host_pack_conv(w1, False).astype(f16)        # [9][64][32]
+    pks = (real_ops.host_pack_conv(wskip, False).astype(f32) * f32(0.70710678118654752440)).astype(f16)[0]   # [64][32]
+    Cf = np.concatenate([(np.asarray(frgb_w, f32)[:, c] * f32(math.sqrt(2))).astype(f16) for c in range(3)] +
+                        [(np.asarray(frgb_b, f32) * f32(math.sqrt(2))).astype(f16)]).reshape(4, 32)
+    b0 = np.asarray(b0, f32); b1 = np.asarray(b1, f32)
+    out = np.full((B, Ro, Ro, 64), np.nan, f32)
+    lds = np.zeros(_D0_LDS // 2, f16)
+    lane = np.arange(64); lr, kh = lane & 31, lane >> 5
+
+    def wr(addr, vals, n=8):
+        for a, v in zip(np.asarray(addr).ravel(), np.asarray(vals).reshape(-1, n)):
+            lds[a // 2:a // 2 + n] = v
+
+    def rd(addr):
+        addr = np.asarray(addr)
+        return np.stack([lds[a // 2:a // 2 + 8] for a in addr.ravel()]).reshape(addr.shape + (8,))
+
+    def frag_to_mat(fr):
+        m = np.zeros((32, 16), np.float64)
+        m[lr[:, None], (kh * 8)[:, None] + np.arange(8)[None, :]] = fr.astype(np.float64)
+        return m
+
+    def wfrag(pk, tap, n0, kk):          # lane (n = lr, kh): pk[tap][n0 + lr][kk*16 + kh*8 ..]
+        return np.stack([pk[tap, n0 + lr[i], kk * 16 + kh[i] * 8:kk * 16 + kh[i] * 8 + 8] for i in range(64)])
+
+    n_steps = B * tiles_x * tiles_y
+    per_block = (n_steps + n_wg - 1) // n_wg
+    t = np.arange(512)
+
+    def run_item(b, tx, k, prime):
+        y0, x0 = 8 * k - 1, 60 * tx - 3            # image row / column of F[0][0]
+        # ---- P1: fromRGB patch, thread -> pixels t and 512 + t (< 792) --------------------------------------------------
+        for px in (t, t[t < 280] + 512):
+            fr, fc = px // 66, px % 66
+            iy, ix = y0 + fr, x0 + fc
+            v = y[b][:, np.clip(iy, 0, R - 1), np.clip(ix, 0, R - 1)].T             # [n, 3] clamped loads
+            c3 = (np.clip((v + f32(1)) * f32(0.5), 0, 1) * f32(2) - f32(1)).astype(f16)
+            ok = (iy >= 0) & (iy < R) & (ix >= 0) & (ix < R)
+            for part in range(4):
+                fw = Cf[:, part * 8:part * 8 + 8].astype(f32)
+                z = (c3[:, 0:1].astype(f32) * fw[0]).astype(f16)
+                z = (c3[:, 1:2].astype(f32) * fw[1] + z.astype(f32)).astype(f16)
+                z = (c3[:, 2:3].astype(f32) * fw[2] + z.astype(f32)).astype(f16)
+                z = (z.astype(f32) + fw[3]).astype(f16)
+                a = np.maximum(z, (z.astype(f32) * f32(f16(0.2))).astype(f16))
+                wr(_D0_OFF_F + _d0_swa(fr, fc, part), np.where(ok[:, None], a, f16(0)))
+        # ---- P2: skip-branch input (FIR pad 1 + ::2 of the fromRGB map) for the four output rows, chunk nh*2 + kh ---------
+        if not prime:
+            for wave in range(8):
+                r, nh = wave >> 1, wave & 1
+                c = nh * 2 + kh
+                fc0 = np.minimum(2 * lr + 2, 62)
+                hr = []
+                for jy in range(4):
+                    a = [rd(_D0_OFF_F + _d0_swa(2 * r + jy, fc0 + jx, c)) for jx in range(4)]
+                    hr.append(_fir4(a[0], a[1], a[2], a[3]))
+                wr(_D0_OFF_XS + _d0_swz(r * 32 + lr, c), _fir4(hr[0], hr[1], hr[2], hr[3]))
+        # ---- P3: conv0, wave = new h row 8k + 2 + wave; horizontal FIR wave-locally; ring slot (row + 2) mod 12 -------------
+        for wave in range(8):
+            yh = 8 * k + 2 + wave
+            ring = _D0_OFF_HB + ((yh + 2 + 12) % 12) * 4096
+            rt = _D0_OFF_RT + wave * 4096
+            jj, cgl = lane >> 2, lane & 3
+            if yh < 0 or yh >= R:
+                for i in range(4):
+                    cb = 4 * jj + i
+                    m = cb <= 60
+                    wr((ring + _d0_slot(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], np.zeros((int(m.sum()), 8), f16))
+                continue
+            acc = np.zeros((2, 32, 32), np.float64)
+            for ky in range(3):
+                for kx in range(3):
+                    for kk in range(2):
+                        wf = frag_to_mat(wfrag(pk0, ky * 3 + kx, 0, kk))
+                        for blk in range(2):
+                            xf = rd(_D0_OFF_F + _d0_swa(wave + 2 + ky, blk * 32 + lr + kx, kk * 2 + kh))
+                            acc[blk] += wf @ frag_to_mat(xf).T
+            for blk in range(2):
+                col = blk * 32 + lr
+                xh = 60 * tx - 2 + col
+                colok = (xh >= 0) & (xh < R)
+                for g in range(4):
+                    quad = np.stack([acc[blk, 8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)]).astype(f32)
+                    bq = np.stack([b0[8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4] for i in range(64)])
+                    v = (quad + bq).astype(f16)
+                    hq = np.maximum((v.astype(f32) * f32(f16(math.sqrt(2)))).astype(f16), (v.astype(f32) * f32(f16(0.2 * math.sqrt(2)))).astype(f16))
+                    hq = np.where(colok[:, None], hq, f16(0))
+                    wr(rt + _vaddr(0, col, g) + kh * 8, hq, n=4)
+            v = []
+            for kq in range(7):
+                c = 4 * jj + kq
+                val = rd(rt + _vaddr(0, np.minimum(c, 63), cgl))
+                v.append(np.where((c < 64)[:, None], val, f16(0)))
+            for i in range(4):
+                cb = 4 * jj + i
+                m = cb <= 60
+                o = _fir4(v[i], v[i + 1], v[i + 2], v[i + 3])
+                wr((ring + _d0_slot(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], o[m])
+        if prime:
+            return
+        # ---- P4: vertical FIR over the ring -> operand image A (aliases F) ------------------------------------------------------
+        tt = t[t < 488]
+        e, half = tt % 244, tt // 244
+        off = _d0_slot(e >> 2, e & 3)
+        rows = [rd(_D0_OFF_HB + ((8 * k + i) % 12) * 4096 + off) for i in range(12)]       # window row i = h row 8k - 2 + i
+        for br in range(9):
+            m = (half == 0) if br < 5 else (half == 1)
+            wr((_D0_OFF_F + br * 4096 + off)[m], _fir4(rows[br], rows[br + 1], rows[br + 2], rows[br + 3])[m])
+        # ---- P5: stride-2 conv, wave = (output row r, n half), + skip MFMAs, transposition through the wave's row image ---------
+        for wave in range(8):
+            r, nh = wave >> 1, wave & 1
+            o_row = 4 * k + r
+            acc = np.zeros((32, 32), np.float64)
+            for ky in range(3):
+                for kx in range(3):
+                    for kk in range(2):
+                        slot = (31 if kx == 1 else (kx >> 1)) + lr
+                        xf = rd(_D0_OFF_F + (2 * r + ky) * 4096 + _d0_slot(slot, kk * 2 + kh))
+                        acc += frag_to_mat(wfrag(pk1, ky * 3 + kx, nh * 32, kk)) @ frag_to_mat(xf).T
+            v = acc.astype(f32) + b1[nh * 32:nh * 32 + 32, None]
+            v = np.maximum(v, f32(0.2) * v).astype(np.float64)
+            for kk in range(2):
+                xf = rd(_D0_OFF_XS + _d0_swz(r * 32 + lr, kk * 2 + kh))
+                wsf = np.stack([pks[nh * 32 + lr[i], kk * 16 + kh[i] * 8:kk * 16 + kh[i] * 8 + 8] for i in range(64)])
+                v += frag_to_mat(wsf) @ frag_to_mat(xf).T
+            res = v.astype(f32).astype(f16)                                  # [ch][px]
+            rt = _D0_OFF_RT + wave * 4096
+            for g in range(4):
+                quad = np.stack([res[8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)])
+                wr(rt + _d0_swz(lr, g) + kh * 8, quad, n=4)
+            for kq in range(2):
+                vv = lane + 64 * kq
+                pix, chv = vv >> 2, vv & 3
+                data = rd(rt + _d0_swz(pix, chv))
+                ox = 30 * tx + pix
+                for i in range(64):
+                    if pix[i] < 30 and ox[i] < Ro and o_row < Ro:
+                        assert np.isnan(out[b, o_row, ox[i], nh * 32 + chv[i] * 8]), "output written twice"
+                        out[b, o_row, ox[i], nh * 32 + chv[i] * 8:nh * 32 + chv[i] * 8 + 8] = data[i]
+
+    for wg in range(n_wg):
+        first, last = wg * per_block, min((wg + 1) * per_block, n_steps)
+        need_prime = True
+        for it in range(first, last):
+            b, rem = divmod(it, tiles_x * tiles_y)
+            tx, k = divmod(rem, tiles_y)
+            if need_prime or k == 0:
+                lds[:] = np.float16(np.nan)            # nothing may be carried across a priming point
+                run_item(b, tx, k - 1, True)
+            need_prime = False
+            run_item(b, tx, k, False)
+    assert not np.isnan(out).any(), "some outputs were never written"
+    return out

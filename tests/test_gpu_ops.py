@@ -406,6 +406,44 @@ def test_d_block_down_fused(B, R, Cin, Cout):
         check("D down fused border " + name, nchw(got)[sl], ref[sl], 8e-3)
 
 
+def _dblock0_case(B, R, seed=21):
+    y = rnd(seed, "y", (B, 3, R, R), 0.8); fw = rnd(seed, "fw", (32, 3, 1, 1)); fb = rnd(seed, "fb", (32,), 0.3)
+    w0 = rnd(seed, "w0", (32, 32, 3, 3)); b0 = rnd(seed, "b0", (32,), 0.3)
+    w1 = rnd(seed, "w1", (64, 32, 3, 3)); b1 = rnd(seed, "b1", (64,), 0.3); ws = rnd(seed, "ws", (64, 32, 1, 1))
+    img = ((torch.tensor(y) + 1) / 2).clip(0, 1) * 2 - 1                                   # utils.py:14-21
+    x = sg._bias_act(sg._conv(img, torch.tensor(fw)), torch.tensor(fb))                    # fromRGB (models.py:1125-1143)
+    h = sg._bias_act(sg._conv(x, torch.tensor(w0), padding=1), torch.tensor(b0))
+    h1 = sg._bias_act(sg._conv(sg._filter(h, sg._fir(), 2, 2), torch.tensor(w1), stride=2), torch.tensor(b1))
+    xs = sg._filter(x, sg._fir(), 1, 1)[:, :, ::2, ::2]
+    ref = ((h1 + sg._conv(xs, torch.tensor(ws))) / math.sqrt(2)).numpy()
+    return (y, fw.reshape(32, 3) / math.sqrt(3), fb, w0, b0, w1, ws, b1), ref
+
+
+@pytest.mark.parametrize("B,R", [
+    (1, 64),       # 16 steps for 256 workgroups: one step per workgroup, every step primed; second tile column holds 2 of 30 pixels
+    (2, 72),       # R/2 = 36: ragged last tile column (6 of 30), 9 steps per column
+    (3, 192),      # 3 x 4 x 24 = 288 steps: two-step ranges, priming mid-column; interior tiles without any padding mask
+    (8, 256),      # 1280 steps: five per workgroup, ranges crossing column and sample boundaries
+])
+def test_dblock0_fused(B, R):
+    """conv_d0.hip: the discriminator's whole full-resolution block in one kernel (skip image -> fromRGB -> conv3x3 -> FIR pad 2 ->
+    conv3x3 stride 2, + the 1x1 skip branch of FIR pad 1 [::2] of the fromRGB map; stylegan2/models.py:1125-1143, modules.py:1204-1254,
+    1587-1601) against the oracle's UNFUSED ops, and — where the two-kernel form applies — against conv_stream<fromrgb> + conv_down."""
+    args, ref = _dblock0_case(B, R)
+    got = ops.dblock0(*args)
+    check("D block0 fused B%d R%d" % (B, R), nchw(got), ref, 6e-3)
+    for name, sl in (("top", np.s_[:, :, :2, :]), ("bottom", np.s_[:, :, -2:, :]), ("left", np.s_[:, :, :, :2]), ("right", np.s_[:, :, :, -2:])):
+        check("D block0 fused border " + name, nchw(got)[sl], ref[sl], 8e-3)
+    if R >= 192 and R % 64 == 0 and ops is not None and hasattr(ops, "load_library"):
+        two = ops.dblock0(*args, impl=1)
+        # same fromRGB / conv0 arithmetic bit for bit; the FIR runs horizontally first here and vertically first in conv_down (one fp16
+        # rounding each way), so outputs agree to a couple of fp16 ulps
+        d = np.abs(got - two)
+        diag("[dblock0] fused vs conv_stream<fromrgb> + conv_down: max |diff| %.3e, %.1f %% of outputs differ" % (d.max(), 100 * (got != two).mean()))
+        assert d.max() <= 2.0 ** -7 * max(1.0, float(np.abs(two).max())), float(d.max())
+        check("D block0 two-kernel form B%d R%d" % (B, R), nchw(two), ref, 6e-3)
+
+
 @pytest.mark.parametrize("impl,M,N,K", [(1, 150, 200, 96), (2, 150, 256, 192), (2, 400, 192, 64), (2, 128, 128, 128)])
 def test_gemm_modes(impl, M, N, K):
     a = rnd(5, "a", (M, K)); w = rnd(5, "w", (N, K), K ** -0.5); bias = rnd(5, "b", (N,), 0.2)

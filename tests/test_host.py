@@ -164,6 +164,23 @@ def test_kernel_arithmetic_emulated_on_cpu():
     T.test_resize_patches(64, 32, 8)
 
 
+def test_dblock0_index_emulation():
+    """conv_d0.hip's index math (patch / ring / priming / masks / fragment and swizzle addresses) emulated on the CPU against the
+    oracle's unfused ops: one workgroup per step (every step primed) and three workgroups with mid-column range starts."""
+    import emu_ops
+    import test_gpu_ops as T
+    saved = T.ops
+    T.ops = emu_ops
+    try:
+        T.test_dblock0_fused(1, 64)
+        args, ref = T._dblock0_case(1, 72, seed=5)
+        for n_wg in (1, 4):
+            got = emu_ops.dblock0(*args, n_wg=n_wg)
+            T.check("D block0 emulated, %d workgroups" % n_wg, T.nchw(got), ref, 6e-3)
+    finally:
+        T.ops = saved
+
+
 def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

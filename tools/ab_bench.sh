@@ -1,13 +1,13 @@
 #!/bin/bash
 # A/B of environment knobs on ONE box: tools/ab_bench.sh <out_dir> "<name>:<ENV=1 ENV2=..>" ...   (name "base": no knobs)
-# Each variant: python bench.py --steps 20 --warmup 3 --no-cpu-baseline, JSON line + per-layer table under <out_dir>/.
+# Each variant: python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-legs, JSON line + per-layer table under <out_dir>/.
 out=$1; shift
 mkdir -p "$out"
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}
   [ "$envs" = "$spec" ] && envs=""
   echo "== $name [$envs]" | tee -a "$out/summary.txt"
-  env $envs GLASS_BENCH_DETAIL="$out/detail_$name.json" timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench_$name.json" 2> "$out/bench_$name.err"
+  env $envs GLASS_BENCH_DETAIL="$out/detail_$name.json" timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-legs > "$out/bench_$name.json" 2> "$out/bench_$name.err"
   python - "$out/bench_$name.json" <<'PY' | tee -a "$out/summary.txt"
 import json, sys
 try:
