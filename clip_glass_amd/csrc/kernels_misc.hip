@@ -60,12 +60,14 @@ __device__ __forceinline__ void dense_body(const float* x, int ldx, int P, int K
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[j] += w[u] * xs[pg * 4 + j][kk + u];
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(w[u], xs[pg * 4 + j][kk + u], acc[j]);   // explicit FMA for every row:
+                // left to -ffp-contract the compiler packed rows (0, 1) as v_pk_fma_f32 and rows (2, 3) as mul + add, so a row's last bit
+                // depended on its POSITION in the launch (found by the full-size text-tower test, r04)
             }
             for (; kk < kmax; ++kk) {
                 const float w = wt[(long long)(k0 + kk) * N + n];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += w * xs[pg * 4 + j][kk];
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_fmaf(w, xs[pg * 4 + j][kk], acc[j]);
             }
         }
         __syncthreads();
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void dense_splitk_kernel(const float* x, int l
 #pragma unroll
         for (int u = 0; u < 16; ++u)
 #pragma unroll
-            for (int j = 0; j < DENSE_PB; ++j) acc[j] += w[u] * xs[j * K + kb + kk + u];
+            for (int j = 0; j < DENSE_PB; ++j) acc[j] = __builtin_fmaf(w[u], xs[j * K + kb + kk + u], acc[j]);
     }
 #pragma unroll
     for (int j = 0; j < DENSE_PB; ++j) red[(wave * DENSE_PB + j) * 64 + lane] = acc[j];
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(1024) void mapping_fused_kernel(const float* z, flo
                 for (int u = 0; u < 8; ++u) {
                     const float xv = u < 4 ? xa[u & 3] : xb[u & 3];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[r][c] += w[u][c] * xv;
+                    for (int c = 0; c < NC; ++c) acc[r][c] = __builtin_fmaf(w[u][c], xv, acc[r][c]);
                 }
             }
         }
