@@ -192,7 +192,7 @@ __global__ __launch_bounds__(1024) void mapping_fused_kernel(const float* z, flo
                 for (int u = 0; u < 8; ++u) {
                     const float xv = u < 4 ? xa[u & 3] : xb[u & 3];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[r][c] = __builtin_fmaf(w[u][c], xv, acc[r][c]);
+                    for (int c = 0; c < NC; ++c) acc[r][c] = __builtin_elementwise_fma(w[u][c], f4{xv, xv, xv, xv}, acc[r][c]);   // (explicit FMA, as in dense_body)
                 }
             }
         }
