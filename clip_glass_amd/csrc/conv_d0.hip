@@ -21,7 +21,10 @@
 // LDS fragment (the pixels) per MFMA — the LDS-fed ceiling of conv_stream / conv_down was 1.5 reads per MFMA.
 //
 // Phases of a step (4 workgroup barriers):
-//   P1  image values (prefetched one step ahead, 1-2 pixels per thread) -> fromRGB -> F (zero outside the image: conv0's padding)
+//   P1  image values (prefetched one step ahead) -> fromRGB AS AN MFMA (K = r, g, b, 1 of 16 slots; the weight / bias rows are one
+//       register-resident fragment; masked pixels are all-zero operands, so the zero padding of conv0 costs two selects) -> F.
+//       Round 4's first version did this in packed fp16 on the VALU: 340 of the step's 1240 VALU instructions per wave, in a kernel
+//       that is bound by VALU issue (the two kernels it replaces spend 7900 wave-instructions on the same area, v1 spent 9900)
 //   P2  skip-branch input: FIR (pad 1) + ::2 of F for the step's 4 x 30 output pixels -> XS image (MFMA B fragments of the skip conv)
 //   P3  conv0: wave w = new h row 8k+2+w, 2 blocks x 18 MFMAs; bias + lrelu in packed fp16 exactly as conv_stream did it; h is zeroed
 //       outside the image (the FIR's padding); the row goes through the wave's own row image and the HORIZONTAL FIR runs wave-locally
@@ -42,8 +45,9 @@ constexpr int ROWB = 64 * 64;                         // one 64-slot row of 64-b
 constexpr int OFF_RT = F_BYTES;                       // per-wave row image (8 x 4096)
 constexpr int OFF_HB = OFF_RT + 8 * ROWB;             // ring of 12 horizontally blurred, de-interleaved h rows
 constexpr int OFF_XS = OFF_HB + 12 * ROWB;            // skip-branch input [4 rows][32 px][32 ch]
-constexpr int OFF_C = OFF_XS + 4 * 32 * 64;           // bias0 [32] f32, bias1 [64] f32, fromRGB rows [4][32] f16
-constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4 + 128 * 2;   // 142976
+constexpr int OFF_C = OFF_XS + 4 * 32 * 64;           // bias0 [32] f32, bias1 [64] f32
+constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4;    // 142720
+constexpr int NFB = (FR * FC + 31) / 32;              // 25 blocks of 32 patch pixels (the last holds 24); block i belongs to wave i % 8
 static_assert(9 * ROWB <= F_BYTES, "operand image aliases the patch");
 
 // patch image: pixel (pr, pc) at row pr * FP + pc, 16-byte chunk XOR-swizzled by the COLUMN only (conv_stream.hip's layout)
@@ -77,7 +81,6 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Cb0 = (float*)(smem + OFF_C);
     float* Cb1 = Cb0 + 32;
-    half_t* Cf = (half_t*)(Cb1 + 64);
     const int R = p.R, Ro = R >> 1;
     const int first = blockIdx.x * per_block;
     const int last = min(first + per_block, n_steps);
@@ -85,17 +88,21 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 
     // ---- resident constants (LDS) and weight fragments (registers) -----------------------------------------------------------------
-    h8 W0f[9][2], W1f[9][2], Wsf[2];
+    h8 W0f[9][2], W1f[9][2], Wsf[2], Wrgb;
     {
         const int t = threadIdx.x;
-        if (t < 32) {
-            Cf[t] = (half_t)(p.rgb_w[t * 3] * GLASS_SQRT2);
-            Cf[32 + t] = (half_t)(p.rgb_w[t * 3 + 1] * GLASS_SQRT2);
-            Cf[64 + t] = (half_t)(p.rgb_w[t * 3 + 2] * GLASS_SQRT2);
-            Cf[96 + t] = (half_t)(p.rgb_b[t] * GLASS_SQRT2);
-            Cb0[t] = p.b0[t];
-        }
+        if (t < 32) Cb0[t] = p.b0[t];
         if (t < 64) Cb1[t] = p.b1[t];
+        {   // fromRGB as an MFMA: A row n = (w[n][r], w[n][g], w[n][b], bias[n]) * sqrt2 in k slots 0 .. 3 (lane half 0), zeros elsewhere
+            const int n = t & 31;
+            Wrgb = zero;
+            if (((t >> 5) & 1) == 0) {
+                Wrgb[0] = (half_t)(p.rgb_w[n * 3] * GLASS_SQRT2);
+                Wrgb[1] = (half_t)(p.rgb_w[n * 3 + 1] * GLASS_SQRT2);
+                Wrgb[2] = (half_t)(p.rgb_w[n * 3 + 2] * GLASS_SQRT2);
+                Wrgb[3] = (half_t)(p.rgb_b[n] * GLASS_SQRT2);
+            }
+        }
         // lane (n = lr, k half kh) holds W[tap][n][kk * 16 + kh * 8 .. + 7]: the A operand of mfma32 (common.h)
         const int lr = t & 31, kh = (t >> 5) & 1, nh = (t >> 6) & 1;
 #pragma unroll
@@ -112,6 +119,40 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
             for (int q = 0; q < 8; ++q) Wsf[kk][q] = (half_t)((float)w[q] * 0.70710678118654752440f);
         }
+    }
+
+    // ---- lane-constant LDS offsets, computed ONCE and kept opaque (left to the compiler they were rebuilt in every step: ~250 of the first
+    // version's 1240 VALU instructions per wave and step were address arithmetic; row / block / tap-row steps are immediate offsets) ------
+    int fb[3][2], sb[3][2], xb[4], hv[7], hw4[4], rtw, p4off, ow[4], orr[2];
+    {
+        const int t = threadIdx.x, lr = t & 31, kh = (t >> 5) & 1, lane = t & 63, wave = t >> 6;
+        const int r = wave >> 1, nh = wave & 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                fb[kx][kk] = opaque(swa(wave + 2, lr + kx, kk * 2 + kh));                                        // P3: + ky * FP * 64 + blk * 2048
+                sb[kx][kk] = opaque(2 * r * ROWB + swz((kx == 1 ? 31 : (kx >> 1)) + lr, kk * 2 + kh));            // P5: + ky * ROWB
+            }
+        const int fc0 = min(2 * lr + 2, FC - 4);
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) xb[jx] = opaque(swa(2 * r, fc0 + jx, nh * 2 + kh));                        // P2: + jy * FP * 64
+        const int jj = lane >> 2, cgl = lane & 3;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) hv[q] = opaque(OFF_RT + wave * ROWB + vrot(min(4 * jj + q, 63), cgl));         // horizontal FIR reads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cbk = 4 * jj + i;
+            hw4[i] = opaque(swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl));                                   // ring writes (+ ring row)
+            ow[i] = opaque(OFF_RT + wave * ROWB + swz(lr, i) + kh * 8);                                           // P5 transposition writes (g = i)
+        }
+        rtw = opaque(OFF_RT + wave * ROWB + vrot(lr, 0) + kh * 8);                                                // conv0 row image: + g * 16 + blk * 2048
+        {
+            const int half = t >= 244 ? 1 : 0, e = t - 244 * half;
+            p4off = opaque(swz(e >> 2, e & 3));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) orr[u] = opaque(OFF_RT + wave * ROWB + swz((lane + 64 * u) >> 2, (lane + 64 * u) & 3));
     }
 
     // ---- the walk: steps (b, tx, k), k fastest (down a tile column); a priming item (k - 1, no output) opens every range / column ---
@@ -143,17 +184,18 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         return r;
     };
 
-    // image values of an item's patch: pixels t and 512 + t (< 792) of the 12 x 66 patch; unconditional loads at clamped coordinates
-    // (the zero padding is a mask applied when the pixel is written to LDS)
-    float yv[2][3];
+    // image values of an item's patch: patch pixel 32 * (wave + 8u) + lr for u = 0 .. 3 (both lane halves fetch the same pixel: the
+    // MFMA operand of a pixel lives in lane half 0); unconditional loads at clamped coordinates (the zero padding is a mask applied
+    // when the operand is built)
+    float yv[4][3];
     auto load_image = [&](const Item& c) {
         const int t = opaque(threadIdx.x);
         const int y0 = 8 * c.k - 1, x0 = 60 * c.tx - 3;
         const long long hw = (long long)R * R;
         const float* yb = p.rgb_y + (long long)c.b * 3 * hw;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int px = min(t + 512 * u, FR * FC - 1);
+        for (int u = 0; u < 4; ++u) {
+            const int px = min(32 * ((t >> 6) + 8 * u) + (t & 31), FR * FC - 1);
             const int fr = px / FC, fc = px - fr * FC;
             const int iy = min(max(y0 + fr, 0), R - 1), ix = min(max(x0 + fc, 0), R - 1);
             const int off = iy * R + ix;
@@ -166,50 +208,49 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         const int b = c.b, tx = c.tx, k = c.k;
         const int y0 = 8 * k - 1, x0 = 60 * tx - 3;
         __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
-        // ---- P1: fromRGB of this thread's pixel(s) -> F ----------------------------------------------------------------------------
+        // ---- P1: fromRGB of this wave's patch blocks -> F: one MFMA per 32 pixels, lrelu in packed fp16, four 8-byte stores per lane -------
         {
-            const int t = opaque(threadIdx.x);
-            half_t hc[2][3];
-            int lrow[2], key[2];
-            bool ok[2];
+            const int t = opaque(threadIdx.x), lr1 = t & 31, kh1 = (t >> 5) & 1, wv = uni(t >> 6);
+            f16x zacc;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int px = min(t + 512 * u, FR * FC - 1);
+            for (int q = 0; q < 16; ++q) zacc[q] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (wv + 8 * u >= NFB) break;                                          // (uniform: only wave 0 has a fourth block)
+                const int pxr = 32 * (wv + 8 * u) + lr1, px = min(pxr, FR * FC - 1);
                 const int fr = px / FC, fc = px - fr * FC;
                 const int iy = y0 + fr, ix = x0 + fc;
+                const bool ok = kh1 == 0 && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
+                h8 cf = zero;                                                          // (r, g, b, 1, 0, 0, 0, 0) or all zero
+                cf[0] = (half_t)(fminf(fmaxf((yv[u][0] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
+                cf[1] = (half_t)(fminf(fmaxf((yv[u][1] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
+                cf[2] = (half_t)(fminf(fmaxf((yv[u][2] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
+                cf[3] = (half_t)1.f;
+                if (!ok) cf = zero;
+                const f16x z = mfma32(Wrgb, cf, zacc);                                 // z[4g + q] = x[channel 8g + 4kh + q] of pixel lr, fp32
+                char* dst = smem + ((fr * FP + fc) << 6) + kh1 * 8;
+                const int key = (fc >> 2) & 3;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
-                    hc[u][ch] = (half_t)(fminf(fmaxf((yv[u][ch] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
-                ok[u] = (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
-                lrow[u] = (fr * FP + fc) << 6;
-                key[u] = (fc >> 2) & 3;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    h4 v;
 #pragma unroll
-            for (int part = 0; part < 4; ++part) {
-                const h8 f0 = *(const h8*)(Cf + part * 8), f1 = *(const h8*)(Cf + 32 + part * 8), f2 = *(const h8*)(Cf + 64 + part * 8),
-                         f3 = *(const h8*)(Cf + 96 + part * 8);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const h8 z = f0 * hc[u][0] + f1 * hc[u][1] + f2 * hc[u][2] + f3;                        // v_pk_fma_f16
-                    const h8 a = __builtin_elementwise_max(z, z * (half_t)0.2f);
-                    if (u == 0 || t < FR * FC - 512) *(h8*)(smem + lrow[u] + ((part ^ key[u]) << 4)) = ok[u] ? a : zero;
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)z[g * 4 + q];
+                    v = __builtin_elementwise_max(v, v * (half_t)0.2f);
+                    if (pxr < FR * FC) *(h4*)(dst + ((g ^ key) << 4)) = v;
                 }
             }
         }
         load_image(nx);        // the next item's image values travel during this item's MFMA phases
         __syncthreads();       // B1: patch complete
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
-        char* RT = smem + OFF_RT + wave * ROWB;
         // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, this wave's output row, chunk nh * 2 + kh ---------------
         if (!c.prime) {
             const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + kh;
-            const int fc0 = min(2 * lr + 2, FC - 4);
             h8 hr[4];
 #pragma unroll
             for (int jy = 0; jy < 4; ++jy) {
-                const int pr = 2 * r + jy;
-                const h8 a0 = *(const h8*)(smem + swa(pr, fc0, ch)), a1 = *(const h8*)(smem + swa(pr, fc0 + 1, ch)),
-                         a2 = *(const h8*)(smem + swa(pr, fc0 + 2, ch)), a3 = *(const h8*)(smem + swa(pr, fc0 + 3, ch));
+                const h8 a0 = *(const h8*)(smem + xb[0] + jy * (FP * 64)), a1 = *(const h8*)(smem + xb[1] + jy * (FP * 64)),
+                         a2 = *(const h8*)(smem + xb[2] + jy * (FP * 64)), a3 = *(const h8*)(smem + xb[3] + jy * (FP * 64));
                 hr[jy] = fir4(a0, a1, a2, a3);
             }
             *(h8*)(smem + OFF_XS + swz(r * 32 + lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
@@ -218,13 +259,11 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         {
             const int yh = 8 * k + 2 + wave;                                           // uniform per wave
             char* ring = smem + OFF_HB + ((yh + 14) % 12) * ROWB;                      // slot of h row y: (y + 2) mod 12
-            const int jj = lane >> 2, cgl = lane & 3;
+            const int jj = lane >> 2;
             if ((unsigned)yh >= (unsigned)R) {                                         // outside the image: the FIR's zero padding
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cbk = 4 * jj + i;
-                    if (cbk <= 60) *(h8*)(ring + swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl)) = zero;
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = zero;
             } else {
                 f16x acc[2];
 #pragma unroll
@@ -239,15 +278,15 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                             for (int blk = 0; blk < 2; ++blk) {
-                                const h8 xf = *(const h8*)(smem + swa(wave + 2 + ky, blk * 32 + lr + kx, kk * 2 + kh));
+                                const h8 xf = *(const h8*)(smem + fb[kx][kk] + ky * (FP * 64) + blk * 2048);
                                 acc[blk] = mfma32(W0f[ky * 3 + kx][kk], xf, acc[blk]);
                             }
                 // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
                 const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
+                const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
-                    const int col = blk * 32 + lr;
-                    const bool colok = (unsigned)(60 * tx - 2 + col) < (unsigned)R;
+                    const bool colok = !edge || (unsigned)(60 * tx - 2 + blk * 32 + lr) < (unsigned)R;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f4 bb = *(const f4*)(Cb0 + 8 * g + 4 * kh);
@@ -255,23 +294,20 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = (half_t)(acc[blk][g * 4 + q] + bb[q]);
                         h4 hq = __builtin_elementwise_max(v * k1, v * k2);
-                        if (!colok) hq = h4{0, 0, 0, 0};
-                        *(h4*)(RT + vrot(col, g) + kh * 8) = hq;
+                        if (edge && !colok) hq = h4{0, 0, 0, 0};
+                        *(h4*)(smem + rtw + g * 16 + blk * 2048) = hq;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
                 h8 v[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    const int col = 4 * jj + q;
-                    v[q] = *(const h8*)(RT + vrot(min(col, 63), cgl));
-                    if (col > 63) v[q] = zero;
+                    v[q] = *(const h8*)(smem + hv[q]);
+                    if (q >= 4 && jj == 15) v[q] = zero;                               // window columns 64 .. 66 do not exist
                 }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cbk = 4 * jj + i;
-                    if (cbk <= 60) *(h8*)(ring + swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl)) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
-                }
+                for (int i = 0; i < 4; ++i)
+                    if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -281,8 +317,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         {
             const int t = opaque(threadIdx.x);
             if (t < 488) {
-                const int half = t >= 244 ? 1 : 0, e = t - 244 * half;
-                const int off = swz(e >> 2, e & 3);
+                const int half = t >= 244 ? 1 : 0;
+                const int off = p4off;
                 const int base = uni((8 * k + 24) % 12);                                // ring slot of window row 0 (h row 8k - 2)
                 const int i0 = half * 5;
                 h8 v[8];
@@ -310,7 +346,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                     for (int kk = 0; kk < 2; ++kk) {
-                        const h8 xf = *(const h8*)(smem + (2 * r + ky) * ROWB + swz((kx == 1 ? 31 : (kx >> 1)) + lr, kk * 2 + kh));
+                        const h8 xf = *(const h8*)(smem + sb[kx][kk] + ky * ROWB);
                         acc = mfma32(W1f[ky * 3 + kx][kk], xf, acc);
                     }
 #pragma unroll
@@ -330,7 +366,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 h4 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)acc[g * 4 + q];
-                *(h4*)(RT + swz(lr, g) + kh * 8) = o;
+                *(h4*)(smem + ow[g]) = o;
             }
             __builtin_amdgcn_wave_barrier();
             const int orow = 4 * k + r;
@@ -338,7 +374,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
-                const h8 d = *(const h8*)(RT + swz(pix, chv));
+                const h8 d = *(const h8*)(smem + orr[u]);
                 if (pix < TW && 30 * tx + pix < Ro && orow < Ro) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
             }
             __builtin_amdgcn_wave_barrier();

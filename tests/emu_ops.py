@@ -539,19 +539,19 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
 
     def run_item(b, tx, k, prime):
         y0, x0 = 8 * k - 1, 60 * tx - 3            # image row / column of F[0][0]
-        # ---- P1: fromRGB patch, thread -> pixels t and 512 + t (< 792) --------------------------------------------------
-        for px in (t, t[t < 280] + 512):
+        # ---- P1: fromRGB patch as an MFMA per 32-pixel block (block i of 25 -> wave i % 8); lane half 0 carries (r, g, b, 1) ------------
+        for blk in range(25):
+            px = 32 * blk + np.arange(32)
+            px = px[px < 792]
             fr, fc = px // 66, px % 66
             iy, ix = y0 + fr, x0 + fc
             v = y[b][:, np.clip(iy, 0, R - 1), np.clip(ix, 0, R - 1)].T             # [n, 3] clamped loads
             c3 = (np.clip((v + f32(1)) * f32(0.5), 0, 1) * f32(2) - f32(1)).astype(f16)
             ok = (iy >= 0) & (iy < R) & (ix >= 0) & (ix < R)
             for part in range(4):
-                fw = Cf[:, part * 8:part * 8 + 8].astype(f32)
-                z = (c3[:, 0:1].astype(f32) * fw[0]).astype(f16)
-                z = (c3[:, 1:2].astype(f32) * fw[1] + z.astype(f32)).astype(f16)
-                z = (c3[:, 2:3].astype(f32) * fw[2] + z.astype(f32)).astype(f16)
-                z = (z.astype(f32) + fw[3]).astype(f16)
+                fw = Cf[:, part * 8:part * 8 + 8].astype(np.float64)
+                z = (c3[:, 0:1].astype(np.float64) * fw[0] + c3[:, 1:2].astype(np.float64) * fw[1] + c3[:, 2:3].astype(np.float64) * fw[2]
+                     + fw[3]).astype(f32).astype(f16)                             # fp16 x fp16 products, fp32 accumulate (MFMA)
                 a = np.maximum(z, (z.astype(f32) * f32(f16(0.2))).astype(f16))
                 wr(_D0_OFF_F + _d0_swa(fr, fc, part), np.where(ok[:, None], a, f16(0)))
         # ---- P2: skip-branch input (FIR pad 1 + ::2 of the fromRGB map) for the four output rows, chunk nh*2 + kh ---------
