@@ -9,27 +9,32 @@
 // store epilogue and a full staging prologue per 64-byte pixel in kernels that are bound by instruction issue, 4.3 ms.  Here only
 // the 12-byte-per-pixel image comes in and the 128-byte-per-pixel block output goes out; x and h exist in LDS only.
 //
-// Geometry.  A step produces 4 output rows x 30 output columns (of the R/2 grid).  It needs h rows 8k-2 .. 8k+9 and columns
-// 60tx-2 .. 60tx+61 (a 12 x 64 window: 64 columns = two 32-pixel MFMA blocks per row, which is what fixes the tile width at 30),
-// and for those the fromRGB map x on rows 8k-1 .. 8k+10 x columns 60tx-3 .. 60tx+62 (the patch F, 12 x 66 pixels).  Steps walk DOWN a
-// tile column, so 4 of the 12 window rows are carried from the previous step: a step computes 8 new h rows.  A workgroup's range
-// starts (and every column starts) with a PRIMING step that only computes the carried rows.
+// Geometry.  A step produces 2 output rows x 30 output columns (of the R/2 grid).  It needs h rows 4k-2 .. 4k+5 and columns
+// 60tx-2 .. 60tx+61 (an 8 x 64 window: 64 columns = two 32-pixel MFMA blocks per row, which is what fixes the tile width at 30),
+// and for the NEW rows of that window the fromRGB map x on rows 4k+1 .. 4k+6 x columns 60tx-3 .. 60tx+62 (the patch F, 6 x 66 pixels).
+// Steps walk DOWN a tile column, so 4 of the 8 window rows are carried from the previous step: a step computes 4 new h rows.  The
+// skip-branch input of an output row needs x rows 2o-1 .. 2o+2: the patch of step k holds them for rows 2k+1 and 2k+2, so that input
+// runs one row AHEAD of the stride-2 conv, through a 3-row ring.  A workgroup's range starts (and every column starts) with a
+// PRIMING step that only computes what the first real step finds carried.
 //
-// One 512-thread workgroup per CU, ALL weights in registers: a wave owns one new h row (conv0: one 32-channel n block, 18 weight
-// fragments = 72 VGPRs) and later one (output row, 32-channel n half) of the stride-2 conv (18 + 2 fragments = 80 VGPRs).  D's
-// weights are the same for every candidate, so the fragments are loaded once per workgroup lifetime and the MFMA loops read ONE
-// LDS fragment (the pixels) per MFMA — the LDS-fed ceiling of conv_stream / conv_down was 1.5 reads per MFMA.
+// 256-thread workgroups, TWO per CU (79 KB of LDS each), ALL weights in registers: a wave owns one new h row (conv0: one 32-channel
+// n block, 18 weight fragments = 72 VGPRs) and later one (output row, 32-channel n half) of the stride-2 conv (18 + 2 fragments = 80
+// VGPRs).  D's weights are the same for every candidate, so the fragments are loaded once per workgroup lifetime and the MFMA
+// loops read ONE LDS fragment (the pixels) per MFMA — the LDS-fed ceiling of conv_stream / conv_down was 1.5 reads per MFMA.
+// (Round 4's first two versions were ONE 512-thread workgroup per CU with 4-row steps: every phase below is bound by a different
+// unit — VALU, LDS, MFMA — and with a single workgroup the phases add up: 4.7 ms, then 4.3 ms after a VALU diet, = the two kernels
+// it replaces.  Two independent workgroups per CU interleave their phases.)
 //
 // Phases of a step (4 workgroup barriers):
 //   P1  image values (prefetched one step ahead) -> fromRGB AS AN MFMA (K = r, g, b, 1 of 16 slots; the weight / bias rows are one
 //       register-resident fragment; masked pixels are all-zero operands, so the zero padding of conv0 costs two selects) -> F.
 //       Round 4's first version did this in packed fp16 on the VALU: 340 of the step's 1240 VALU instructions per wave, in a kernel
 //       that is bound by VALU issue (the two kernels it replaces spend 7900 wave-instructions on the same area, v1 spent 9900)
-//   P2  skip-branch input: FIR (pad 1) + ::2 of F for the step's 4 x 30 output pixels -> XS image (MFMA B fragments of the skip conv)
-//   P3  conv0: wave w = new h row 8k+2+w, 2 blocks x 18 MFMAs; bias + lrelu in packed fp16 exactly as conv_stream did it; h is zeroed
+//   P2  skip-branch input: FIR (pad 1) + ::2 of F for output rows 2k+1, 2k+2 -> XS ring (MFMA B fragments of the skip conv)
+//   P3  conv0: wave w = new h row 4k+2+w, 2 blocks x 18 MFMAs; bias + lrelu in packed fp16 exactly as conv_stream did it; h is zeroed
 //       outside the image (the FIR's padding); the row goes through the wave's own row image and the HORIZONTAL FIR runs wave-locally
-//       (LDS is in order per wave: no workgroup barrier), de-interleaved (even | odd blurred columns) into the 12-row ring HB
-//   P4  vertical FIR over the ring -> operand image A of the stride-2 conv (9 rows; aliases F)
+//       (LDS is in order per wave: no workgroup barrier), de-interleaved (even | odd blurred columns) into the 8-row ring HB
+//   P4  vertical FIR over the ring -> operand image A of the stride-2 conv (5 rows; aliases F)
 //   P5  stride-2 conv: wave (row r, n half): 18 MFMAs; bias + lrelu in the accumulators; + 2 skip MFMAs (the skip rows carry the
 //       merge's 1/sqrt2, the activation's sqrt2 cancels against it); transposition through the wave's row image; 16-byte stores.
 // Index-level CPU emulation of the whole scheme (patch / ring / priming / masks / fragment addresses): tests/emu_ops.py dblock0
@@ -39,16 +44,19 @@
 #include <stdlib.h>
 
 namespace {
-constexpr int NTHR = 512, TW = 30, FP = 68, FR = 12, FC = 66;
-constexpr int F_BYTES = FR * FP * 64;                 // 52224: fromRGB patch; the operand image A (9 x 4096) aliases it
+constexpr int NW = 4, NTHR = 64 * NW;                 // waves = new h rows per step
+constexpr int TW = 30, FP = 66, FR = NW + 2, FC = 66; // patch: 6 rows x 66 columns (the swizzle key is the column only: any pitch works)
+constexpr int RING = 8, AR = 5, XSR = 3;              // h window rows (4 carried + 4 new), operand rows, skip-input ring rows
+constexpr int F_BYTES = FR * FP * 64;                 // 25344: fromRGB patch; the operand image A (5 x 4096) aliases it
 constexpr int ROWB = 64 * 64;                         // one 64-slot row of 64-byte pixels
-constexpr int OFF_RT = F_BYTES;                       // per-wave row image (8 x 4096)
-constexpr int OFF_HB = OFF_RT + 8 * ROWB;             // ring of 12 horizontally blurred, de-interleaved h rows
-constexpr int OFF_XS = OFF_HB + 12 * ROWB;            // skip-branch input [4 rows][32 px][32 ch]
-constexpr int OFF_C = OFF_XS + 4 * 32 * 64;           // bias0 [32] f32, bias1 [64] f32
-constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4;    // 142720
-constexpr int NFB = (FR * FC + 31) / 32;              // 25 blocks of 32 patch pixels (the last holds 24); block i belongs to wave i % 8
-static_assert(9 * ROWB <= F_BYTES, "operand image aliases the patch");
+constexpr int OFF_RT = F_BYTES;                       // per-wave row image (4 x 4096)
+constexpr int OFF_HB = OFF_RT + NW * ROWB;            // ring of 8 horizontally blurred, de-interleaved h rows
+constexpr int OFF_XS = OFF_HB + RING * ROWB;          // skip-branch input ring [3 rows][32 px][32 ch]
+constexpr int OFF_C = OFF_XS + XSR * 32 * 64;         // bias0 [32] f32, bias1 [64] f32
+constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4;    // 81024 -> two workgroups per CU
+constexpr int NFB = (FR * FC + 31) / 32;              // 13 blocks of 32 patch pixels (the last holds 12); block i belongs to wave i % 4
+static_assert(AR * ROWB <= F_BYTES, "operand image aliases the patch");
+static_assert(2 * ((LDS_BYTES + 511) / 512 * 512) <= 160 * 1024, "two workgroups per CU");
 
 // patch image: pixel (pr, pc) at row pr * FP + pc, 16-byte chunk XOR-swizzled by the COLUMN only (conv_stream.hip's layout)
 __device__ __forceinline__ int swa(int pr, int pc, int chunk) { return ((pr * FP + pc) << 6) + ((chunk ^ ((pc >> 2) & 3)) << 4); }
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 
     // ---- lane-constant LDS offsets, computed ONCE and kept opaque (left to the compiler they were rebuilt in every step: ~250 of the first
     // version's 1240 VALU instructions per wave and step were address arithmetic; row / block / tap-row steps are immediate offsets) ------
-    int fb[3][2], sb[3][2], xb[4], hv[7], hw4[4], rtw, p4off, ow[4], orr[2];
+    int fb[3][2], sb[3][2], xb[4], hv[7], hw4[4], rtw, p4off, ow[4];
     {
         const int t = threadIdx.x, lr = t & 31, kh = (t >> 5) & 1, lane = t & 63, wave = t >> 6;
         const int r = wave >> 1, nh = wave & 1;
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                fb[kx][kk] = opaque(swa(wave + 2, lr + kx, kk * 2 + kh));                                        // P3: + ky * FP * 64 + blk * 2048
+                fb[kx][kk] = opaque(swa(wave, lr + kx, kk * 2 + kh));                                            // P3: + ky * FP * 64 + blk * 2048
                 sb[kx][kk] = opaque(2 * r * ROWB + swz((kx == 1 ? 31 : (kx >> 1)) + lr, kk * 2 + kh));            // P5: + ky * ROWB
             }
         const int fc0 = min(2 * lr + 2, FC - 4);
@@ -147,12 +155,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             ow[i] = opaque(OFF_RT + wave * ROWB + swz(lr, i) + kh * 8);                                           // P5 transposition writes (g = i)
         }
         rtw = opaque(OFF_RT + wave * ROWB + vrot(lr, 0) + kh * 8);                                                // conv0 row image: + g * 16 + blk * 2048
-        {
-            const int half = t >= 244 ? 1 : 0, e = t - 244 * half;
-            p4off = opaque(swz(e >> 2, e & 3));
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) orr[u] = opaque(OFF_RT + wave * ROWB + swz((lane + 64 * u) >> 2, (lane + 64 * u) & 3));
+        p4off = opaque(swz(min(t, 243) >> 2, t & 3));
     }
 
     // ---- the walk: steps (b, tx, k), k fastest (down a tile column); a priming item (k - 1, no output) opens every range / column ---
@@ -184,18 +187,18 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         return r;
     };
 
-    // image values of an item's patch: patch pixel 32 * (wave + 8u) + lr for u = 0 .. 3 (both lane halves fetch the same pixel: the
+    // image values of an item's patch: patch pixel 32 * (wave + 4u) + lr for u = 0 .. 3 (both lane halves fetch the same pixel: the
     // MFMA operand of a pixel lives in lane half 0); unconditional loads at clamped coordinates (the zero padding is a mask applied
     // when the operand is built)
     float yv[4][3];
     auto load_image = [&](const Item& c) {
         const int t = opaque(threadIdx.x);
-        const int y0 = 8 * c.k - 1, x0 = 60 * c.tx - 3;
+        const int y0 = 4 * c.k + 1, x0 = 60 * c.tx - 3;
         const long long hw = (long long)R * R;
         const float* yb = p.rgb_y + (long long)c.b * 3 * hw;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int px = min(32 * ((t >> 6) + 8 * u) + (t & 31), FR * FC - 1);
+            const int px = min(32 * ((t >> 6) + NW * u) + (t & 31), FR * FC - 1);
             const int fr = px / FC, fc = px - fr * FC;
             const int iy = min(max(y0 + fr, 0), R - 1), ix = min(max(x0 + fc, 0), R - 1);
             const int off = iy * R + ix;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 
     auto step = [&](const Item& c, const Item& nx) {
         const int b = c.b, tx = c.tx, k = c.k;
-        const int y0 = 8 * k - 1, x0 = 60 * tx - 3;
+        const int y0 = 4 * k + 1, x0 = 60 * tx - 3;
         __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
         // ---- P1: fromRGB of this wave's patch blocks -> F: one MFMA per 32 pixels, lrelu in packed fp16, four 8-byte stores per lane -------
         {
@@ -216,8 +219,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             for (int q = 0; q < 16; ++q) zacc[q] = 0.f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (wv + 8 * u >= NFB) break;                                          // (uniform: only wave 0 has a fourth block)
-                const int pxr = 32 * (wv + 8 * u) + lr1, px = min(pxr, FR * FC - 1);
+                if (wv + NW * u >= NFB) break;                                         // (uniform: only wave 0 has a fourth block)
+                const int pxr = 32 * (wv + NW * u) + lr1, px = min(pxr, FR * FC - 1);
                 const int fr = px / FC, fc = px - fr * FC;
                 const int iy = y0 + fr, ix = x0 + fc;
                 const bool ok = kh1 == 0 && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
@@ -243,8 +246,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         load_image(nx);        // the next item's image values travel during this item's MFMA phases
         __syncthreads();       // B1: patch complete
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
-        // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, this wave's output row, chunk nh * 2 + kh ---------------
-        if (!c.prime) {
+        // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, output row 2k + 1 + r (one row ahead of P5), chunk nh * 2 + kh ----
+        {
             const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + kh;
             h8 hr[4];
 #pragma unroll
@@ -253,12 +256,13 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                          a2 = *(const h8*)(smem + xb[2] + jy * (FP * 64)), a3 = *(const h8*)(smem + xb[3] + jy * (FP * 64));
                 hr[jy] = fir4(a0, a1, a2, a3);
             }
-            *(h8*)(smem + OFF_XS + swz(r * 32 + lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
+            const int xslot = uni((2 * k + 1 + r + 3) % 3);                             // ring slot of output row o: o mod 3 (k >= -1)
+            *(h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
         }
         // ---- P3: conv0 of new h row 8k + 2 + wave -> row image -> horizontal FIR -> ring -------------------------------------------------
         {
-            const int yh = 8 * k + 2 + wave;                                           // uniform per wave
-            char* ring = smem + OFF_HB + ((yh + 14) % 12) * ROWB;                      // slot of h row y: (y + 2) mod 12
+            const int yh = 4 * k + 2 + wave;                                           // uniform per wave
+            char* ring = smem + OFF_HB + ((yh + 2 + RING) & (RING - 1)) * ROWB;        // slot of h row y: (y + 2) mod 8
             const int jj = lane >> 2;
             if ((unsigned)yh >= (unsigned)R) {                                         // outside the image: the FIR's zero padding
 #pragma unroll
@@ -313,28 +317,20 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         }
         if (c.prime) return;
         __syncthreads();       // B2: ring complete; every wave is done reading F
-        // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 8 = blurred rows 8k .. 8k + 8) -----------------------------------
+        // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 4 = blurred rows 4k .. 4k + 4) -----------------------------------
         {
             const int t = opaque(threadIdx.x);
-            if (t < 488) {
-                const int half = t >= 244 ? 1 : 0;
-                const int off = p4off;
-                const int base = uni((8 * k + 24) % 12);                                // ring slot of window row 0 (h row 8k - 2)
-                const int i0 = half * 5;
+            if (t < 244) {
+                const int base = uni((4 * k + RING) & (RING - 1));                      // ring slot of window row 0 (h row 4k - 2)
                 h8 v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int s = base + min(i0 + i, 11);
-                    s = s >= 12 ? s - 12 : s;
-                    v[i] = *(const h8*)(smem + OFF_HB + s * ROWB + off);
-                }
+                for (int i = 0; i < 8; ++i) v[i] = *(const h8*)(smem + OFF_HB + ((base + i) & (RING - 1)) * ROWB + p4off);
 #pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    if (j < 4 || !half) *(h8*)(smem + (i0 + j) * ROWB + off) = fir4(v[j], v[j + 1], v[j + 2], v[j + 3]);
+                for (int j = 0; j < AR; ++j) *(h8*)(smem + j * ROWB + p4off) = fir4(v[j], v[j + 1], v[j + 2], v[j + 3]);
             }
         }
         __syncthreads();       // B3: operand image complete
-        // ---- P5: stride-2 conv + skip, wave = (output row 4k + r, n half nh) ----------------------------------------------------------------
+        // ---- P5: stride-2 conv + skip, wave = (output row 2k + r, n half nh) ----------------------------------------------------------------
         {
             const int r = wave >> 1, nh = wave & 1;
             f16x acc;
@@ -358,8 +354,9 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                     acc[g * 4 + q] = fmaxf(v, 0.2f * v);        // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2
                 }
             }
+            const int xslot = uni((2 * k + r) % 3);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + swz(r * 32 + lr, kk * 2 + kh)), acc);
+            for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);
             // transposition through the wave's row image (32 px x 64 B), then 16-byte stores in row order
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -369,12 +366,12 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 *(h4*)(smem + ow[g]) = o;
             }
             __builtin_amdgcn_wave_barrier();
-            const int orow = 4 * k + r;
+            const int orow = 2 * k + r;
             half_t* yrow = p.y + (((long long)b * Ro + orow) * Ro + 30 * tx) * 64 + nh * 32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
-                const h8 d = *(const h8*)(smem + orr[u]);
+                const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
                 if (pix < TW && 30 * tx + pix < Ro && orow < Ro) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
             }
             __builtin_amdgcn_wave_barrier();
@@ -395,7 +392,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 
 bool dblock0_supported(int R, int Cin, int Cout) {
     static const bool off = getenv("GLASS_NO_D0_FUSE") != nullptr;   // A/B knob: conv_stream<fromrgb> + conv_down instead
-    return !off && glass_lds_fits(LDS_BYTES) && R % 8 == 0 && R >= 16 && Cin == 32 && Cout == 64 && 3LL * R * R < (1LL << 31);
+    return !off && glass_lds_fits(LDS_BYTES) && R % 4 == 0 && R >= 16 && Cin == 32 && Cout == 64 && 3LL * R * R < (1LL << 31);
 }
 
 // Returns the kernel symbol, or nullptr when the block does not qualify (caller runs the two-kernel form).
@@ -404,12 +401,12 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     if (!dblock0_supported(R, Cin, Cout)) return nullptr;
     D0Params p;
     p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
-    const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 8;
+    const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 4;
     const long long n_steps = (long long)B * tiles_x * tiles_y;
     if (n_steps >= (1LL << 30)) return nullptr;
     static DevOnce once;
     if (once.first()) (void)hipFuncSetAttribute((const void*)dblock0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    const int slots = glass_cu_count();           // one 512-thread workgroup per CU (143 KB of LDS)
+    const int slots = 2 * glass_cu_count();       // two 256-thread workgroups per CU (79 KB of LDS each)
     const int per_block = (int)((n_steps + slots - 1) / slots);
     const int grid = (int)((n_steps + per_block - 1) / per_block);
     hipLaunchKernelGGL(dblock0_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);

@@ -476,26 +476,26 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# conv_d0.hip / dblock0_kernel emulated at the level of its INDEX MATH: 4 x 30 output tiles walked down tile columns, the fromRGB
-# patch F (12 x 66 px, pitch 68, column-keyed chunk swizzle), conv0 per wave = one new h row (2 x 32 px blocks) with the weight
-# fragments in registers, wave-local horizontal FIR through the per-wave row image into the 12-row ring of de-interleaved rows,
-# vertical FIR into the operand image (aliases F), stride-2 conv per (row, n half) wave + skip MFMAs from the XS image, priming
-# steps at every range / column start.  Constants and address functions mirror the kernel's namespace.
-_D0 = dict(TW=30, TH=4, HW=64, FP=68, FR=12)
-_D0_OFF_F, _D0_OFF_RT, _D0_OFF_HB, _D0_OFF_XS = 0, 52224, 52224 + 32768, 52224 + 32768 + 49152
-_D0_LDS = _D0_OFF_XS + 8192
+# conv_d0.hip / dblock0_kernel emulated at the level of its INDEX MATH: 2 x 30 output tiles walked down tile columns, the fromRGB
+# patch F (6 x 66 px, column-keyed chunk swizzle) built by one MFMA per 32-pixel block, conv0 per wave = one new h row (2 x 32 px
+# blocks) with the weight fragments in registers, wave-local horizontal FIR through the per-wave row image into the 8-row ring of
+# de-interleaved rows, vertical FIR into the operand image (aliases F), stride-2 conv per (row, n half) wave + skip MFMAs from the
+# 3-row XS ring (filled one output row ahead), priming steps at every range / column start.  Constants and address functions
+# mirror the kernel's namespace.
+_D0_NW, _D0_FR, _D0_FC, _D0_FP, _D0_RING, _D0_AR, _D0_XSR = 4, 6, 66, 66, 8, 5, 3
+_D0_OFF_F = 0
+_D0_OFF_RT = _D0_FR * _D0_FP * 64
+_D0_OFF_HB = _D0_OFF_RT + _D0_NW * 4096
+_D0_OFF_XS = _D0_OFF_HB + _D0_RING * 4096
+_D0_LDS = _D0_OFF_XS + _D0_XSR * 2048
 
 
 def _d0_swa(pr, pc, chunk):
-    return ((pr * 68 + pc) << 6) + ((chunk ^ ((pc >> 2) & 3)) << 4)
+    return ((pr * _D0_FP + pc) << 6) + ((chunk ^ ((pc >> 2) & 3)) << 4)
 
 
 def _d0_swz(row, chunk):
     return (row << 6) + ((chunk ^ ((row >> 2) & 3)) << 4)
-
-
-def _d0_slot(slot, lc):
-    return (slot << 6) + ((lc ^ ((slot >> 2) & 3)) << 4)
 
 
 def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
@@ -504,9 +504,9 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
     f16, f32 = np.float16, np.float32
     y = np.asarray(y, f32)
     B, _, R, _ = y.shape
-    assert R % 8 == 0
+    assert R % 4 == 0
     Ro = R // 2
-    tiles_x, tiles_y = (Ro + 29) // 30, R // 8
+    tiles_x, tiles_y = (Ro + 29) // 30, R // 4
     pk0 = real_ops.host_pack_conv(w0, False).astype(f16)        # [9][32][32]
     pk1 = real_ops.host_pack_conv(w1, False).astype(f16)        # [9][64][32]
     pks = (real_ops.host_pack_conv(wskip, False).astype(f32) * f32(0.70710678118654752440)).astype(f16)[0]   # [64][32]
@@ -535,15 +535,16 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
 
     n_steps = B * tiles_x * tiles_y
     per_block = (n_steps + n_wg - 1) // n_wg
-    t = np.arange(512)
+    t = np.arange(64 * _D0_NW)
+    NPX = _D0_FR * _D0_FC
 
     def run_item(b, tx, k, prime):
-        y0, x0 = 8 * k - 1, 60 * tx - 3            # image row / column of F[0][0]
-        # ---- P1: fromRGB patch as an MFMA per 32-pixel block (block i of 25 -> wave i % 8); lane half 0 carries (r, g, b, 1) ------------
-        for blk in range(25):
+        y0, x0 = 4 * k + 1, 60 * tx - 3            # image row / column of F[0][0]
+        # ---- P1: fromRGB patch as an MFMA per 32-pixel block (block i of 13 -> wave i % 4); lane half 0 carries (r, g, b, 1) ------------
+        for blk in range((NPX + 31) // 32):
             px = 32 * blk + np.arange(32)
-            px = px[px < 792]
-            fr, fc = px // 66, px % 66
+            px = px[px < NPX]
+            fr, fc = px // _D0_FC, px % _D0_FC
             iy, ix = y0 + fr, x0 + fc
             v = y[b][:, np.clip(iy, 0, R - 1), np.clip(ix, 0, R - 1)].T             # [n, 3] clamped loads
             c3 = (np.clip((v + f32(1)) * f32(0.5), 0, 1) * f32(2) - f32(1)).astype(f16)
@@ -554,28 +555,27 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                      + fw[3]).astype(f32).astype(f16)                             # fp16 x fp16 products, fp32 accumulate (MFMA)
                 a = np.maximum(z, (z.astype(f32) * f32(f16(0.2))).astype(f16))
                 wr(_D0_OFF_F + _d0_swa(fr, fc, part), np.where(ok[:, None], a, f16(0)))
-        # ---- P2: skip-branch input (FIR pad 1 + ::2 of the fromRGB map) for the four output rows, chunk nh*2 + kh ---------
-        if not prime:
-            for wave in range(8):
-                r, nh = wave >> 1, wave & 1
-                c = nh * 2 + kh
-                fc0 = np.minimum(2 * lr + 2, 62)
-                hr = []
-                for jy in range(4):
-                    a = [rd(_D0_OFF_F + _d0_swa(2 * r + jy, fc0 + jx, c)) for jx in range(4)]
-                    hr.append(_fir4(a[0], a[1], a[2], a[3]))
-                wr(_D0_OFF_XS + _d0_swz(r * 32 + lr, c), _fir4(hr[0], hr[1], hr[2], hr[3]))
-        # ---- P3: conv0, wave = new h row 8k + 2 + wave; horizontal FIR wave-locally; ring slot (row + 2) mod 12 -------------
-        for wave in range(8):
-            yh = 8 * k + 2 + wave
-            ring = _D0_OFF_HB + ((yh + 2 + 12) % 12) * 4096
+        # ---- P2: skip-branch input (FIR pad 1 + ::2 of the fromRGB map) of output rows 2k + 1, 2k + 2 -> ring slot o mod 3 ---------------
+        for wave in range(_D0_NW):
+            r, nh = wave >> 1, wave & 1
+            c = nh * 2 + kh
+            fc0 = np.minimum(2 * lr + 2, _D0_FC - 4)
+            hr = []
+            for jy in range(4):
+                a = [rd(_D0_OFF_F + _d0_swa(2 * r + jy, fc0 + jx, c)) for jx in range(4)]
+                hr.append(_fir4(a[0], a[1], a[2], a[3]))
+            wr(_D0_OFF_XS + ((2 * k + 1 + r) % 3) * 2048 + _d0_swz(lr, c), _fir4(hr[0], hr[1], hr[2], hr[3]))
+        # ---- P3: conv0, wave = new h row 4k + 2 + wave; horizontal FIR wave-locally; ring slot (row + 2) mod 8 --------------------------
+        for wave in range(_D0_NW):
+            yh = 4 * k + 2 + wave
+            ring = _D0_OFF_HB + ((yh + 2) % _D0_RING) * 4096
             rt = _D0_OFF_RT + wave * 4096
             jj, cgl = lane >> 2, lane & 3
             if yh < 0 or yh >= R:
                 for i in range(4):
                     cb = 4 * jj + i
                     m = cb <= 60
-                    wr((ring + _d0_slot(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], np.zeros((int(m.sum()), 8), f16))
+                    wr((ring + _d0_swz(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], np.zeros((int(m.sum()), 8), f16))
                 continue
             acc = np.zeros((2, 32, 32), np.float64)
             for ky in range(3):
@@ -583,7 +583,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                     for kk in range(2):
                         wf = frag_to_mat(wfrag(pk0, ky * 3 + kx, 0, kk))
                         for blk in range(2):
-                            xf = rd(_D0_OFF_F + _d0_swa(wave + 2 + ky, blk * 32 + lr + kx, kk * 2 + kh))
+                            xf = rd(_D0_OFF_F + _d0_swa(wave + ky, blk * 32 + lr + kx, kk * 2 + kh))
                             acc[blk] += wf @ frag_to_mat(xf).T
             for blk in range(2):
                 col = blk * 32 + lr
@@ -605,32 +605,30 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                 cb = 4 * jj + i
                 m = cb <= 60
                 o = _fir4(v[i], v[i + 1], v[i + 2], v[i + 3])
-                wr((ring + _d0_slot(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], o[m])
+                wr((ring + _d0_swz(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], o[m])
         if prime:
             return
         # ---- P4: vertical FIR over the ring -> operand image A (aliases F) ------------------------------------------------------
-        tt = t[t < 488]
-        e, half = tt % 244, tt // 244
-        off = _d0_slot(e >> 2, e & 3)
-        rows = [rd(_D0_OFF_HB + ((8 * k + i) % 12) * 4096 + off) for i in range(12)]       # window row i = h row 8k - 2 + i
-        for br in range(9):
-            m = (half == 0) if br < 5 else (half == 1)
-            wr((_D0_OFF_F + br * 4096 + off)[m], _fir4(rows[br], rows[br + 1], rows[br + 2], rows[br + 3])[m])
-        # ---- P5: stride-2 conv, wave = (output row r, n half), + skip MFMAs, transposition through the wave's row image ---------
-        for wave in range(8):
+        tt = t[t < 244]
+        off = _d0_swz(tt >> 2, tt & 3)
+        rows = [rd(_D0_OFF_HB + ((4 * k + i) % _D0_RING) * 4096 + off) for i in range(8)]        # window row i = h row 4k - 2 + i
+        for br in range(_D0_AR):
+            wr(_D0_OFF_F + br * 4096 + off, _fir4(rows[br], rows[br + 1], rows[br + 2], rows[br + 3]))
+        # ---- P5: stride-2 conv, wave = (output row 2k + r, n half), + skip MFMAs, transposition through the wave's row image -----
+        for wave in range(_D0_NW):
             r, nh = wave >> 1, wave & 1
-            o_row = 4 * k + r
+            o_row = 2 * k + r
             acc = np.zeros((32, 32), np.float64)
             for ky in range(3):
                 for kx in range(3):
                     for kk in range(2):
                         slot = (31 if kx == 1 else (kx >> 1)) + lr
-                        xf = rd(_D0_OFF_F + (2 * r + ky) * 4096 + _d0_slot(slot, kk * 2 + kh))
+                        xf = rd(_D0_OFF_F + (2 * r + ky) * 4096 + _d0_swz(slot, kk * 2 + kh))
                         acc += frag_to_mat(wfrag(pk1, ky * 3 + kx, nh * 32, kk)) @ frag_to_mat(xf).T
             v = acc.astype(f32) + b1[nh * 32:nh * 32 + 32, None]
             v = np.maximum(v, f32(0.2) * v).astype(np.float64)
             for kk in range(2):
-                xf = rd(_D0_OFF_XS + _d0_swz(r * 32 + lr, kk * 2 + kh))
+                xf = rd(_D0_OFF_XS + (o_row % 3) * 2048 + _d0_swz(lr, kk * 2 + kh))
                 wsf = np.stack([pks[nh * 32 + lr[i], kk * 16 + kh[i] * 8:kk * 16 + kh[i] * 8 + 8] for i in range(64)])
                 v += frag_to_mat(wsf) @ frag_to_mat(xf).T
             res = v.astype(f32).astype(f16)                                  # [ch][px]

@@ -421,7 +421,7 @@ def _dblock0_case(B, R, seed=21):
 
 @pytest.mark.parametrize("B,R", [
     (1, 64),       # 16 steps for 256 workgroups: one step per workgroup, every step primed; second tile column holds 2 of 30 pixels
-    (2, 72),       # R/2 = 36: ragged last tile column (6 of 30), 9 steps per column
+    (2, 68),       # R/2 = 34: ragged last tile column (4 of 30), 17 steps per column (R % 8 != 0)
     (3, 192),      # 3 x 4 x 24 = 288 steps: two-step ranges, priming mid-column; interior tiles without any padding mask
     (8, 256),      # 1280 steps: five per workgroup, ranges crossing column and sample boundaries
 ])

@@ -173,7 +173,7 @@ def test_dblock0_index_emulation():
     T.ops = emu_ops
     try:
         T.test_dblock0_fused(1, 64)
-        args, ref = T._dblock0_case(1, 72, seed=5)
+        args, ref = T._dblock0_case(1, 68, seed=5)
         for n_wg in (1, 4):
             got = emu_ops.dblock0(*args, n_wg=n_wg)
             T.check("D block0 emulated, %d workgroups" % n_wg, T.nchw(got), ref, 6e-3)
