@@ -131,7 +131,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 
     // ---- lane-constant LDS offsets, computed ONCE and kept opaque (left to the compiler they were rebuilt in every step: ~250 of the first
     // version's 1240 VALU instructions per wave and step were address arithmetic; row / block / tap-row steps are immediate offsets) ------
-    int fb[3][2], sb[3][2], xb[4], hv[7], hw4[4], rtw, p4off, ow[4];
+    int fb[3][2], sb[3][2], rtw, p4off;      // (the once-per-step addresses — P2, horizontal FIR, ring and transposition
+    // writes — are rebuilt per step: keeping them too left ONE fragment register for the MFMA loops, every MFMA behind its own LDS round trip)
     {
         const int t = threadIdx.x, lr = t & 31, kh = (t >> 5) & 1, lane = t & 63, wave = t >> 6;
         const int r = wave >> 1, nh = wave & 1;
@@ -142,18 +143,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 fb[kx][kk] = opaque(swa(wave, lr + kx, kk * 2 + kh));                                            // P3: + ky * FP * 64 + blk * 2048
                 sb[kx][kk] = opaque(2 * r * ROWB + swz((kx == 1 ? 31 : (kx >> 1)) + lr, kk * 2 + kh));            // P5: + ky * ROWB
             }
-        const int fc0 = min(2 * lr + 2, FC - 4);
-#pragma unroll
-        for (int jx = 0; jx < 4; ++jx) xb[jx] = opaque(swa(2 * r, fc0 + jx, nh * 2 + kh));                        // P2: + jy * FP * 64
-        const int jj = lane >> 2, cgl = lane & 3;
-#pragma unroll
-        for (int q = 0; q < 7; ++q) hv[q] = opaque(OFF_RT + wave * ROWB + vrot(min(4 * jj + q, 63), cgl));         // horizontal FIR reads
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int cbk = 4 * jj + i;
-            hw4[i] = opaque(swz((cbk & 1) ? 31 + (cbk >> 1) : (cbk >> 1), cgl));                                   // ring writes (+ ring row)
-            ow[i] = opaque(OFF_RT + wave * ROWB + swz(lr, i) + kh * 8);                                           // P5 transposition writes (g = i)
-        }
+        (void)lane; (void)nh;
         rtw = opaque(OFF_RT + wave * ROWB + vrot(lr, 0) + kh * 8);                                                // conv0 row image: + g * 16 + blk * 2048
         p4off = opaque(swz(min(t, 243) >> 2, t & 3));
     }
@@ -243,7 +233,6 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 }
             }
         }
-        load_image(nx);        // the next item's image values travel during this item's MFMA phases
         __syncthreads();       // B1: patch complete
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
         // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, output row 2k + 1 + r (one row ahead of P5), chunk nh * 2 + kh ----
@@ -252,8 +241,9 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             h8 hr[4];
 #pragma unroll
             for (int jy = 0; jy < 4; ++jy) {
-                const h8 a0 = *(const h8*)(smem + xb[0] + jy * (FP * 64)), a1 = *(const h8*)(smem + xb[1] + jy * (FP * 64)),
-                         a2 = *(const h8*)(smem + xb[2] + jy * (FP * 64)), a3 = *(const h8*)(smem + xb[3] + jy * (FP * 64));
+                const int fc0 = min(2 * lr + 2, FC - 4);
+                const h8 a0 = *(const h8*)(smem + swa(2 * r + jy, fc0, ch)), a1 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 1, ch)),
+                         a2 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 2, ch)), a3 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 3, ch));
                 hr[jy] = fir4(a0, a1, a2, a3);
             }
             const int xslot = uni((2 * k + 1 + r + 3) % 3);                             // ring slot of output row o: o mod 3 (k >= -1)
@@ -263,7 +253,10 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         {
             const int yh = 4 * k + 2 + wave;                                           // uniform per wave
             char* ring = smem + OFF_HB + ((yh + 2 + RING) & (RING - 1)) * ROWB;        // slot of h row y: (y + 2) mod 8
-            const int jj = lane >> 2;
+            const int jj = lane >> 2, cgl = lane & 3;
+            int hw4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hw4[i] = swz(((i & 1) ? 31 : 0) + 2 * jj + (i >> 1), cgl);        // blurred column 4jj + i: even | odd slots
             if ((unsigned)yh >= (unsigned)R) {                                         // outside the image: the FIR's zero padding
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -274,17 +267,28 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+                // Software-pipelined by hand: the four fragments of tap t + 1 are requested before the four MFMAs of tap t issue.  Left to
+                // the scheduler (at ~250 live VGPRs it minimises pressure) every MFMA sat behind its own LDS round trip: ds_read,
+                // s_waitcnt lgkmcnt(0), v_mfma, 36 times per step (r04 v3 ISA) — with two waves per SIMD nothing hides that.
+                h8 xq[2][4];
+                auto rd4 = [&](int tap, h8 (&d)[4]) {
+                    const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
+                        for (int blk = 0; blk < 2; ++blk) d[kk * 2 + blk] = *(const h8*)(smem + fb[kx][kk] + ky * (FP * 64) + blk * 2048);
+                };
+                rd4(0, xq[0]);
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (tap + 1 < 9) rd4(tap + 1, xq[(tap + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                            for (int blk = 0; blk < 2; ++blk) {
-                                const h8 xf = *(const h8*)(smem + fb[kx][kk] + ky * (FP * 64) + blk * 2048);
-                                acc[blk] = mfma32(W0f[ky * 3 + kx][kk], xf, acc[blk]);
-                            }
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk) acc[blk] = mfma32(W0f[tap][kk], xq[tap & 1][kk * 2 + blk], acc[blk]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
                 const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
                 const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 h8 v[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    v[q] = *(const h8*)(smem + hv[q]);
+                    v[q] = *(const h8*)(smem + OFF_RT + wave * ROWB + vrot(min(4 * jj + q, 63), cgl));
                     if (q >= 4 && jj == 15) v[q] = zero;                               // window columns 64 .. 66 do not exist
                 }
 #pragma unroll
@@ -315,6 +319,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        load_image(nx);        // the next item's image values travel during P4 / P5 (issued here, not before conv0: twelve fewer live
+                               // registers in the step's tightest loop)
         if (c.prime) return;
         __syncthreads();       // B2: ring complete; every wave is done reading F
         // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 4 = blurred rows 4k .. 4k + 4) -----------------------------------
@@ -336,15 +342,23 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             f16x acc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            // (pipelined like conv0's loop: the fragments of taps t + 1 and t + 2 are in flight while tap t's two MFMAs issue)
+            h8 xq[3][2];
+            auto rd2 = [&](int tap, h8 (&d)[2]) {
+                const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int kk = 0; kk < 2; ++kk) d[kk] = *(const h8*)(smem + sb[kx][kk] + ky * ROWB);
+            };
+            rd2(0, xq[0]);
+            rd2(1, xq[1]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 2 < 9) rd2(tap + 2, xq[(tap + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const h8 xf = *(const h8*)(smem + sb[kx][kk] + ky * ROWB);
-                        acc = mfma32(W1f[ky * 3 + kx][kk], xf, acc);
-                    }
+                for (int kk = 0; kk < 2; ++kk) acc = mfma32(W1f[tap][kk], xq[tap % 3][kk], acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f4 bb = *(const f4*)(Cb1 + nh * 32 + 8 * g + 4 * kh);
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 h4 o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = (half_t)acc[g * 4 + q];
-                *(h4*)(smem + ow[g]) = o;
+                *(h4*)(smem + OFF_RT + wave * ROWB + swz(lr, g) + kh * 8) = o;
             }
             __builtin_amdgcn_wave_barrier();
             const int orow = 2 * k + r;
