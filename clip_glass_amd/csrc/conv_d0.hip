@@ -41,6 +41,7 @@
 // (tests/test_host.py::test_dblock0_index_emulation).
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -83,8 +84,15 @@ struct D0Params {
     const float* b1;      // [64]
     half_t* y;            // [B][R/2][R/2][64]
     int B, R;
+    unsigned long long* trace;   // dev build (make TRACE=1, GLASS_D0_TRACE): phase timestamps of workgroup 0
 };
+// phases: 0 top, 1 after B0, 2 patch written, 3 after B1, 4 P2 done, 5 conv0 MFMAs done, 6 ring written, 7 after B2, 8 P4 done, 9 after B3,
+// 10 conv1 MFMAs done, 11 stores issued
+#define D0TRACE(ph)                                                                                          \
+    if (TR && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && n_item < 96)                                      \
+        p.trace[(n_item * 16 + (ph)) * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime()
 
+template <bool TR>
 __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_x, int tiles_y, int n_steps, int per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Cb0 = (float*)(smem + OFF_C);
@@ -197,10 +205,13 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         }
     };
 
+    int n_item = 0;
     auto step = [&](const Item& c, const Item& nx) {
         const int b = c.b, tx = c.tx, k = c.k;
         const int y0 = 4 * k + 1, x0 = 60 * tx - 3;
+        D0TRACE(0);
         __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
+        D0TRACE(1);
         // ---- P1: fromRGB of this wave's patch blocks -> F: one MFMA per 32 pixels, lrelu in packed fp16, four 8-byte stores per lane -------
         {
             const int t = opaque(threadIdx.x), lr1 = t & 31, kh1 = (t >> 5) & 1, wv = uni(t >> 6);
@@ -233,22 +244,33 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 }
             }
         }
+        D0TRACE(2);
         __syncthreads();       // B1: patch complete
+        D0TRACE(3);
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
         // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, output row 2k + 1 + r (one row ahead of P5), chunk nh * 2 + kh ----
         {
             const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + kh;
             h8 hr[4];
+            const int fc0 = min(2 * lr + 2, FC - 4);
+            int xa[4];
 #pragma unroll
-            for (int jy = 0; jy < 4; ++jy) {
-                const int fc0 = min(2 * lr + 2, FC - 4);
-                const h8 a0 = *(const h8*)(smem + swa(2 * r + jy, fc0, ch)), a1 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 1, ch)),
-                         a2 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 2, ch)), a3 = *(const h8*)(smem + swa(2 * r + jy, fc0 + 3, ch));
-                hr[jy] = fir4(a0, a1, a2, a3);
+            for (int jx = 0; jx < 4; ++jx) xa[jx] = swa(2 * r, fc0 + jx, ch);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {                                     // eight reads in flight, then their two FIRs
+                h8 a[2][4];
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) a[j2][jx] = *(const h8*)(smem + xa[jx] + (2 * half + j2) * (FP * 64));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2) hr[2 * half + j2] = fir4(a[j2][0], a[j2][1], a[j2][2], a[j2][3]);
             }
             const int xslot = uni((2 * k + 1 + r + 3) % 3);                             // ring slot of output row o: o mod 3 (k >= -1)
             *(h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
         }
+        D0TRACE(4);
         // ---- P3: conv0 of new h row 8k + 2 + wave -> row image -> horizontal FIR -> ring -------------------------------------------------
         {
             const int yh = 4 * k + 2 + wave;                                           // uniform per wave
@@ -262,11 +284,15 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int i = 0; i < 4; ++i)
                     if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = zero;
             } else {
+                // the accumulators START at the bias (lane (px, kh) owns channels 8g + 4kh + q): the first version read the bias quads in the
+                // epilogue, eight LDS round trips in a row with nothing to overlap them (2400 of the step's 12 900 clocks)
                 f16x acc[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int g = 0; g < 4; ++g) {
+                    const f4 bb = *(const f4*)(Cb0 + 8 * g + 4 * kh);
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+                    for (int q = 0; q < 4; ++q) { acc[0][g * 4 + q] = bb[q]; acc[1][g * 4 + q] = bb[q]; }
+                }
                 // Software-pipelined by hand: the four fragments of tap t + 1 are requested before the four MFMAs of tap t issue.  Left to
                 // the scheduler (at ~250 live VGPRs it minimises pressure) every MFMA sat behind its own LDS round trip: ds_read,
                 // s_waitcnt lgkmcnt(0), v_mfma, 36 times per step (r04 v3 ISA) — with two waves per SIMD nothing hides that.
@@ -289,23 +315,28 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                         for (int blk = 0; blk < 2; ++blk) acc[blk] = mfma32(W0f[tap][kk], xq[tap & 1][kk * 2 + blk], acc[blk]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                D0TRACE(5);
                 // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
                 const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
                 const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
+                auto epi0 = [&](bool masked) {
 #pragma unroll
-                for (int blk = 0; blk < 2; ++blk) {
-                    const bool colok = !edge || (unsigned)(60 * tx - 2 + blk * 32 + lr) < (unsigned)R;
+                    for (int blk = 0; blk < 2; ++blk) {
+                        const bool colok = !masked || (unsigned)(60 * tx - 2 + blk * 32 + lr) < (unsigned)R;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f4 bb = *(const f4*)(Cb0 + 8 * g + 4 * kh);
-                        h4 v;
+                        for (int g = 0; g < 4; ++g) {
+                            h4 v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] = (half_t)(acc[blk][g * 4 + q] + bb[q]);
-                        h4 hq = __builtin_elementwise_max(v * k1, v * k2);
-                        if (edge && !colok) hq = h4{0, 0, 0, 0};
-                        *(h4*)(smem + rtw + g * 16 + blk * 2048) = hq;
+                            for (int q = 0; q < 4; ++q) v[q] = (half_t)acc[blk][g * 4 + q];
+                            h4 hq = __builtin_elementwise_max(v * k1, v * k2);
+                            if (masked && !colok) hq = h4{0, 0, 0, 0};
+                            *(h4*)(smem + rtw + g * 16 + blk * 2048) = hq;
+                        }
                     }
-                }
+                };
+                if (edge) epi0(true);
+                else epi0(false);
+                D0TRACE(12);
                 __builtin_amdgcn_wave_barrier();
                 h8 v[7];
 #pragma unroll
@@ -313,16 +344,20 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                     v[q] = *(const h8*)(smem + OFF_RT + wave * ROWB + vrot(min(4 * jj + q, 63), cgl));
                     if (q >= 4 && jj == 15) v[q] = zero;                               // window columns 64 .. 66 do not exist
                 }
+                if (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+                D0TRACE(13);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        D0TRACE(6);
         load_image(nx);        // the next item's image values travel during P4 / P5 (issued here, not before conv0: twelve fewer live
                                // registers in the step's tightest loop)
-        if (c.prime) return;
+        if (c.prime) { ++n_item; return; }
         __syncthreads();       // B2: ring complete; every wave is done reading F
+        D0TRACE(7);
         // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 4 = blurred rows 4k .. 4k + 4) -----------------------------------
         {
             const int t = opaque(threadIdx.x);
@@ -335,13 +370,19 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int j = 0; j < AR; ++j) *(h8*)(smem + j * ROWB + p4off) = fir4(v[j], v[j + 1], v[j + 2], v[j + 3]);
             }
         }
+        D0TRACE(8);
         __syncthreads();       // B3: operand image complete
+        D0TRACE(9);
         // ---- P5: stride-2 conv + skip, wave = (output row 2k + r, n half nh) ----------------------------------------------------------------
         {
             const int r = wave >> 1, nh = wave & 1;
-            f16x acc;
+            f16x acc;                                                               // starts at the bias (see conv0)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const f4 bb = *(const f4*)(Cb1 + nh * 32 + 8 * g + 4 * kh);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[g * 4 + q] = bb[q];
+            }
             // (pipelined like conv0's loop: the fragments of taps t + 1 and t + 2 are in flight while tap t's two MFMAs issue)
             h8 xq[3][2];
             auto rd2 = [&](int tap, h8 (&d)[2]) {
@@ -359,15 +400,9 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int kk = 0; kk < 2; ++kk) acc = mfma32(W1f[tap][kk], xq[tap % 3][kk], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            D0TRACE(10);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f4 bb = *(const f4*)(Cb1 + nh * 32 + 8 * g + 4 * kh);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float v = acc[g * 4 + q] + bb[q];
-                    acc[g * 4 + q] = fmaxf(v, 0.2f * v);        // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2
-                }
-            }
+            for (int q = 0; q < 16; ++q) acc[q] = fmaxf(acc[q], 0.2f * acc[q]);        // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2
             const int xslot = uni((2 * k + r) % 3);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);
@@ -389,7 +424,9 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 if (pix < TW && 30 * tx + pix < Ro && orow < Ro) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
             }
             __builtin_amdgcn_wave_barrier();
+            D0TRACE(11);
         }
+        ++n_item;
     };
 
     __syncthreads();           // constants staged
@@ -415,14 +452,39 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     if (!dblock0_supported(R, Cin, Cout)) return nullptr;
     D0Params p;
     p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
+    p.trace = nullptr;
     const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 4;
     const long long n_steps = (long long)B * tiles_x * tiles_y;
     if (n_steps >= (1LL << 30)) return nullptr;
     static DevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)dblock0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (once.first()) (void)hipFuncSetAttribute((const void*)dblock0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     const int slots = 2 * glass_cu_count();       // two 256-thread workgroups per CU (79 KB of LDS each)
     const int per_block = (int)((n_steps + slots - 1) / slots);
     const int grid = (int)((n_steps + per_block - 1) / per_block);
-    hipLaunchKernelGGL(dblock0_kernel, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
+#ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps of workgroup 0 to a file; synchronises, single engine only
+    if (const char* tp = getenv("GLASS_D0_TRACE")) {
+        constexpr int NTR = 96 * 16 * 4;
+        (void)hipMalloc(&p.trace, NTR * sizeof(unsigned long long));
+        (void)hipMemset(p.trace, 0, NTR * sizeof(unsigned long long));
+        (void)hipFuncSetAttribute((const void*)dblock0_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipLaunchKernelGGL(dblock0_kernel<true>, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
+        static unsigned long long hb[NTR];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hb, p.trace, sizeof hb, hipMemcpyDeviceToHost);
+        (void)hipFree(p.trace);
+        if (FILE* f = fopen(tp, "a")) {
+            fprintf(f, "# dblock0_kernel<trace> B=%d R=%d per_block=%d: item phase t[wave0..3]\n", B, R, per_block);
+            for (int i = 0; i < 96; ++i)
+                for (int ph = 0; ph < 16; ++ph) {
+                    fprintf(f, "%d %d", i, ph);
+                    for (int w = 0; w < 4; ++w) fprintf(f, " %llu", hb[(i * 16 + ph) * 4 + w] ? hb[(i * 16 + ph) * 4 + w] - hb[0] : 0ULL);
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
+        return "dblock0_kernel<trace>";
+    }
+#endif
+    hipLaunchKernelGGL(dblock0_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
     return "dblock0_kernel";
 }
