@@ -68,7 +68,7 @@ def _cmp_modules(tag, g, sim, dis, feats):
     diag("[golden] %s sim rel err %.3e (range %.3f..%.3f)" % (tag, rel.max(), g["sim"].min(), g["sim"].max()))
     assert rel.max() < 1e-3                                   # BASELINE.json north_star tolerance
     check(tag + " features", feats, g["features"], 5e-3)
-    check_logits(tag + " D logits", dis, g["dis"])
+    check_logits(tag + " D logits", dis, g["dis"], case=str(g["config"]))
 
 
 # ------------------------------- oracle (CPU) ---------------------------------------------
@@ -195,7 +195,7 @@ def test_engine_matches_reference_problem_evaluate():
          % (g["F"][:, 0].min(), g["F"][:, 0].max(), rel.max(), np.abs(F[:, 1] - g["F"][:, 1]).max()))
     # real text feature vs random-image features: sims are O(0.01-0.1); the relative bar applies where |sim| is not ~0
     assert np.all(np.abs(F[:, 0] - g["F"][:, 0]) < 1e-3 * np.maximum(np.abs(g["F"][:, 0]), 0.05))
-    check_logits("golden mini_problem hinge", F[:, 1], g["F"][:, 1])
+    check_logits("golden mini_problem hinge", F[:, 1], g["F"][:, 1], case="mini")
 
 
 @pytest.mark.gpu
@@ -218,4 +218,4 @@ def test_engine_matches_reference_modules(fixture):
     g = _load(fixture)
     F, det = _engine(g, g["target"], same_noise=False)
     _cmp_modules("golden " + fixture, g, det["sim"], det["dis"], det["features"])
-    check_logits("golden %s hinge" % fixture, F[:, 1], g["hinge"])
+    check_logits("golden %s hinge" % fixture, F[:, 1], g["hinge"], case=str(g["config"]))

@@ -52,8 +52,8 @@ def _run_case(name, P, batch_size, use_d, noise_mode, chunk=0, seed=0):
     np.testing.assert_allclose(Fe[:, 0], -det["sim"], rtol=0, atol=1e-7)
     if use_d:
         dis_o = detail["dis"].numpy()[:, 0]
-        check_logits(tag + " D logits", det["dis"], dis_o)
-        check_logits(tag + " hinge", Fe[:, 1], np.maximum(1 - dis_o, 0))
+        check_logits(tag + " D logits", det["dis"], dis_o, case=name)
+        check_logits(tag + " hinge", Fe[:, 1], np.maximum(1 - dis_o, 0), case=name)
     return Fe
 
 
@@ -133,7 +133,7 @@ def test_generation_problem_drop_in():
     rel = np.abs(out["F"][:, 0] - Fo[:, 0]) / np.abs(Fo[:, 0])
     diag("[e2e] GenerationProblem drop-in: sim rel err %.3e, hinge abs err %.3e" % (rel.max(), np.abs(out["F"][:, 1] - Fo[:, 1]).max()))
     assert rel.max() < 1e-3
-    check_logits("drop-in hinge", out["F"][:, 1], Fo[:, 1])
+    check_logits("drop-in hinge", out["F"][:, 1], Fo[:, 1], case="mini")
     ls = cfg.latent(cfg)
     ls.set_from_population(x[:3])
     img = prob.generator.generate(ls)                      # run.py:118 — no minibatch argument
@@ -260,8 +260,8 @@ def test_pop512_as_eight_shards_of_64():
         rel = np.abs(-Fx[:Pg, 0] - g["sim"]) / np.abs(g["sim"])
         diag("[e2e] pop512 %s rows 0-%d vs reference fixture: sim rel err %.3e, hinge abs err %.3e" % (tag, Pg - 1, rel.max(), np.abs(Fx[:Pg, 1] - g["hinge"]).max()))
         assert rel.max() < 1e-3
-        check_logits("pop512 %s hinge rows 0-%d" % (tag, Pg - 1), Fx[:Pg, 1], g["hinge"])
-    check_logits("pop512 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"])
+        check_logits("pop512 %s hinge rows 0-%d" % (tag, Pg - 1), Fx[:Pg, 1], g["hinge"], case="mid")
+    check_logits("pop512 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], case="mid")
     # every launch-size threshold in the dispatchers is evaluated at the nominal population (csrc/common.h GLASS_NOMINAL_POP), so a
     # 512-row launch and a 64-row launch run every layer on the same kernel instance with the same summation order: bitwise equal
     np.testing.assert_array_equal(Fs, F_whole)
@@ -316,7 +316,7 @@ def test_full_size_ffhq_full_population():
     diag("[e2e] ffhq P=64 default chunk: rows 0-%d vs reference fixture: sim rel err %.3e, D abs err %.3e; chunk 64 vs 4 max |dF| %.3e"
          % (Pg - 1, rel.max(), np.abs(det["dis"][:Pg] - g["dis"]).max(), np.abs(Fs[0] - Fs[1]).max()))
     assert rel.max() < 1e-3
-    check_logits("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"])
+    check_logits("ffhq P=64 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], case="ffhq")
     assert np.isfinite(Fs[0]).all() and Fs[0].shape == (P, 2)
     # chunk 64 and chunk 4 launches run the same kernel instance per layer (dispatch looks at the layer geometry only): bitwise equal
     np.testing.assert_array_equal(Fs[0], Fs[1])
