@@ -43,7 +43,9 @@ D_ATOL, D_RTOL = 1.5e-3, 1.5e-3
 # Per-architecture bars: ~1.35 x the largest error the engine delivers on that architecture over every case of the GPU
 # suite (gpurun_out/diag.log of the r04 run; the runs are bitwise reproducible), so that a 2 x regression of the D path fails on
 # the architecture where it happens instead of hiding under the loosest case's bar.  north_star states no D tolerance.
-D_TOL = {"mini": (1.5e-3, 1.5e-3), "mid": (1.5e-3, 1.5e-3), "ffhq": (1.5e-3, 1.5e-3), "church": (1.5e-3, 1.5e-3), "car": (1.5e-3, 1.5e-3)}
+# Largest |error| of the r04 GPU run per architecture: mini 7.3e-4, mid 1.56e-3 (one case: P8 bs4 vs the oracle; its other cases <= 6.7e-4),
+# ffhq 6.1e-4, church 1.8e-4, car 8.0e-4.
+D_TOL = {"mini": (1.0e-3, 5e-4), "mid": (2.0e-3, 5e-4), "ffhq": (9e-4, 5e-4), "church": (4e-4, 5e-4), "car": (1.1e-3, 5e-4)}
 
 
 def check_logits(name, got, ref, atol=None, rtol=None, case=None):
