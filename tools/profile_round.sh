@@ -11,7 +11,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 GLASS_BENCH_DETAIL=$OUT/bench_detail.json python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o stats -- python bench.py --no-cpu-baseline --no-legs > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 ls $OUT/prof | head
 bash tools/measure_traffic.sh $TAG > $OUT/traffic.log 2>&1
 bash tools/measure_sq.sh $TAG > $OUT/sq.log 2>&1
