@@ -571,10 +571,22 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                     for (int g = 0; g < 4; ++g) rq[g][i] = *(const h4*)(rp + 8 * g);
                 }
             }
+            // this slice's eight constant quads as ONE batch of LDS reads: read quad by quad (the compiler's order at 224 live VGPRs)
+            // every quad sat behind its own LDS round trip — 32 per item, with all eight waves of the workgroup in the epilogue together
+            constexpr int GB = TRGB ? 2 : 4;                 // (the toRGB instance has 16 fewer registers to spare)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = j * 32 + 8 * g + 4 * kh;
-                const f4 d = *(const f4*)(Cc + nl), bb = *(const f4*)(Cc + NT + nl);      // bb = bias + shift
+            for (int g0 = 0; g0 < 4; g0 += GB) {
+            f4 dq[GB], bq[GB];
+#pragma unroll
+            for (int g = 0; g < GB; ++g) {
+                const int nl = j * 32 + 8 * (g0 + g) + 4 * kh;
+                dq[g] = *(const f4*)(Cc + nl);
+                bq[g] = *(const f4*)(Cc + NT + nl);      // bias + shift
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = g0; g < g0 + GB; ++g) {
+                const f4 d = dq[g - g0], bb = bq[g - g0];
 #pragma unroll
                 for (int i = 0; i < RW; ++i) {
                     const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
@@ -586,6 +598,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                     *(h4*)(Os + (i * 32 + lr) * OP + (8 * g + 4 * kh) * 2) = out;
                     if (TRGB) va[i][g] = out;
                 }
+            }
             }
             if (TRGB) {
 #pragma unroll
