@@ -331,11 +331,15 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
             const int oyb = ty0 + wr * 2;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
+                f4 bq[4];                                   // the slice's four bias quads as ONE batch of LDS reads (see conv_glds.hip)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *(const f4*)(Cc + (wn * 2 + j) * 32 + 8 * g + 4 * kh);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f4 bb = *(const f4*)(Cc + (wn * 2 + j) * 32 + 8 * g + 4 * kh);
+                        const f4 bb = bq[g];
                         const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
                         const f4 sk = {acs[i][j][g * 4], acs[i][j][g * 4 + 1], acs[i][j][g * 4 + 2], acs[i][j][g * 4 + 3]};
                         const f4 v = act_apply(a + bb, ak) + sk * p.out_scale;

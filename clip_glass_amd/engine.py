@@ -49,7 +49,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("GLASS_LIB") or LIB_PATH      # GLASS_LIB: A/B knob (a second build of libglass.so on the same box)
     if not os.path.exists(path):
         raise RuntimeError("libglass.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C clip_glass_amd/csrc` — there is no CPU fallback" % path)
