@@ -610,21 +610,35 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
                 }
                 const int yb = 2 * PY * (iyi0 + 1);                        // first virtual output row of the step's second image row
+                // Software-pipelined by hand (r04): row r + 1's four T vectors are requested before row r is filtered, and only the STORE is
+                // predicated.  As a plain loop every row was: 4 ds_read_b128, s_waitcnt, 8 packed ops, branch, ~30 packed ops, store — an
+                // exposed LDS round trip per row, 16 per step, in a phase where nothing else is in flight.
+                h8 cv[4];
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) cv[jx] = *(const h8*)(tr[jx]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
-                             v3 = *(const h8*)(tr[3] + r * 4096);
-                    hs[r & 3] = (v1 + v2) * f3 + (v0 + v3);           // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
+                    h8 nv[4];
+                    if (r + 1 < 16) {
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) nv[jx] = *(const h8*)(tr[jx] + (r + 1) * 4096);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    hs[r & 3] = (cv[1] + cv[2]) * f3 + (cv[0] + cv[3]);   // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
                     const int ovy = ovy0 + r;
                     const bool second = ovy >= yb;
                     const int iyo = iyi0 + (second ? 1 : 0);
                     const int oy = ovy - 2 * PY * iyo;
                     const int img = img0 + iyo * g.NXI + ixo;
-                    if ((step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B) {
-                        const h8 bn = bias8 + (half_t)nzr[r];
-                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
-                        half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
-                        *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
+                    const bool emit = (step > 0 || r >= 4) && oy >= 0 && oy < p.Ho && iyo < g.NYI && img < p.B;
+                    const h8 bn = bias8 + (half_t)nzr[r];
+                    const h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
+                    half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
+                    if (emit) *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r + 1 < 16) {
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) cv[jx] = nv[jx];
                     }
                 }
                 *(h8*)(hs_slot) = hs[1]; *(h8*)(hs_slot + 16) = hs[2]; *(h8*)(hs_slot + 32) = hs[3];
@@ -704,19 +718,35 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 }
                 const long long rowpitch = (long long)p.Wo * p.Cout;
                 half_t* yp = p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)
+                // (software-pipelined like the grid instance's loop above: row r + 1's T vectors and noise value are requested before row r
+                // is filtered, only the store is predicated — the plain loop had TWO exposed LDS round trips per row)
+                h8 cv[4];
+                float cnz;
+                auto rdrow = [&](int r, h8 (&v_)[4], float& nz_) {
+#pragma unroll
+                    for (int jx = 0; jx < 4; ++jx) v_[jx] = *(const h8*)(tr[jx] + r * 4096);
+                    nz_ = *(const float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4);
+                };
+                rdrow(0, cv, cnz);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const h8 v0 = *(const h8*)(tr[0] + r * 4096), v1 = *(const h8*)(tr[1] + r * 4096), v2 = *(const h8*)(tr[2] + r * 4096),
-                             v3 = *(const h8*)(tr[3] + r * 4096);
-                    hs[r & 3] = (v1 + v2) * f3 + (v0 + v3);           // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
-                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) {
-                        const h8 bn = bias8 + (half_t)*(const float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4);
-                        h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
-                        v = __builtin_elementwise_max(v * k1, v * k2);
-                        if (p.post_scale16) v = v * ps8;                // (uniform: per-sample-weight layers feed a conv whose weights carry its style)
-                        *(h8*)yp = v;
-                    }
+                    h8 nv[4];
+                    float nnz;
+                    if (r + 1 < 16) rdrow(r + 1, nv, nnz);
+                    __builtin_amdgcn_sched_barrier(0);
+                    hs[r & 3] = (cv[1] + cv[2]) * f3 + (cv[0] + cv[3]);   // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
+                    const h8 bn = bias8 + (half_t)cnz;
+                    h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
+                    v = __builtin_elementwise_max(v * k1, v * k2);
+                    if (p.post_scale16) v = v * ps8;                // (uniform: per-sample-weight layers feed a conv whose weights carry its style)
+                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) *(h8*)yp = v;
                     yp += rowpitch;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r + 1 < 16) {
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) cv[jx] = nv[jx];
+                        cnz = nnz;
+                    }
                 }
                 *(h8*)(hs_slot) = hs[1]; *(h8*)(hs_slot + 16) = hs[2]; *(h8*)(hs_slot + 32) = hs[3];
             }
