@@ -248,11 +248,14 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         __syncthreads();       // B1: patch complete
         D0TRACE(3);
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, lane = tm & 63, wave = uni(tm >> 6);
-        // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, output row 2k + 1 + r (one row ahead of P5), chunk nh * 2 + kh ----
+        // ---- P2: skip-branch input: FIR 4x4 (pad 1) + ::2 of the fromRGB map, output row 2k + 1 + r (one row ahead of P5).  The wave's 32
+        // pixels x 2 chunks are dealt (pixel = lane / 2, chunk = nh * 2 + lane % 2): a stride-2 pixel walk touches every other 64-byte
+        // window, so sixteen consecutive lanes must bring two chunks each to cover all sixteen 16-byte bank groups (the image goes
+        // through LDS to the skip MFMAs anyway, so this phase's lane mapping is free) ----
         {
-            const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + kh;
+            const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + (lane & 1), lrx = lane >> 1;
             h8 hr[4];
-            const int fc0 = min(2 * lr + 2, FC - 4);
+            const int fc0 = min(2 * lrx + 2, FC - 4);
             int xa[4];
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) xa[jx] = swa(2 * r, fc0 + jx, ch);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int j2 = 0; j2 < 2; ++j2) hr[2 * half + j2] = fir4(a[j2][0], a[j2][1], a[j2][2], a[j2][3]);
             }
             const int xslot = uni((2 * k + 1 + r + 3) % 3);                             // ring slot of output row o: o mod 3 (k >= -1)
-            *(h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
+            *(h8*)(smem + OFF_XS + xslot * 2048 + swz(lrx, ch)) = fir4(hr[0], hr[1], hr[2], hr[3]);
         }
         D0TRACE(4);
         // ---- P3: conv0 of new h row 8k + 2 + wave -> row image -> horizontal FIR -> ring -------------------------------------------------
@@ -330,7 +333,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                             for (int q = 0; q < 4; ++q) v[q] = (half_t)acc[blk][g * 4 + q];
                             h4 hq = __builtin_elementwise_max(v * k1, v * k2);
                             if (masked && !colok) hq = h4{0, 0, 0, 0};
-                            *(h4*)(smem + rtw + g * 16 + blk * 2048) = hq;
+                            *(h4*)(smem + rtw + ((g ^ ((lr >> 2) & 3)) << 4) + blk * 2048) = hq;    // chunk XOR-swizzled by the column group: the
+                            // 32 lanes of a half-wave write 8 bytes each at the SAME offset of 32 different pixels — 8-way conflicts unswizzled
                         }
                     }
                 };
@@ -341,7 +345,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 h8 v[7];
 #pragma unroll
                 for (int q = 0; q < 7; ++q) {
-                    v[q] = *(const h8*)(smem + OFF_RT + wave * ROWB + vrot(min(4 * jj + q, 63), cgl));
+                    const int colq = min(4 * jj + q, 63);
+                    v[q] = *(const h8*)(smem + OFF_RT + wave * ROWB + vrot(colq, cgl ^ ((colq >> 2) & 3)));
                     if (q >= 4 && jj == 15) v[q] = zero;                               // window columns 64 .. 66 do not exist
                 }
                 if (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

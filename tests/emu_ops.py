@@ -558,13 +558,14 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
         # ---- P2: skip-branch input (FIR pad 1 + ::2 of the fromRGB map) of output rows 2k + 1, 2k + 2 -> ring slot o mod 3 ---------------
         for wave in range(_D0_NW):
             r, nh = wave >> 1, wave & 1
-            c = nh * 2 + kh
-            fc0 = np.minimum(2 * lr + 2, _D0_FC - 4)
+            c = nh * 2 + (lane & 1)                      # lane -> (pixel lane / 2, chunk nh * 2 + lane % 2)
+            lrx = lane >> 1
+            fc0 = np.minimum(2 * lrx + 2, _D0_FC - 4)
             hr = []
             for jy in range(4):
                 a = [rd(_D0_OFF_F + _d0_swa(2 * r + jy, fc0 + jx, c)) for jx in range(4)]
                 hr.append(_fir4(a[0], a[1], a[2], a[3]))
-            wr(_D0_OFF_XS + ((2 * k + 1 + r) % 3) * 2048 + _d0_swz(lr, c), _fir4(hr[0], hr[1], hr[2], hr[3]))
+            wr(_D0_OFF_XS + ((2 * k + 1 + r) % 3) * 2048 + _d0_swz(lrx, c), _fir4(hr[0], hr[1], hr[2], hr[3]))
         # ---- P3: conv0, wave = new h row 4k + 2 + wave; horizontal FIR wave-locally; ring slot (row + 2) mod 8 --------------------------
         for wave in range(_D0_NW):
             yh = 4 * k + 2 + wave
@@ -595,11 +596,12 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                     v = (quad + bq).astype(f16)
                     hq = np.maximum((v.astype(f32) * f32(f16(math.sqrt(2)))).astype(f16), (v.astype(f32) * f32(f16(0.2 * math.sqrt(2)))).astype(f16))
                     hq = np.where(colok[:, None], hq, f16(0))
-                    wr(rt + _vaddr(0, col, g) + kh * 8, hq, n=4)
+                    wr(rt + _vaddr(0, col, g ^ ((col >> 2) & 3)) + kh * 8, hq, n=4)
             v = []
             for kq in range(7):
                 c = 4 * jj + kq
-                val = rd(rt + _vaddr(0, np.minimum(c, 63), cgl))
+                cq = np.minimum(c, 63)
+                val = rd(rt + _vaddr(0, cq, cgl ^ ((cq >> 2) & 3)))
                 v.append(np.where((c < 64)[:, None], val, f16(0)))
             for i in range(4):
                 cb = 4 * jj + i
