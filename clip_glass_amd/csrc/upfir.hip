@@ -305,6 +305,14 @@ constexpr int U_OFF_HS = U_OFF_LNZ + 16 * 60 * 4;  // [256 threads][3 rows] h8: 
 constexpr int U_LDS = U_OFF_HS + 256 * 48;         // 81664 B: two workgroups per CU (163328 of 163840)
 static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32 * ROWB, "constant tables fit behind the staging images");
 __device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// T tile of upfir2 (r04): a row's 64 columns sit de-interleaved — column x at position (x & 1) * 32 + (x >> 1), 64 B each, the 16-byte
+// chunk index XORed with (x >> 2) & 3.  The MFMA lanes write columns 2 lr + c: with the columns in order, the 16 lanes of one ds_write_b64
+// group were 128 B apart and hit the same eight banks four deep (16 LDS cycles per instruction where 4 is ideal); 64 B apart and
+// chunk-rotated every second lane they are two deep (8).  The FIR's ds_read_b128 groups (lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31})
+// stay conflict-free when each group holds four columns of distinct (x >> 1) & 3: the FIR thread of column index ci takes column
+// u_fir_col(ci) (2 <-> 3 and 4 <-> 5 swapped within every 8).  tests/emu_ops.py carries the same index maps.
+__device__ __forceinline__ int u_tpos(int x) { return (x & 1) * 32 + (x >> 1); }
+__device__ __forceinline__ int u_fir_col(int ci) { return ci ^ (((ci >> 2) ^ (ci >> 1)) & 1); }
 }  // namespace
 
 // GRID = true: shared weights, candidates on a virtual grid, per-image operands through the LDS tables.
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             mfma_block();
             // ---- this step's constants: LDS tables -> registers (the T tile is about to cover them) -------------------------
             const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
-            const int cg = t & 3, oxl = t >> 2;              // FIR phase: 8-channel group, local output column 0..59 (t < 240)
+            const int cg = t & 3, oxl = u_fir_col(t >> 2);   // FIR phase: 8-channel group, local output column 0..59 (oxl < 60)
             f4 dq[2][4];
             {
                 const int ixl = (int)__umulhi((unsigned)max(mx0 + lr, 0), g.invPX) - ixi0;
@@ -579,10 +587,10 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 
             // ---- t tile -> LDS (demod applied; it commutes with the FIR); layout as in upfir_kernel --------------------------
             {
-                char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+                char* tw = (char*)T + ((2 * wave * 2) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
                 int so[4];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
+                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ ((lr >> 1) & 3)) * 16;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                             h4 o;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) o[q] = (half_t)(acc[i][ph][gq * 4 + q] * dq[i][gq][q]);
-                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1) * 32) * 64) = o;
                         }
             }
             __syncthreads();
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
                     const int ltx = oxl + 1 + jx;
-                    tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+                    tr[jx] = (const char*)T + u_tpos(ltx) * 64 + ((cg ^ ((ltx >> 2) & 3)) * 16);
                 }
                 const int yb = 2 * PY * (iyi0 + 1);                        // first virtual output row of the step's second image row
                 // Software-pipelined by hand (r04): row r + 1's four T vectors are requested before row r is filtered, and only the STORE is
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             // ---- single image: everything the FIR needs from global memory is fetched HERE, unconditionally and in one batch, so that
             // it lands under the last MFMA block (upfir_kernel's scheme) ----
             const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
-            const int cg = t & 3, oxl = t >> 2;
+            const int cg = t & 3, oxl = u_fir_col(t >> 2);
             const int ox = txi * 60 + oxl;
             const int pxc = min(ox, p.Wo - 1);
             f4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
@@ -677,10 +685,10 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             }
             __syncthreads();   // everyone is done with the staging area: overlay T
             {
-                char* tw = (char*)T + ((2 * wave * 2) * 64 + 2 * lr) * 64 + kh * 8;
+                char* tw = (char*)T + ((2 * wave * 2) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
                 int so[4];
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ (lr & 3)) * 16;
+                for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ ((lr >> 1) & 3)) * 16;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                             h4 o;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) o[q] = (half_t)acc[i][ph][gq * 4 + q];
-                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1)) * 64) = o;
+                            *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1) * 32) * 64) = o;
                         }
             }
             __syncthreads();
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
                     const int ltx = oxl + 1 + jx;
-                    tr[jx] = (const char*)T + ltx * 64 + ((cg ^ ((ltx >> 1) & 3)) * 16);
+                    tr[jx] = (const char*)T + u_tpos(ltx) * 64 + ((cg ^ ((ltx >> 2) & 3)) * 16);
                 }
                 const long long rowpitch = (long long)p.Wo * p.Cout;
                 half_t* yp = p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)

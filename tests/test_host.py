@@ -181,6 +181,43 @@ def test_dblock0_index_emulation():
         T.ops = saved
 
 
+def test_upfir2_t_tile_index_maps():
+    """upfir2's T tile (csrc/upfir.hip, u_tpos / u_fir_col): what the MFMA lanes write is what the FIR threads read — every (row, column,
+    8-channel chunk) of the tile lands on its own 16 bytes, FIR thread (column, chunk) finds the chunk the writers put there, the 60
+    FIR columns are each filtered once — and the layout costs what DESIGN says under the guide's bank model (writes 8 cycles, reads 4)."""
+    import emu_ops as E
+    where = {}                                   # (row, column, chunk, half) -> byte address
+    for wave in range(4):
+        for lane in range(64):
+            lr, kh = lane & 31, lane >> 5
+            for i in range(2):
+                for ph in range(4):
+                    for gq in range(4):
+                        key = (4 * wave + 2 * i + (ph >> 1), 2 * lr + (ph & 1), gq, kh)
+                        assert key not in where
+                        where[key] = E.upfir2_t_write_addr(wave, lane, i, ph, gq)
+    assert len(where) == 16 * 64 * 4 * 2
+    assert sorted(where.values()) == list(range(0, 65536, 8))          # a bijection onto the 64 KB tile
+    cols = sorted(E.upfir2_fir_col(t >> 2) for t in range(0, 240, 4))
+    assert cols == list(range(60))
+    for t in range(240):
+        cg, oxl = t & 3, E.upfir2_fir_col(t >> 2)
+        for jx in range(4):
+            for r in (0, 7, 15):
+                a = E.upfir2_t_read_addr(t, jx, r)
+                assert a == where[(r, oxl + 1 + jx, cg, 0)] and a + 8 == where[(r, oxl + 1 + jx, cg, 1)]
+    for ph in range(4):
+        for gq in range(4):
+            assert E.lds_cycles([E.upfir2_t_write_addr(1, l, 0, ph, gq) for l in range(64)], 8, "write") == 8
+    for wave in range(4):
+        for jx in range(4):
+            addrs = [E.upfir2_t_read_addr(64 * wave + l, jx, 3) if 64 * wave + l < 240 else None for l in range(64)]
+            assert E.lds_cycles(addrs, 16, "read") == 4
+    # the layout it replaced (columns in order, chunk ^ (column >> 1) & 3): 16-cycle writes
+    old = [((2 * (l & 31)) * 64) + ((1 ^ ((l & 31) & 3)) << 4) + (l >> 5) * 8 for l in range(64)]
+    assert E.lds_cycles(old, 8, "write") == 16
+
+
 def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
