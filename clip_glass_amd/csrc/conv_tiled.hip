@@ -22,6 +22,15 @@
 #include <stdlib.h>
 
 #define ROWB 80  // bytes per LDS row (32 halfs + 8 pad)
+// Staging order (r04): the thread that would stage row q of a group of eight takes row (q >> 1) + 4 * (q & 1) instead, so the 8 lanes of one
+// ds_write_b128 bank group hold rows r and r + 4 (320 B apart = 16 banks: disjoint) rather than r and r + 1 (80 B apart: the second
+// row's last 16 B wrap onto the first row's banks — 16 LDS cycles per instruction where 8 is the floor).  Global loads still cover the
+// same sixteen 64-byte rows per wave instruction.  tests/test_host.py::test_conv_tiled_lds_rows models both orders.
+__device__ __forceinline__ int tl_row(int r) { return (r & ~7) | ((r & 7) >> 1) | ((r & 1) << 2); }
+// blur-down by-product: thread column index ci filters output column tl_col(ci) (2 <-> 3 and 4 <-> 5 swapped in every 8) so that each
+// ds_read_b128 bank group (lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}) holds columns of one parity: 160-byte strides then tile
+// the 64 banks exactly (4 LDS cycles instead of 8)
+__device__ __forceinline__ int tl_col(int ci) { return ci ^ (((ci >> 2) ^ (ci >> 1)) & 1); }
 
 // dev tool (GLASS_TILED_TRACE=path): shader-clock stamps of the K stages of ONE workgroup in the middle of the grid (TR instance only)
 __device__ unsigned long long* g_tiled_trace = nullptr;
@@ -65,6 +74,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
     const int wr = SPL ? (wave & 1) : wave, wn = SPL ? (wave >> 1) : 0;   // this wave's row group / n group
     const int lr = lane & 31, kh = lane >> 5;
     const int part = t & 3;
+    const int trow = tl_row(t >> 2);           // staging: this thread's row within each block of 64 rows (vector k: row trow + 64 k)
     const int tpi = tiles_x * tiles_y;
     const int PT8 = (PT + 7) & ~7;
     const int n_work = PT8 * NTn;              // work items = (pixel tile, n tile)
@@ -106,11 +116,10 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
         for (int k = 0; k < (NA + 1) / 2; ++k) a_loff[k] = 0;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int v = t + 256 * k;
-            const int pix = v >> 2;
+            const int pix = trow + 64 * k;
             const int pr = pix / PW, pc = pix - pr * PW;
             const int iy = w.ty0 * S - p.pad + pr, ix = w.tx0 * S - p.pad + pc;
-            const bool ok = (k < NA - 1 || v < NVA) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const bool ok = (k < NA - 1 || pix < PH * PW) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             a_goff[k] = ok ? ((iy >> p.in_up) * (p.W >> p.in_up) + (ix >> p.in_up)) * p.Cin + part * 8 : part * 8;
             okm |= (ok ? 1 : 0) << k;
             int lrow = pix;
@@ -143,18 +152,19 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
     auto load_b = [&](h8 (&RB)[NB], int c0, int ty) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int u = min(t + 256 * k, NVB - 1);
-            const int tx = u / (NT * 4);
-            const int n = (u >> 2) % NT;
+            const int row = min(trow + 64 * k, KS * NT - 1);      // (KS * NT rows: whole groups of eight)
+            const int tx = row / NT;
+            const int n = row % NT;
             RB[k] = *(const h8*)(wb + ((long long)(ty * KS + tx) * p.Neff + ld_n0 + n) * p.Cin + c0 + part * 8);
         }
     };
     auto a_lds = [&](int k) { return As + ((a_loff[k >> 1] >> ((k & 1) * 16)) & 0xffff); };
     auto store_a = [&]() {
+        const bool last_in = trow + 64 * (NA - 1) < PH * PW;   // this thread's last vector is a pixel of the patch
         if (!border && !p.sn16 && !p.pre_shift16) {      // interior tile, no input transform: registers -> LDS
 #pragma unroll
             for (int k = 0; k < NA; ++k)
-                if (k < NA - 1 || t + 256 * k < NVA) *(h8*)a_lds(k) = ra[k];
+                if (k < NA - 1 || last_in) *(h8*)a_lds(k) = ra[k];
             return;
         }
         const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -162,12 +172,12 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
             const h8 shf = *(const h8*)(psb + ld_c0);    // fetched here to keep it out of the K-loop registers
 #pragma unroll
             for (int k = 0; k < NA; ++k)
-                if (k < NA - 1 || t + 256 * k < NVA)
+                if (k < NA - 1 || last_in)
                     *(h8*)a_lds(k) = ((okm >> k) & 1) ? __builtin_elementwise_max(ra[k] * sh + shf, zero) : zero;
         } else {
 #pragma unroll
             for (int k = 0; k < NA; ++k)
-                if (k < NA - 1 || t + 256 * k < NVA)
+                if (k < NA - 1 || last_in)
                     *(h8*)a_lds(k) = (((okm >> k) & 1) ? ra[k] : zero) * sh;    // 4 x v_pk_mul_f16 (1.0 without a style)
         }
     };
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int u = t + 256 * k;
-            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (u >> 2) * ROWB + part * 16) = RB[k];
+            if (k < NB - 1 || u < NVB) *(h8*)(Bs + (trow + 64 * k) * ROWB + part * 16) = RB[k];
         }
     };
 
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                 static_assert(!XS || (KS == 3 && S == 1 && TH == 8), "patch = tile + 1-pixel halo");
                 int tq = threadIdx.x;
                 asm volatile("" : "+v"(tq));                      // (geometry derived here, not hoisted above the MFMA blocks as loop invariants)
-                const int part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
+                const int part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = tl_col(pix & 15);
                 h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass (one row live at a time)
 #pragma unroll
                 for (int jy = 0; jy < 4; ++jy) {

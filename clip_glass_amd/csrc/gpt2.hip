@@ -668,32 +668,67 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
 // LDS; the value rows are read coalesced.  Sum orders as in gpt2_attention_kernel.
 __global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* qkv, const float* part, int S, const float* bias, float* kc, float* vc,
                                                                   int P, int Tmax, int heads, float* out, const int* past_dev) {
-    __shared__ __attribute__((aligned(16))) float qs[4][64], ks[4][64], ps[4][64];
+    __shared__ __attribute__((aligned(16))) float qs[4][64], ks[4][64], ps[4][64], hs[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
     if (item >= P * heads) return;                    // (no workgroup barrier below: waves are independent)
     const int past = *past_dev, ns = past + 1;
     const int D = heads * 64, seq = item / heads, h = item - seq * heads;
-    float r[3];
-    if (part) {      // slices in groups of four: their 12 loads are in flight together (a loop of dependent single loads was 9 round trips)
+    // One round trip (round 4): this lane's key row (16 x 16 B), the value rows of the whole history (up to 64 coalesced rows, in
+    // wave-uniform groups of 16) — the cache reads depend on `past` only — and the first four qkv slices are all requested before anything
+    // is summed.  As written in round 3 the kernel was a chain of dependent round trips (slices, key rows, one per 16 value rows): 11.5 us.
+    float r[3], bq[3] = {0.f, 0.f, 0.f}, pv[4][3];
+    f4 kk[16];
+    {
+        const float* kr = kc + ((long long)seq * Tmax + min(lane, Tmax - 1)) * D + h * 64;      // (rows past the history: loaded, never used)
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) kk[d4] = *(const f4*)(kr + 4 * d4);
+    }
+    const float* vr = vc + (long long)seq * Tmax * D + h * 64 + lane;
+    float vv[4][16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (16 * g < past) {                          // (wave-uniform; clamped row, zero weight past the history)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vv[g][u] = vr[(long long)min(16 * g + u, past - 1) * D];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) vv[g][u] = 0.f;
+        }
+    }
+    if (part) {
+        if (bias) {
+#pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3) bq[w3] = bias[w3 * D + h * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3)       // (unconditional, clamped slice: no branch between the loads)
+                pv[u][w3] = part[((long long)min(u, S - 1) * P + seq) * 3 * D + w3 * D + h * 64 + lane];
+    } else {
+#pragma unroll
+        for (int w3 = 0; w3 < 3; ++w3) r[w3] = qkv[(long long)seq * 3 * D + w3 * D + h * 64 + lane];
+    }
+    if (part) {      // slice order per element; + 0 for the slices past S; further groups of four (S > 4) as they come
         float a[3] = {0.f, 0.f, 0.f};
-        for (int z0 = 0; z0 < S; z0 += 4) {
-            float pv[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w3 = 0; w3 < 3; ++w3) a[w3] += u < S ? pv[u][w3] : 0.f;
+        for (int z0 = 4; z0 < S; z0 += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int w3 = 0; w3 < 3; ++w3)
-                    pv[u][w3] = z0 + u < S ? part[((long long)(z0 + u) * P + seq) * 3 * D + w3 * D + h * 64 + lane] : 0.f;
+                    pv[u][w3] = part[((long long)min(z0 + u, S - 1) * P + seq) * 3 * D + w3 * D + h * 64 + lane];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int w3 = 0; w3 < 3; ++w3) a[w3] += pv[u][w3];          // (slice order per element; + 0 for the slices past S)
+                for (int w3 = 0; w3 < 3; ++w3) a[w3] += z0 + u < S ? pv[u][w3] : 0.f;
         }
 #pragma unroll
-        for (int w3 = 0; w3 < 3; ++w3) r[w3] = a[w3] + (bias ? bias[w3 * D + h * 64 + lane] : 0.f);
-    } else {
-#pragma unroll
-        for (int w3 = 0; w3 < 3; ++w3) r[w3] = qkv[(long long)seq * 3 * D + w3 * D + h * 64 + lane];
+        for (int w3 = 0; w3 < 3; ++w3) r[w3] = a[w3] + bq[w3];
     }
     kc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[1];
     vc[((long long)seq * Tmax + past) * D + h * 64 + lane] = r[2];
@@ -707,10 +742,6 @@ __global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* q
 #pragma unroll 16
             for (int d = 0; d < 64; ++d) a += qs[wave][d] * ks[wave][d];
         } else {
-            const float* kr = kc + ((long long)seq * Tmax + lane) * D + h * 64;
-            f4 kk[16];
-#pragma unroll
-            for (int d4 = 0; d4 < 16; ++d4) kk[d4] = *(const f4*)(kr + 4 * d4);
 #pragma unroll
             for (int d4 = 0; d4 < 16; ++d4) {
                 const f4 qq = *(const f4*)(&qs[wave][4 * d4]);
@@ -727,16 +758,21 @@ __global__ __launch_bounds__(256) void gpt2_attention_step_kernel(const float* q
     float z = e2;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
-    ps[wave][lane] = e2 / z;
+    const float prob = e2 / z;
+    ps[wave][lane] = prob;
+    hs[wave][lane] = lane < past ? prob : 0.f;        // the history's weights alone (zero from the current position on)
     __builtin_amdgcn_wave_barrier();
-    const float* vr = vc + (long long)seq * Tmax * D + h * 64 + lane;
     float a = 0.f;
-    for (int j0 = 0; j0 < past; j0 += 16) {           // sixteen value rows in flight (clamped row, zero weight past the history); key order
-        float vv[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) vv[u] = vr[(long long)min(j0 + u, past - 1) * D];
+    for (int g = 0; g < 4; ++g) {
+        if (16 * g < past) {                          // sixteen value rows per group, key order
 #pragma unroll
-        for (int u = 0; u < 16; ++u) a += (j0 + u < past ? ps[wave][j0 + u] : 0.f) * vv[u];
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const f4 pw = *(const f4*)(&hs[wave][16 * g + 4 * u4]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a += pw[j] * vv[g][4 * u4 + j];
+            }
+        }
     }
     a += ps[wave][past] * r[2];
     out[(long long)seq * D + h * 64 + lane] = a;

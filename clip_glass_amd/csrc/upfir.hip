@@ -311,6 +311,9 @@ __device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); ret
 // chunk-rotated every second lane they are two deep (8).  The FIR's ds_read_b128 groups (lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31})
 // stay conflict-free when each group holds four columns of distinct (x >> 1) & 3: the FIR thread of column index ci takes column
 // u_fir_col(ci) (2 <-> 3 and 4 <-> 5 swapped within every 8).  tests/emu_ops.py carries the same index maps.
+// staging order of the padded 80-byte rows (as conv_tiled.hip's tl_row): the 8 lanes of a ds_write_b128 bank group hold rows r and r + 4
+// (disjoint banks) instead of r and r + 1 (the second row wraps onto the first one's banks: 16 LDS cycles where 8 is the floor)
+__device__ __forceinline__ int u_stage_row(int r) { return (r & ~7) | ((r & 7) >> 1) | ((r & 1) << 2); }
 __device__ __forceinline__ int u_tpos(int x) { return (x & 1) * 32 + (x >> 1); }
 __device__ __forceinline__ int u_fir_col(int ci) { return ci ^ (((ci >> 2) ^ (ci >> 1)) & 1); }
 }  // namespace
@@ -320,7 +323,7 @@ __device__ __forceinline__ int u_fir_col(int ci) { return ci ^ (((ci >> 2) ^ (ci
 // divisions — the 512^2 / 1024^2 layers are instruction-issue bound, every instruction per step counts.
 template <bool GRID>
 __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
-    constexpr int PW = U_PW, NVA = U_NVA, NA = U_NA, NVB = U_NVB, NB = U_NB, A_BYTES = U_A_BYTES;
+    constexpr int PW = U_PW, NA = U_NA, NVB = U_NVB, NB = U_NB, A_BYTES = U_A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + A_BYTES;
@@ -343,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     const int ixi0 = GRID ? (int)__umulhi((unsigned)max(mx0 - 1, 0), g.invPX) : 0;     // first image column the tile's patch touches
 
     const half_t* wb = p.w_up + (p.w_bstride ? (long long)img0 * p.w_bstride : 0LL);   // per-sample weights: one image per grid
-    // weight vector u = t + 256 k sits at tap (u >> 7), row (u >> 2) & 31: k only moves the tap, by a uniform 2 k * Cout * Cin
+    // weight vector u = t + 256 k sits at tap (u >> 7), row u_stage_row(u >> 2) & 31: k only moves the tap, by a uniform 2 k * Cout * Cin
     // (the last, half-empty round re-reads round 3's vector in threads >= 128)
-    const int b_goff0 = ((threadIdx.x >> 7) * p.Cout + n0 + ((threadIdx.x >> 2) & 31)) * p.Cin + (threadIdx.x & 3) * 8;
+    const int b_goff0 = ((threadIdx.x >> 7) * p.Cout + n0 + (u_stage_row(threadIdx.x >> 2) & 31)) * p.Cin + (threadIdx.x & 3) * 8;
     const int b_step = 2 * p.Cout * p.Cin;
     // FIR threads keep a sliding window of horizontally filtered t rows that runs on from step to step: its three live rows wait
     // in a thread-private LDS slot during the K loop (16 registers the K loop needs, next to the prefetched operands)
@@ -374,20 +377,19 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             const int t = u_opaque(threadIdx.x), part = t & 3;
 #pragma unroll
             for (int k = 0; k < NA; ++k) {
-                const int v = t + 256 * k;
-                const int pix = v >> 2;
+                const int pix = u_stage_row(t >> 2) + 64 * k;
                 const int pr = pix / PW, pc = pix - pr * PW;
                 const int vy = my0 - 1 + pr, vx = mx0 - 1 + pc;
                 if (GRID) {
                     const int iyi = (int)__umulhi((unsigned)max(vy, 0), g.invPY), ixi = (int)__umulhi((unsigned)max(vx, 0), g.invPX);
                     const int iy = vy - iyi * PY, ix = vx - ixi * PX;
                     const int img = img0 + iyi * g.NXI + ixi;
-                    const bool ok = v < NVA && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
+                    const bool ok = pix < U_PH * U_PW && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
                     a_goff[k] = ok ? img * (int)p.x_bstride + (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
                     okm |= (ok ? 1 : 0) << k;
                     selm |= ((((iyi - iyi0) << 2) + (ixi - ixi0)) & 7) << (3 * k);
                 } else {
-                    const bool ok = v < NVA && vy >= 0 && vx >= 0 && vy < p.H && vx < p.W;
+                    const bool ok = pix < U_PH * U_PW && vy >= 0 && vx >= 0 && vy < p.H && vx < p.W;
                     a_goff[k] = ok ? img0 * (int)p.x_bstride + (vy * p.W + vx) * p.Cin + part * 8 : part * 8;
                     okm |= (ok ? 1 : 0) << k;
                 }
@@ -407,17 +409,18 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         };
         auto store_a = [&](int c0) {
             const int t = threadIdx.x, part = t & 3;
-            char* ab = As + (t >> 2) * ROWB + part * 16;          // vector k sits 64 rows further down
+            const int trow = u_stage_row(t >> 2);
+            char* ab = As + trow * ROWB + part * 16;              // vector k sits 64 rows further down
             if (plain) {
 #pragma unroll
                 for (int k = 0; k < NA; ++k)
-                    if (k < NA - 1 || t + 256 * k < NVA) *(h8*)(ab + k * 64 * ROWB) = ra[k];
+                    if (k < NA - 1 || trow + 64 * k < U_PH * U_PW) *(h8*)(ab + k * 64 * ROWB) = ra[k];
             } else {
                 const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 const char* sty = smem + U_OFF_STY + (c0 + part * 8) * 2;
 #pragma unroll
                 for (int k = 0; k < NA; ++k) {
-                    if (k < NA - 1 || t + 256 * k < NVA) {
+                    if (k < NA - 1 || trow + 64 * k < U_PH * U_PW) {
                         h8 a = ((okm >> k) & 1) ? ra[k] : zero;
                         if (GRID && p.sn16) a = a * *(const h8*)(sty + ((selm >> (3 * k)) & 7) * 1024);   // the vector's own image's style
                         *(h8*)(ab + k * 64 * ROWB) = a;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         };
         auto store_b = [&]() {
             const int t = threadIdx.x, part = t & 3;
-            char* bb = Bs + (t >> 2) * ROWB + part * 16;
+            char* bb = Bs + u_stage_row(t >> 2) * ROWB + part * 16;
 #pragma unroll
             for (int k = 0; k < NB; ++k)
                 if (k < NB - 1 || t + 256 * k < NVB) *(h8*)(bb + k * 64 * ROWB) = rb[k];

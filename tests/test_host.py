@@ -218,6 +218,26 @@ def test_upfir2_t_tile_index_maps():
     assert E.lds_cycles(old, 8, "write") == 16
 
 
+def test_conv_tiled_lds_rows():
+    """conv_tiled.hip's padded 80-byte LDS rows under the guide's bank model: fragment reads are conflict-free, the staging order tl_row()
+    halves the cost of the staging writes (rows r, r + 4 per bank group instead of r, r + 1), tl_col() that of the blur-down reads; both
+    maps are permutations (every row staged once, every column filtered once)."""
+    import emu_ops as E
+    assert sorted(E.conv_tiled_row(r) for r in range(64)) == list(range(64))
+    assert sorted(E.upfir2_fir_col(c) for c in range(16)) == list(range(16))      # tl_col() is the same map as u_fir_col()
+    for base in (0, 1, 35, 340):
+        for kk in (0, 1):
+            frag = [(base + (l & 31)) * 80 + (kk * 2 + (l >> 5)) * 16 for l in range(64)]
+            assert E.lds_cycles(frag, 16, "read") == 4
+    plain = [(l >> 2) * 80 + (l & 3) * 16 for l in range(64)]
+    staged = [E.conv_tiled_row(l >> 2) * 80 + (l & 3) * 16 for l in range(64)]
+    assert E.lds_cycles(plain, 16, "write") == 16 and E.lds_cycles(staged, 16, "write") == 8
+    for j in range(4):          # blur-down: thread (part, column index) reads patch column 2 lx + j of a 34-pixel row
+        plain = [(2 * ((l >> 2) & 15) + j) * 80 + (l & 3) * 16 for l in range(64)]
+        perm = [(2 * E.upfir2_fir_col((l >> 2) & 15) + j) * 80 + (l & 3) * 16 for l in range(64)]
+        assert E.lds_cycles(plain, 16, "read") == 8 and E.lds_cycles(perm, 16, "read") == 4
+
+
 def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
