@@ -1570,7 +1570,7 @@ static void gpt2_work_free(glass_engine* e) {
     if (w.exec) hipGraphExecDestroy(w.exec);
     if (w.graph) hipGraphDestroy(w.graph);
     hipFree(w.d_tok); hipFree(w.d_gen); hipFree(w.d_state); hipFree(w.x); hipFree(w.ln); hipFree(w.qkv); hipFree(w.att); hipFree(w.hid);
-    hipFree(w.last); hipFree(w.logits); hipFree(w.kc); hipFree(w.vc); hipFree(w.part); hipFree(w.stats); hipFree(w.pairs);
+    hipFree(w.last); hipFree(w.logits); hipFree(w.kc); hipFree(w.vc); hipFree(w.part); hipFree(w.stats); hipFree(w.pairs); hipFree(w.pst);
     w = glass_engine::Gpt2Work();
 }
 
@@ -1625,7 +1625,8 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
         if (err == hipSuccess) err = hipMalloc(&w.vc, (size_t)nl * P * Tmax * D * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.part, w.part_elems * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.pairs, (size_t)2 * P * ((V + 31) / 32) * sizeof(float));   // (max, index) per (row, 32-column block)
-        if (err == hipSuccess) err = hipMalloc(&w.stats, (size_t)P * (2 + 2 * 32) * sizeof(float));   // + the two-stage arg-max's (value, index) pairs
+        if (err == hipSuccess) err = hipMalloc(&w.stats, (size_t)P * (2 + 2 * 32) * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&w.pst, (size_t)P * 24 * 2 * sizeof(float));   // row partials (mean, M2) of the complete-output step products   // + the two-stage arg-max's (value, index) pairs
         if (err != hipSuccess) {
             gpt2_work_free(e);
             glass_set_error(std::string("gpt2_decode: hipMalloc failed: ") + hipGetErrorString(err));
@@ -1646,6 +1647,12 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
+        // round 4 (gpt2.hip): the attention output product and the MLP's first product in the complete-output form — no slices, so no
+        // gpt2_finalize / splitk_reduce launch behind them: 6 launches per layer instead of 8.  (The qkv product and the MLP's second one
+        // stay split: complete, they were 12-14 us against 9.5 and 34 against 12 + 5.)  A/B knob: GLASS_GPT2_NO_ROWBLK.
+        static const bool no_rowblk = getenv("GLASS_GPT2_NO_ROWBLK") != nullptr;
+        const bool rowblk = step_state && fuse_ok && !no_rowblk && D % 32 == 0 && D / 32 <= 24 &&
+                            gemm_f32_rowblk_supported(P, D, D, D, false, true) && gemm_f32_rowblk_supported(P, 4 * D, D, D, true, false);
         if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st, fuse_ok ? w.stats : nullptr);
         else launch_gpt2_embed(w.d_tok, e->g_wte, e->g_wpe, M, nd, past, D, w.x, st);
         if (step_state && fuse_ok) {      // (the embedding kernel left the first layer's LayerNorm statistics)
@@ -1661,12 +1668,18 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
                     if (S > 1) launch_gpt2_reduce(w.part, S, b.b_qkv, w.qkv, P, 3 * D, 3 * D, 0, st);
                     launch_gpt2_attention(w.qkv, kcl, vcl, P, 1, past, Tmax, heads, w.att, st, step_state);
                 }
-                S = launch_gemm_f32_step(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
-                step_refused |= S == 0;
-                launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_o, w.x, P, D, w.stats, st);       // residual + LayerNorm 2 statistics
-                S = launch_gemm_f32_step(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, w.stats, b.ln2_g, b.ln2_b);
-                step_refused |= S == 0;
-                if (S > 1) launch_gpt2_reduce(w.part, S, b.b_fc, w.hid, P, 4 * D, 4 * D, 1, st);
+                if (rowblk) {       // x += att @ Wo + b (row partials of LayerNorm 2 in the epilogue); hid = gelu(LN2(x) @ Wfc + b)
+                    bool ok = launch_gemm_f32_rowblk(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, nullptr, 0, nullptr, nullptr, w.pst);
+                    ok &= launch_gemm_f32_rowblk(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.pst, D / 32, b.ln2_g, b.ln2_b, nullptr);
+                    step_refused |= !ok;
+                } else {
+                    S = launch_gemm_f32_step(w.att, b.w_o, b.b_o, w.x, P, D, D, D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
+                    step_refused |= S == 0;
+                    launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_o, w.x, P, D, w.stats, st);       // residual + LayerNorm 2 statistics
+                    S = launch_gemm_f32_step(w.x, b.w_fc, b.b_fc, w.hid, P, 4 * D, D, D, 4 * D, 1, st, w.part, w.part_elems, w.stats, b.ln2_g, b.ln2_b);
+                    step_refused |= S == 0;
+                    if (S > 1) launch_gpt2_reduce(w.part, S, b.b_fc, w.hid, P, 4 * D, 4 * D, 1, st);
+                }
                 S = launch_gemm_f32_step(w.hid, b.w_pr, b.b_pr, w.x, P, D, 4 * D, 4 * D, D, 2, st, w.part, w.part_elems, nullptr, nullptr, nullptr);
                 step_refused |= S == 0;
                 launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_pr, w.x, P, D, w.stats, st);      // residual + next LayerNorm's statistics

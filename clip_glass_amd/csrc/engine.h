@@ -140,7 +140,7 @@ struct glass_engine {
         int P = 0, nctx = 0, length = 0;
         int *d_tok = nullptr, *d_gen = nullptr, *d_state = nullptr;
         float *x = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *last = nullptr, *logits = nullptr,
-              *kc = nullptr, *vc = nullptr, *part = nullptr, *stats = nullptr, *pairs = nullptr;   // stats: [P][2] LayerNorm {mean, rstd} of the fused step
+              *kc = nullptr, *vc = nullptr, *part = nullptr, *stats = nullptr, *pairs = nullptr, *pst = nullptr;   // stats: [P][2] LayerNorm {mean, rstd} of the fused step
         size_t part_elems = 0;
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;

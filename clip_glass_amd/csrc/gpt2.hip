@@ -23,7 +23,7 @@ __global__ void gpt2_embed_kernel(const int* tok, const float* wte, const float*
 // stats != nullptr (fused step, D <= 1024): also the row's LayerNorm statistics {mean, rstd} for the first layer's fused LayerNorm — the
 // arithmetic of gpt2_finalize_kernel with 256 threads (two-pass mean / variance, lanes xor tree then waves 0..3).
 __global__ __launch_bounds__(256) void gpt2_embed_step_kernel(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D,
-                                                              float* x, float* stats) {
+                                                              float* x, float* stats, int partial_fmt) {
     __shared__ float red[4];
     const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int past = state[0], step = state[1];
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(256) void gpt2_embed_step_kernel(const int* gen, co
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const float d = t + 256 * k < D ? v[k] - mean : 0.f; q += d * d; }
-    const float var = block_sum(q) / (float)D;
-    if (t == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(var + 1e-5f); }
+    const float m2 = block_sum(q), var = m2 / (float)D;
+    if (t == 0) { stats[2 * row] = mean; stats[2 * row + 1] = partial_fmt ? m2 : rsqrtf(var + 1e-5f); }      // partial_fmt: ONE (mean, M2) partial over the row
 }
 void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st,
-                            float* stats) {
-    hipLaunchKernelGGL(gpt2_embed_step_kernel, dim3(P), dim3(256), 0, st, gen, state, P, wte, wpe, D, x, D <= 1024 ? stats : nullptr);
+                            float* stats, bool partial_fmt) {
+    hipLaunchKernelGGL(gpt2_embed_step_kernel, dim3(P), dim3(256), 0, st, gen, state, P, wte, wpe, D, x, D <= 1024 ? stats : nullptr, partial_fmt ? 1 : 0);
 }
 __global__ void gpt2_advance_kernel(int* state) {
     state[0] += 1;
@@ -308,6 +308,162 @@ static void launch_stream_inst(const float* A, const float* W, const float* bias
     if (stats) { if (one) GS_LAUNCH(true, true); else GS_LAUNCH(true, false); }
     else { if (one) GS_LAUNCH(false, true); else GS_LAUNCH(false, false); }
 #undef GS_LAUNCH
+}
+
+// ---- single-token steps, complete-output form (round 4) ---------------------------------------------------------------------------------
+// rocprofv3's timeline of a step (profiles/r04_gpt2_step_timeline.txt): every launch of the captured graph costs ~4.2 us before its first
+// instruction, whatever it does — gpt2_advance_kernel, ONE thread, is 4.2 us start to start; HIP_FORCE_DEV_KERNARG, packet capture, eager
+// launches and a second stream with half the rows change nothing (the dispatch cost is serial device-wide) — and a step was ~100 launches:
+// 420 of its 940 us.  What a step can still save is LAUNCHES.  The split-K products needed two helpers per layer that only existed to
+// add slices (splitk_reduce for the GELU input, gpt2_finalize for the residual stream + LayerNorm statistics) and an attention kernel
+// that summed slices on load.  Here a workgroup owns 32 rows x 32 columns over the WHOLE K: NK = 12 waves take one 64-deep chunk each
+// (K = 768; four chunks each through two register sets at K = 3072) — every load of the workgroup is in flight at once, as in
+// gemm_f32_stream_kernel, but two row blocks per column block double the workgroup count instead of a global split (48 / 192 workgroups of
+// 768 threads for the two products that use it) — and the twelve partial blocks meet through LDS in a fixed order.  Bias, GELU and the residual add happen
+// in the epilogue; the epilogue of a residual product also leaves each row's (mean, M2) over its 32 columns, and the next LayerNorm-fused
+// product combines a row's 24 partials (equal ranges: mean of means, M2s + range size x squared mean offsets; fixed order) while its operands
+// travel.  Measured per product (us, start to start, old split form incl. its helper launch -> complete form): attention output 7.1 + 5.0 ->
+// 11.4, MLP first 13.4 + 4.9 -> 14.4-16; the qkv product 9.5 -> 12-14 (its slices are summed by the attention kernel for free) and the
+// MLP's second one 11.9 + 5.0 -> 34 (K = 3072: four chunks per wave on 48 workgroups) stay split: 6 launches per layer instead of 8.
+// pst layout: [row][np][2] = (mean, sum of squared deviations) of the row's np equal column ranges.
+template <int NK, bool LNX, bool ONE>
+__global__ __launch_bounds__(64 * NK) void gemm_f32_rowblk_kernel(const float* A, const float* W, const float* bias, float* out, int M, int N,
+                                                                  int K, int lda, int ldo, int mode, const float* pst_in, int np_in,
+                                                                  const float* lng, const float* lnb, float* pst_out) {
+    static_assert(NK >= 8, "eight waves finish the block");
+    __shared__ float Rs[NK][16][64];                          // the K parts' partial blocks
+    __shared__ __attribute__((aligned(16))) float Gs[LNX ? 1024 : 4], Bs[LNX ? 1024 : 4];
+    __shared__ float Ms[32], Is[32];                          // LNX: mean / rstd of the workgroup's 32 rows
+    const int t = threadIdx.x, lane = t & 63, kp = t >> 6, lr = lane & 31, kh = lane >> 5;
+    const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int kpart = K / NK, k_lo = kp * kpart, n_ch = kpart / GS_KC;
+    const float* wrow = W + (long long)min(n0 + lr, N - 1) * K + k_lo + 4 * kh;          // rows past N / M re-read the last row (never stored)
+    const float* xrow = A + (long long)min(m0 + lr, M - 1) * lda + k_lo + 4 * kh;
+    f4 wr[ONE ? 1 : 2][8], xr[ONE ? 1 : 2][8];
+    auto load = [&](int c, int set) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+            xr[set][b] = *(const f4*)(xrow + c * GS_KC + 8 * b);
+        }
+    };
+    f16x acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    load(0, 0);
+    float mu = 0.f, rs = 1.f;
+    if (LNX) {
+        for (int i = t; i < K; i += 64 * NK) { Gs[i] = lng[i]; Bs[i] = lnb[i]; }
+        if (t < 32) {
+            const float* pp = pst_in + (long long)min(m0 + t, M - 1) * np_in * 2;
+            constexpr int NPMAX = 24;
+            float pm[NPMAX], pq[NPMAX];
+#pragma unroll
+            for (int j = 0; j < NPMAX; ++j) {                 // one batch of loads (clamped index), then the fixed-order combine
+                const int jj = min(j, np_in - 1);
+                pm[j] = pp[2 * jj]; pq[j] = pp[2 * jj + 1];
+            }
+            // equal ranges: mean = mean of the means, M2 = sum of the M2s + count * sum of the squared mean offsets (fixed order j = 0 ..)
+            float msum = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPMAX; ++j) {
+                msum += j < np_in ? pm[j] : 0.f;
+                m2 += j < np_in ? pq[j] : 0.f;
+            }
+            const float mean = msum / (float)np_in;
+            float off = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPMAX; ++j) {
+                const float d = pm[j] - mean;
+                off += j < np_in ? d * d : 0.f;
+            }
+            m2 += (float)(K / np_in) * off;
+            Ms[t] = mean;
+            Is[t] = rsqrtf(m2 / (float)K + 1e-5f);
+        }
+        __syncthreads();
+        mu = Ms[lr]; rs = Is[lr];
+    }
+    auto chunk = [&](int c, int set) {            // set = c & 1, a compile-time constant at both call sites
+        if (!ONE && c + 1 < n_ch) load(c + 1, ONE ? 0 : set ^ 1);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            f4 xv = xr[set][b];
+            if (LNX) {
+                const int kl = k_lo + c * GS_KC + 8 * b + 4 * kh;
+                xv = (xv - mu) * rs * *(const f4*)(Gs + kl) + *(const f4*)(Bs + kl);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s2], wr[set][b][s2], acc, 0, 0, 0);   // D[m][n]
+        }
+    };
+    if (ONE) {
+        chunk(0, 0);
+    } else {
+        for (int c = 0; c < n_ch; c += 2) {
+            chunk(c, 0);
+            if (c + 1 < n_ch) chunk(c + 1, 1);
+        }
+    }
+    // the NK partial blocks meet in LDS; waves 0 .. 7 then finish two accumulator registers (= 2 x 2 rows of the block) each: K parts added
+    // in order 0 .. NK-1, bias / GELU / residual, store, row partials
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Rs[kp][q][lane] = acc[q];
+    __syncthreads();
+    if (kp >= 8) return;
+    const int n = n0 + lr;
+    const bool n_ok = n < N;
+    const float bv = (bias && n_ok) ? bias[n] : 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int reg = 2 * kp + qq;
+        const int m = m0 + mfma32_row(reg, lane);
+        const bool ok = n_ok && m < M;
+        const float rv = (mode == 2 && ok) ? out[(long long)m * ldo + n] : 0.f;       // residual value: in flight under the LDS reads
+        float pz[NK];
+#pragma unroll
+        for (int z = 0; z < NK; ++z) pz[z] = Rs[z][reg][lane];
+        float v = pz[0];
+#pragma unroll
+        for (int z = 1; z < NK; ++z) v += pz[z];
+        v += bv;
+        if (mode == 1) {
+            const float c = 0.7978845608028654f;  // sqrt(2/pi)
+            v = 0.5f * v * (1.f + tanhf(c * (v + 0.044715f * v * v * v)));
+        } else if (mode == 2) {
+            v += rv;
+        }
+        if (ok) out[(long long)m * ldo + n] = v;
+        if (pst_out) {                             // (N % 32 == 0: every lane holds a column) this row's 32 columns sit in the lanes of one kh half
+            float sum = v;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * (1.f / 32.f), d = v - mean;
+            float q = d * d;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            if (lr == 0 && m < M) {
+                float* po = pst_out + ((long long)m * gridDim.x + blockIdx.x) * 2;
+                po[0] = mean; po[1] = q;
+            }
+        }
+    }
+}
+bool gemm_f32_rowblk_supported(int M, int N, int K, int lda, bool ln_fused, bool stats_out) {
+    return M > 0 && M <= 64 && N % 32 == 0 && K % (12 * GS_KC) == 0 && lda % 4 == 0 && !(ln_fused && K > 1024) && !(stats_out && N / 32 > 24);
+}
+// false: shape not covered, nothing launched.  pst_in / np_in: the LayerNorm-fused operand's row partials; pst_out: [M][N / 32][2]
+bool launch_gemm_f32_rowblk(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
+                            hipStream_t st, const float* pst_in, int np_in, const float* lng, const float* lnb, float* pst_out) {
+    if (!gemm_f32_rowblk_supported(M, N, K, lda, pst_in != nullptr, pst_out != nullptr) || (pst_in && (np_in < 1 || np_in > 24 || K % np_in != 0)))
+        return false;
+    const dim3 g(N / 32, (M + 31) / 32), b(64 * 12);
+    const bool one = K == 12 * GS_KC;
+#define RB_LAUNCH(LN, ON) hipLaunchKernelGGL((gemm_f32_rowblk_kernel<12, LN, ON>), g, b, 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, pst_in, np_in, lng, lnb, pst_out)
+    if (pst_in) { if (one) RB_LAUNCH(true, true); else RB_LAUNCH(true, false); }
+    else { if (one) RB_LAUNCH(false, true); else RB_LAUNCH(false, false); }
+#undef RB_LAUNCH
+    return true;
 }
 
 // x[m][:] += bias + sum_s part[s][m][:] (split-K slices in a fixed order; part == nullptr: x as it is), then the row's LayerNorm statistics

@@ -129,7 +129,11 @@ void launch_gpt2_attention_step(const float* qkv, const float* part, int S, cons
                                 float* out, hipStream_t st, const int* past_dev);
 void launch_argmax(const float* logits, int rows, int N, int* out, hipStream_t st, const int* step_dev = nullptr, float* scratch = nullptr);
 void launch_gpt2_embed_step(const int* gen, const int* state, int P, const float* wte, const float* wpe, int D, float* x, hipStream_t st,
-                            float* stats = nullptr);
+                            float* stats = nullptr, bool partial_fmt = false);
+// complete-output step product: a workgroup = 32 rows x 32 columns over the whole K (gpt2.hip); false = shape not covered, nothing launched
+bool gemm_f32_rowblk_supported(int M, int N, int K, int lda, bool ln_fused, bool stats_out);
+bool launch_gemm_f32_rowblk(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
+                            hipStream_t st, const float* pst_in, int np_in, const float* lng, const float* lnb, float* pst_out);
 void launch_gpt2_advance(int* state, hipStream_t st);
 // NCHW fp32 image [n][3][S][S] -> CLIP patch matrix [n*G*G][3*ps*ps] fp16
 void launch_image_patches(const float* img, int n, int S, int ps, half_t* patches, hipStream_t st);
