@@ -18,6 +18,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 constexpr int NT = 128, NTHR = 512;
@@ -313,7 +314,9 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 // buffer and nowhere else: the output transposition goes through it in four 32-channel slices (4 KB + pad per wave).
 // XS: ConvParams::xs_out — FIR 4x4 (pad 1) + ::2 of the INPUT map (the D block's skip-branch input) from the patch of each chunk as it
 // becomes visible: 8 x 16 pixels x 4 parts = one vector per thread per chunk (n tile 0 only); its store is one more op in the wait counts.
-template <bool TRGB, bool XS = false>
+// ST: the layer is modulated (ConvParams::sn16) — a template parameter so that the K loop is ONE straight-line body: with the test inside,
+// every sub-step is its own basic block and the waits between them fall back to lgkmcnt(0).
+template <bool TRGB, bool XS = false, bool ST = true>
 __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int TW = 32;
     using G = Geo<TW>;
@@ -501,28 +504,48 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                 *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + ly) * (p.W >> 1) + (tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
             }
             const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
+            // Six (tap, 16-channel half) sub-steps of 8 MFMAs.  Rolling fragment registers (r04): a weight fragment is dead after its two
+            // MFMAs, so the NEXT sub-step's fragment is read into its place right behind them, and the next pixel fragments (two extra
+            // registers sets of 4) at the top of the sub-step — every read of sub-step u + 1 is issued between the MFMAs of sub-step u and
+            // has 6-8 MFMAs (200-250 cycles) to land; only the first sub-step of a stage waits for a whole LDS round trip.  (hipcc still closes
+            // every sub-step with s_waitcnt lgkmcnt(0), i.e. it also waits for the two pixel fragments it has just requested: a spare weight
+            // register set to issue everything earlier was re-ordered by the scheduler into the same pattern.)  conv_gldsp layers 8.28 -> 8.02 ms.
+            {
+                h8 wf[4], xf[RW], xn[RW], sv, svn;
+                auto rdw = [&](int u, int j) {
+                    const int tx = u >> 1, lc = (u & 1) * 2 + kh, row = tx * NT + j * 32 + lr;
+                    return *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                };
+                auto rdx = [&](int u, int i) {
+                    const int tx = u >> 1, lc = (u & 1) * 2 + kh, pix = (wave * RW + i + ty) * PW + lr + tx;
+                    return *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
+                };
+                auto rds = [&](int u) { return *(const h8*)(Ss + c * 32 + ((u & 1) * 2 + kh) * 8); };
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx) {
+                for (int j = 0; j < 4; ++j) wf[j] = rdw(0, j);
+                if (ST) sv = rds(0);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int lc = kk * 2 + kh;
-                    h8 wf[4];
+                for (int i = 0; i < RW; ++i) xf[i] = rdx(0, i);
+#pragma unroll
+                for (int u = 0; u < 6; ++u) {
+                    if (u < 5) {
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) xn[i] = rdx(u + 1, i);
+                        if (ST) svn = rds(u + 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int row = tx * NT + j * 32 + lr;
-                        wf[j] = *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                        const h8 w = ST ? wf[j] * sv : wf[j];
+#pragma unroll
+                        for (int i = 0; i < RW; ++i) acc[i][j] = mfma32(w, xf[i], acc[i][j]);
+                        if (u < 5) wf[j] = rdw(u + 1, j);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (p.sn16) {
-                        const h8 sv = *(const h8*)(Ss + c * 32 + lc * 8);
+                    if (u < 5) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) wf[j] = wf[j] * sv;
-                    }
-#pragma unroll
-                    for (int i = 0; i < RW; ++i) {
-                        const int pix = (wave * RW + i + ty) * PW + lr + tx;
-                        const h8 xf = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(wf[j], xf, acc[i][j]);
+                        for (int i = 0; i < RW; ++i) xf[i] = xn[i];
+                        if (ST) sv = svn;
                     }
                 }
             }
@@ -650,19 +673,28 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
     const int n_cu = glass_cu_count() - glass_cu_count() % 8;       // a workgroup keeps its XCD (id % 8) across items
     static DevOnce once_p;
     if (once_p.first()) {
-        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
     }
     // (>= 2 work items per CU at the NOMINAL population, common.h: this branch also decides whether the blur-down by-product exists,
     // so it must be a function of the layer geometry only)
     const long long work_nominal = (long long)GLASS_NOMINAL_POP * tiles_x * tiles_y * NTn;
     if (TW == 32 && !no_persist && (p.Cin & 63) == 0 && work_nominal >= 2 * n_cu) {   // ring parity needs an even chunk count
         // (reported under the symbol that runs, so that the per-kernel profile lines up with rocprofv3's kernel names)
-        const char* pname = (p.xs_out && !TRGB) ? "conv_gldsp_kernel<false,true>" : (TRGB ? "conv_gldsp_kernel<true>" : "conv_gldsp_kernel<false>");
+        const bool xs = p.xs_out && !TRGB, sty = p.sn16 != nullptr;
+        const char* pname = xs ? (sty ? "conv_gldsp_kernel<false,true,true>" : "conv_gldsp_kernel<false,true,false>")
+                          : TRGB ? (sty ? "conv_gldsp_kernel<true,false,true>" : "conv_gldsp_kernel<true,false,false>")
+                                 : (sty ? "conv_gldsp_kernel<false,false,true>" : "conv_gldsp_kernel<false,false,false>");
         if (p.dry_run) return pname;
-        if (p.xs_out && !TRGB) hipLaunchKernelGGL((conv_gldsp_kernel<false, true>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
-        else hipLaunchKernelGGL((conv_gldsp_kernel<TRGB>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
+#define GLDSP_LAUNCH(...) hipLaunchKernelGGL((conv_gldsp_kernel<__VA_ARGS__>), dim3(n_cu), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT)
+        if (xs) { if (sty) GLDSP_LAUNCH(false, true, true); else GLDSP_LAUNCH(false, true, false); }
+        else if (sty) GLDSP_LAUNCH(TRGB, false, true);
+        else GLDSP_LAUNCH(TRGB, false, false);
+#undef GLDSP_LAUNCH
         return pname;
     }
     if (p.xs_out) return nullptr;            // (the blur-down by-product exists in the persistent form only)
