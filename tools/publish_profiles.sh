@@ -13,6 +13,7 @@ cp gpurun_out/pmc_sq_$R/sq_counters.txt profiles/${R}_sq_counters.txt
 cp gpurun_out/$R/pytest_gpu.log profiles/${R}_pytest_gpu.log
 cp gpurun_out/$R/bench_biggan512.json profiles/${R}_bench_biggan512.json
 cp gpurun_out/$R/bench_gpt2.json profiles/${R}_bench_gpt2.json
+[ -f gpurun_out/$R/gpt2_step_timeline.txt ] && cp gpurun_out/$R/gpt2_step_timeline.txt profiles/${R}_gpt2_step_timeline.txt
 { echo "# tools/mfma_peak (v_mfma_f32_32x32x16_f16; >= 50 ms timed after a 100 ms warm-up; zero vs non-zero operands)"; cat gpurun_out/$R/mfma_peak.txt;
   echo; echo "# tools/hbm_peak (16-byte accesses, 1 GiB arrays, best of 5)"; cat gpurun_out/$R/hbm_peak.txt;
   echo; echo "# tools/inflight_probe (HBM read rate vs waves per CU x 16-byte loads in flight per thread)"; cat gpurun_out/$R/inflight_probe.txt; } > profiles/${R}_device_peaks.txt
