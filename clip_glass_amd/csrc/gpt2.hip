@@ -735,13 +735,23 @@ void launch_gemm_f32(const float* A, const float* W, const float* bias, float* o
         if (S > 1)
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out,
                                M, N, ldo, mode);
-    } else if (((M + 127) / 128) * ((N + 127) / 128) < 200) {
-        // prefill with a narrow output (N = 768: 72 tiles of 128 x 128 for 256 CUs): 64 x 64 tiles fill the chip
-        dim3 g((M + 63) / 64, (N + 63) / 64, 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
     } else {
-        dim3 g((M + 127) / 128, (N + 127) / 128, 1);
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
+        // prefill: the tile shape whose grid quantises best on the CUs — rounds x tile area (a workgroup is four waves, one per SIMD:
+        // 288 tiles of 128 x 128 on 256 CUs take two rounds, 576 of 128 x 64 take three of half the size); larger tiles on ties (fewer
+        // LDS bytes per MFMA).  Every shape adds an element's k terms in the same order: the choice never changes a value.
+        static const int shapes[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+        const int n_cu = glass_cu_count();
+        int best = 0;
+        long long best_cost = -1;
+        for (int i = 0; i < 3; ++i) {
+            const long long tiles = (long long)((M + shapes[i][0] - 1) / shapes[i][0]) * ((N + shapes[i][1] - 1) / shapes[i][1]);
+            const long long cost = ((tiles + n_cu - 1) / n_cu) * shapes[i][0] * shapes[i][1];
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
+        }
+        const dim3 g((M + shapes[best][0] - 1) / shapes[best][0], (N + shapes[best][1] - 1) / shapes[best][1], 1);
+        if (best == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
+        else if (best == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
+        else hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
     }
 }
 
