@@ -1613,7 +1613,7 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
         w.part_elems = (size_t)16 * P * 4 * D;
         hipError_t err = hipMalloc(&w.d_tok, rows * sizeof(int));
         if (err == hipSuccess) err = hipMalloc(&w.d_gen, (size_t)P * length * sizeof(int));
-        if (err == hipSuccess) err = hipMalloc(&w.d_state, 2 * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&w.d_state, 3 * sizeof(int));      // {past length, step index, ticket counter of the fused step tail}
         if (err == hipSuccess) err = hipMalloc(&w.x, rows * D * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.ln, rows * D * sizeof(float));
         if (err == hipSuccess) err = hipMalloc(&w.qkv, rows * 3 * D * sizeof(float));
@@ -1645,6 +1645,11 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     const bool fuse_ok = !no_fuse && gemm_f32_step_supported(P, D, D, true) && gemm_f32_step_supported(P, 4 * D, 4 * D, false);
     bool step_refused = false;
     static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
+    // fused step tail (round 4): the pick also writes the NEXT step's embedding + first LayerNorm statistics and advances the state — a step
+    // starts at layer 0's qkv product; the first step's embedding is one eager launch after the prefill.  A/B knob: GLASS_GPT2_NO_TAIL.
+    static const bool no_head = getenv("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
+    static const bool no_tail = getenv("GLASS_GPT2_NO_TAIL") != nullptr;
+    const bool tail_fused = fuse_ok && !no_head && !no_tail && D <= 1024 && gpt2_head_supported(P, V, D, D);
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
         // round 4 (gpt2.hip): the attention output product and the MLP's first product in the complete-output form — no slices, so no
@@ -1653,7 +1658,7 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
         static const bool no_rowblk = getenv("GLASS_GPT2_NO_ROWBLK") != nullptr;
         const bool rowblk = step_state && fuse_ok && !no_rowblk && D % 32 == 0 && D / 32 <= 24 &&
                             gemm_f32_rowblk_supported(P, D, D, D, false, true) && gemm_f32_rowblk_supported(P, 4 * D, D, D, true, false);
-        if (step_state) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st, fuse_ok ? w.stats : nullptr);
+        if (step_state) { if (!tail_fused) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st, fuse_ok ? w.stats : nullptr); }
         else launch_gpt2_embed(w.d_tok, e->g_wte, e->g_wpe, M, nd, past, D, w.x, st);
         if (step_state && fuse_ok) {      // (the embedding kernel left the first layer's LayerNorm statistics)
             for (int l = 0; l < nl; ++l) {
@@ -1684,7 +1689,11 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
                 step_refused |= S == 0;
                 launch_gpt2_finalize(S > 1 ? w.part : nullptr, S, b.b_pr, w.x, P, D, w.stats, st);      // residual + next LayerNorm's statistics
             }
-            static const bool no_head = getenv("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
+            if (tail_fused) {
+                step_refused |= !launch_gpt2_head_tail(w.x, e->g_wte, P, V, D, D, w.stats, e->g_lnf_g, e->g_lnf_b, w.pairs, w.d_gen, w.d_state, e->g_wte, e->g_wpe,
+                                                       w.x, w.stats, st);
+                return;
+            }
             if (no_head || !launch_gpt2_head(w.x, e->g_wte, P, V, D, D, w.stats, e->g_lnf_g, e->g_lnf_b, nullptr, w.pairs, w.d_gen, w.d_state, st)) {
                 // ln_f fused; the real vocabulary (1571 column blocks) is never split, a small one may be
                 const int S = launch_gemm_f32_step(w.x, e->g_wte, nullptr, w.logits, P, V, D, D, V, 0, st, w.part, w.part_elems, w.stats, e->g_lnf_g, e->g_lnf_b);
@@ -1716,10 +1725,11 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     std::vector<int32_t> gen((size_t)P * length);
     GLASS_HIP(hipEventRecord(e->ev0, st));
     hipMemcpyAsync(w.d_tok, context, rows * sizeof(int), hipMemcpyHostToDevice, st);
-    const int state0[2] = {0, 0}, state1[2] = {nctx, 1};
+    const int state0[3] = {0, 0, 0}, state1[3] = {nctx, 1, 0};
     hipMemcpyAsync(w.d_state, state0, sizeof state0, hipMemcpyHostToDevice, st);
     pass(nctx, 0, nullptr);                                 // prefill = step 0 (writes d_gen[0 .. P))
     hipMemcpyAsync(w.d_state, state1, sizeof state1, hipMemcpyHostToDevice, st);
+    if (tail_fused && length > 1) launch_gpt2_embed_step(w.d_gen, w.d_state, P, e->g_wte, e->g_wpe, D, w.x, st, w.stats);   // step 1's embedding (later ones: the step tail)
     hipError_t err = hipSuccess;
     if (length > 1) {
         // the 29 single-token steps are the same ~190 launches each: capture one step once, replay it (launch latency, not work,

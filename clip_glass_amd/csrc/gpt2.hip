@@ -633,10 +633,78 @@ __global__ __launch_bounds__(256) void argmax_pairs_kernel(const float* pv, cons
     }
     if (threadIdx.x == 0) out[(step_dev ? (long long)step_dev[1] * gridDim.x : 0) + blockIdx.x] = bi[0];
 }
+// stage 2 + the NEXT step's first kernel + the state update in one launch (round 4: a launch is ~4 us of dispatch whatever it does): the
+// row's token goes to gen[step][row], its embedding at position past + 1 and the first layer's LayerNorm statistics are left exactly as
+// gpt2_embed_step_kernel would leave them at the top of the next step (same arithmetic), and the LAST workgroup to get here advances
+// {past, step} — every workgroup has read the state before it takes its ticket.  state[2] is the ticket counter (zero between launches).
+__global__ __launch_bounds__(256) void gpt2_pick_embed_kernel(const float* pv, const int* pi, int NB, int* gen, int* state, int P, const float* wte,
+                                                              const float* wpe, int D, float* x, float* stats) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    __shared__ float red[4];
+    const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int past = state[0], step = state[1];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = t; i < NB; i += 256) {
+        const float v = pv[(long long)row * NB + i];
+        const int j = pi[(long long)row * NB + i];
+        if (v > best || (v == best && j < idx)) { best = v; idx = j; }
+    }
+    bv[t] = best;
+    bi[t] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) {
+            const float v2 = bv[t + o];
+            const int i2 = bi[t + o];
+            if (v2 > bv[t] || (v2 == bv[t] && i2 < bi[t])) { bv[t] = v2; bi[t] = i2; }
+        }
+        __syncthreads();
+    }
+    const int tok = bi[0];
+    if (t == 0) gen[(long long)step * P + row] = tok;
+    const float* te = wte + (long long)tok * D;
+    const float* pe = wpe + (long long)(past + 1) * D;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = t + 256 * k;
+        if (i < D) { v[k] = te[i] + pe[i]; x[(long long)row * D + i] = v[k]; }
+    }
+    auto block_sum = [&](float q) {
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        __syncthreads();
+        if (lane == 0) red[wave] = q;
+        __syncthreads();
+        return ((red[0] + red[1]) + red[2]) + red[3];
+    };
+    const float mean = block_sum((v[0] + v[1]) + (v[2] + v[3])) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float d = t + 256 * k < D ? v[k] - mean : 0.f; q += d * d; }
+    const float var = block_sum(q) / (float)D;
+    if (t == 0) {
+        stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(var + 1e-5f);
+        __threadfence();
+        if (atomicAdd(&state[2], 1) == (int)gridDim.x - 1) { state[0] = past + 1; state[1] = step + 1; state[2] = 0; }
+    }
+}
+bool gpt2_head_supported(int M, int N, int K, int lda) { return M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && N >= 4096; }
+// the vocabulary projection + the fused pick / embed / advance tail (D <= 1024); false: shape not covered, nothing launched
+bool launch_gpt2_head_tail(const float* A, const float* W, int M, int N, int K, int lda, const float* stats_in, const float* lng, const float* lnb,
+                           float* pairs, int* gen, int* state, const float* wte, const float* wpe, float* x, float* stats_out, hipStream_t st) {
+    if (!gpt2_head_supported(M, N, K, lda) || !pairs || K > 1024) return false;
+    const int NB = (N + 31) / 32;
+    int* pi = (int*)(pairs + (size_t)M * NB);
+    hipLaunchKernelGGL(gpt2_head_kernel, dim3((NB + HD_NW - 1) / HD_NW), dim3(64 * HD_NW), 0, st, A, W, M, N, K, lda, stats_in, lng, lnb, (float*)nullptr, pairs, pi, NB);
+    hipLaunchKernelGGL(gpt2_pick_embed_kernel, dim3(M), dim3(256), 0, st, pairs, pi, NB, gen, state, M, wte, wpe, K, x, stats_out);
+    return true;
+}
 // false: shape not covered (caller: generic product + launch_argmax).  pairs: scratch of 2 * M * ceil(N / 32) words.
 bool launch_gpt2_head(const float* A, const float* W, int M, int N, int K, int lda, const float* stats, const float* lng, const float* lnb,
                       float* logits, float* pairs, int* out, const int* step_dev, hipStream_t st) {
-    if (M > 64 || K % GS_KC != 0 || lda % 4 != 0 || !pairs || N < 4096) return false;
+    if (!gpt2_head_supported(M, N, K, lda) || !pairs) return false;
     const int NB = (N + 31) / 32;
     int* pi = (int*)(pairs + (size_t)M * NB);
     hipLaunchKernelGGL(gpt2_head_kernel, dim3((NB + HD_NW - 1) / HD_NW), dim3(64 * HD_NW), 0, st, A, W, M, N, K, lda, stats, lng, lnb, logits, pairs, pi, NB);

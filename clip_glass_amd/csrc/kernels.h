@@ -118,6 +118,10 @@ bool gemm_f32_step_supported(int M, int K, int lda, bool ln_fused);   // launch_
 // fused single-token step (round 3): products with LayerNorm on the activation operand / complete outputs, and the residual + statistics pass
 int launch_gemm_f32_step(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo, int mode,
                          hipStream_t st, float* part, size_t part_elems, const float* stats, const float* lng, const float* lnb);
+bool gpt2_head_supported(int M, int N, int K, int lda);
+// vocabulary projection + pick + the next step's embedding / first LayerNorm statistics + state advance (state[2] = ticket counter, zero)
+bool launch_gpt2_head_tail(const float* A, const float* W, int M, int N, int K, int lda, const float* stats_in, const float* lng, const float* lnb,
+                           float* pairs, int* gen, int* state, const float* wte, const float* wpe, float* x, float* stats_out, hipStream_t st);
 bool launch_gpt2_head(const float* A, const float* W, int M, int N, int K, int lda, const float* stats, const float* lng, const float* lnb,
                       float* logits, float* pairs, int* out, const int* step_dev, hipStream_t st);
 void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out, int M, int N, int ldo, int mode, hipStream_t st);
