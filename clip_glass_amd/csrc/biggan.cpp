@@ -284,8 +284,10 @@ struct BgConv {
     const float* bias = nullptr;
     const half_t* resid = nullptr;
     int res_cs = 0, res_up = 0;
+    float* rgb_tanh = nullptr;      // planar tanh(channels 0..2) instead of y (ConvParams::rgb_tanh_out)
+    bool dry = false;               // only ask whether conv_tiled takes the layer in that form
 };
-void bg_conv(glass_engine* e, const char* tag, int c0, int B, const BgConv& q) {
+bool bg_conv(glass_engine* e, const char* tag, int c0, int B, const BgConv& q) {
     BgState& g = e->bg;
     ConvParams p = conv_defaults();
     const int rin = q.res >> q.in_up;
@@ -316,10 +318,16 @@ void bg_conv(glass_engine* e, const char* tag, int c0, int B, const BgConv& q) {
     p.res_cs = q.res_cs;
     p.res_up = q.res_up;
     p.y = q.y;
+    p.rgb_tanh_out = q.rgb_tanh;
+    if (q.dry) {
+        p.dry_run = 1;
+        return launch_conv_tiled(p, e->cur) != nullptr;
+    }
     const double M = (double)B * q.res * q.res, Min = (double)B * rin * rin;
     const double rbytes = q.resid ? M * q.cout / (q.res_up ? 4 : 1) : 0.0;
     run_conv(e, p, tag, 2.0 * M * q.cout * q.cin * q.ks * q.ks,
-             2.0 * (Min * q.cin + M * q.cout + rbytes + (double)q.cout * q.cin * q.ks * q.ks));
+             2.0 * (Min * q.cin + (q.rgb_tanh ? M * 6.0 : M * q.cout) + rbytes + (double)q.cout * q.cin * q.ks * q.ks));
+    return true;
 }
 
 void bg_attention(glass_engine* e, int B, const half_t* x, half_t* y) {
@@ -441,9 +449,21 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
         BgConv q{R, ch, g.rgb_cpad, 3, g.rgb_w, g.x[cur], g.t2};
         q.pre_bn = g.final_bn_off;
         q.bias = g.rgb_b;
-        bg_conv(e, "bg.final.conv_to_rgb", c0, B, q);
-        Prof pr(e, "bg.final.tanh", 0, B * (double)R * R * (2.0 * g.rgb_cpad + 12.0));
-        launch_bg_rgb_tanh(g.t2, B, (long long)R * R, g.rgb_cpad, y, e->cur);
+        // round 4: tanh(channels 0..2) straight from the conv's accumulators as planar fp32 — the 32-channel fp16 map (1.07 GB at 512 px,
+        // P = 64) and the pass that re-read it are gone; A/B knob GLASS_BG_NO_RGB_FUSE.  (Small test geometries the instance does not
+        // take keep the two-pass form.)
+        static const bool no_rgb_fuse = getenv("GLASS_BG_NO_RGB_FUSE") != nullptr;
+        BgConv qd = q;
+        qd.rgb_tanh = y;
+        qd.dry = true;
+        if (!no_rgb_fuse && bg_conv(e, "bg.final.conv_to_rgb", c0, B, qd)) {
+            qd.dry = false;
+            bg_conv(e, "bg.final.conv_to_rgb+tanh", c0, B, qd);
+        } else {
+            bg_conv(e, "bg.final.conv_to_rgb", c0, B, q);
+            Prof pr(e, "bg.final.tanh", 0, B * (double)R * R * (2.0 * g.rgb_cpad + 12.0));
+            launch_bg_rgb_tanh(g.t2, B, (long long)R * R, g.rgb_cpad, y, e->cur);
+        }
     }
     return GLASS_OK;
 }

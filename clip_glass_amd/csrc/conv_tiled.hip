@@ -449,6 +449,15 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                         const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
                         f4 v = act_apply(a * d + bb + nzr[i], ak);           // (SKIP: activation was applied before the skip stages: ak = scale only)
                         if (p.res) v += f4{(float)rq[g][i][0], (float)rq[g][i][1], (float)rq[g][i][2], (float)rq[g][i][3]} * p.out_scale;
+                        if (NT == 32 && !TRGB && !SKIP && !XS && p.rgb_tanh_out) {   // channels 0..2 of this pixel: the lanes of half 0, quad 0
+                            if (nl == 0) {
+                                const long long hw = (long long)p.Ho * p.Wo;
+                                float* yo = p.rgb_tanh_out + (long long)b * 3 * hw + (long long)(oy0 + i) * p.Wo + ox;
+#pragma unroll
+                                for (int cc = 0; cc < 3; ++cc) yo[cc * hw] = tanhf(v[cc]);
+                            }
+                            continue;
+                        }
                         h4 out;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) out[q] = (half_t)v[q];
@@ -478,6 +487,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                 }
             }
             __builtin_amdgcn_wave_barrier();              // LDS is in-order per wave: only pin the compiler's order
+            if (!(NT == 32 && !TRGB && !SKIP && !XS && p.rgb_tanh_out)) {
 #pragma unroll
             for (int i = 0; i < RW; ++i) {
                 half_t* yrow = p.y + (((long long)b * p.Ho + oy0 + i) * p.Wo + cur.tx0) * p.Cout + cur.n0 + wn * NJ * 32;
@@ -487,6 +497,7 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                     const int pix = v / (NJ * 4), chv = v % (NJ * 4);
                     *(h8*)(yrow + (long long)pix * p.Cout + chv * 8) = *(const h8*)(Os + (i * 32 + pix) * OROW + chv * 16);
                 }
+            }
             }
         } else {
             // generic path (folded up-conv with depth-to-space, odd channel counts, persistent variant)
@@ -600,6 +611,13 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     if (no_ts) p.no_tstore = 1;
     // A/B knob GLASS_DEEP: 0 = round 2's one-stage prefetch distance, 1 = patch three stages ahead, 2 = + two weight register sets (stride 2)
     static const int deep_on = getenv("GLASS_DEEP") ? atoi(getenv("GLASS_DEEP")) : 1;
+    if (p.rgb_tanh_out) {   // planar tanh(channels 0..2) from the accumulators: the one-n-tile 3x3 instance's fast path only
+        if (p.y32 || p.trgb_yout || p.xs_out || p.up || p.KS != 3 || p.stride != 1 || p.pad != 1 || p.no_tstore || p.Neff != 32 || p.Cout != 32 ||
+            p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || (p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16) || p.res || p.noise ||
+            (p.x_bstride == 0 && p.B > 1) || (long long)p.H * p.W * p.Cin >= (1LL << 31))
+            return nullptr;
+        return launch_inst<3, 1, 8, 32>(p, st, "conv_tiled_kernel<3,1,8,32>");
+    }
     if (p.y32 || !p.y) return nullptr;
     if (p.trgb_yout) {   // fused toRGB: only where one workgroup holds every output channel of its pixels
         if (!p.trgb_tab || !p.trgb_b || p.up || p.KS != 3 || p.stride != 1 || p.pad != 1 || p.no_tstore || p.Neff != 64 || p.Cout != 64 ||

@@ -777,6 +777,14 @@ void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flop
     }
     Prof pr(e, tag, flops, bytes);
     const char* k = p.up ? launch_upconv_fused(p, e->cur) : nullptr;
+    if (p.rgb_tanh_out) {      // (one kernel family writes this output; the caller asked conv_tiled's dry run first)
+        k = launch_conv_tiled(p, e->cur);
+        if (!k && e->launch_error.empty()) e->launch_error = std::string("no kernel writes the planar tanh output of layer ") + tag;
+        if (!k) k = "(refused)";
+        if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+        if (e->profiling) e->tag_kernel[tag] = k;
+        return;
+    }
     if (!k) k = launch_conv_stream(p, e->cur);
     if (!k) k = launch_conv_glds(p, e->cur);
     if (!k) k = launch_conv_tiled(p, e->cur);
