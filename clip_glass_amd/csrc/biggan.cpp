@@ -429,6 +429,21 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
             snprintf(tag, sizeof tag, "bg.b%zu.conv2.r%d.%dx%d", i, ro, b.mid, b.mid);
             bg_conv(e, tag, c0, B, q);
         }
+        // round 4: the LAST block's conv_3 + skip, the final bn - relu, conv_to_rgb[:3] and tanh in one kernel (bg_tail.hip): the
+        // 128-channel full-resolution map between them never exists.  Not when that block's output was asked for as a tap; A/B knob
+        // GLASS_BG_NO_TAIL.
+        static const bool no_tail = getenv("GLASS_BG_NO_TAIL") != nullptr;
+        if (i + 1 == g.blocks.size() && !no_tail && e->bg_tap != (int)i && ro == g.R &&
+            bg_tail_supported(ro, b.mid, b.cout, b.cin, b.up, g.rgb_cpad)) {
+            BgTailParams tp;
+            tp.h = g.t3; tp.x0 = x; tp.w3 = b.w[3]; tp.b3 = b.b3;
+            tp.tab = g.tab + (size_t)c0 * 2 * g.Ctot; tp.bnf_off = g.final_bn_off; tp.ctot = g.Ctot;
+            tp.rgb_w = g.rgb_w; tp.cpad = g.rgb_cpad; tp.rgb_b = g.rgb_b; tp.y = y; tp.B = B; tp.R = ro;
+            const double M = (double)B * ro * ro;
+            Prof pr(e, "bg.tail.conv3+bn+to_rgb+tanh", 2.0 * M * (32.0 * 128 + 128.0 * 27), M * (2.0 * 32 + 2.0 * 128 / 4 + 12.0));
+            launch_bg_tail(tp, e->cur);
+            return GLASS_OK;
+        }
         {   // skip = x0[:, :cout] (channel drop), nearest x2 when up: read straight from the block input
             BgConv q{ro, b.mid, b.cout, 1, b.w[3], g.t3, g.x[cur ^ 1]};
             q.bias = b.b3;

@@ -106,6 +106,22 @@ void launch_bg_attn_split(const half_t* T, int B, int H, int W, int c8, int c2, 
 void launch_bg_softmax(const float* S, long long rows, int n, half_t* Pm, hipStream_t st);
 void launch_bg_rgb_tanh(const half_t* x, int B, long long hw, int C, float* y, hipStream_t st);
 
+// --- BigGAN-deep's last stage in one kernel (bg_tail.hip): conv_3 + skip -> bn -> relu -> conv_to_rgb[:3] -> tanh ---------------
+struct BgTailParams {
+    const half_t* h;        // [B][R][R][32]: relu(bn_3(conv_2)) of the last block (conv_2's epilogue applied them)
+    const half_t* x0;       // [B][R/2][R/2][128]: the block's input (skip source, nearest x2)
+    const half_t* w3;       // [128][32] conv_3 weights (spectral norm folded)
+    const float* b3;        // [128]
+    const float* tab;       // this chunk's first row of the batch-norm affine table: scale at [bnf_off + c], shift at [ctot + bnf_off + c]
+    int bnf_off, ctot;
+    const half_t* rgb_w;    // [9][cpad][128] conv_to_rgb weights (rows 0..2 of each tap used)
+    int cpad;
+    const float* rgb_b;     // [>= 3]
+    float* y;               // [B][3][R][R] fp32
+    int B, R;
+};
+bool bg_tail_supported(int R, int mid, int cout, int cin, int up, int cpad);
+bool launch_bg_tail(const BgTailParams& p, hipStream_t st);
 // --- GPT-2 (fp32, gpt2.hip) ----------------------------------------------------------
 void launch_gpt2_embed(const int* tok, const float* wte, const float* wpe, int rows, int L, int pos0, int D, float* x,
                        hipStream_t st);
