@@ -22,15 +22,18 @@ constexpr int BT_TH = 8, BT_TW = 32, BT_PH = BT_TH + 2, BT_PW = BT_TW + 2, BT_NP
 
 __global__ __launch_bounds__(256, 2) void bg_tail_kernel(BgTailParams p, int tiles_x, int tiles_y, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Ps[BT_NBLK * 32][32];   // P[pixel][27 used of 32]; 16-byte chunk index ^ (pixel & 7)
-    __shared__ __attribute__((aligned(16))) float Ca[128], Cc[128];       // final bn scale; conv_3 bias * scale + shift
+    __shared__ __attribute__((aligned(16))) half_t Ca[128], Cc[128];      // final bn scale; conv_3 bias * scale + shift (fp16: the epilogue is packed)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
     const int R = p.R, R2 = R >> 1;
     // weight fragments (MFMA A operands), resident for the whole launch
+    // (conv_3's rows carry the final bn's scale: bn(conv + bias + skip) = (scale * W) x + skip * scale + (bias * scale + shift))
     h8 w3f[4][2], wtf[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+        const half_t sc = (half_t)p.tab[p.bnf_off + j * 32 + lr];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) w3f[j][kk] = *(const h8*)(p.w3 + (j * 32 + lr) * 32 + kk * 16 + kh * 8);
+        for (int kk = 0; kk < 2; ++kk) w3f[j][kk] = *(const h8*)(p.w3 + (j * 32 + lr) * 32 + kk * 16 + kh * 8) * sc;
+    }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {          // row n = tap * 3 + colour; K slots in accumulator-lane channel order
         const int j = s >> 1, gp = s & 1;
@@ -45,28 +48,49 @@ __global__ __launch_bounds__(256, 2) void bg_tail_kernel(BgTailParams p, int til
     }
     if (t < 128) {                         // (the generator's last bn is unconditional: every sample's table row holds the same values)
         const float a = p.tab[p.bnf_off + t], s = p.tab[p.ctot + p.bnf_off + t];
-        Ca[t] = a;
-        Cc[t] = p.b3[t] * a + s;
+        Ca[t] = (half_t)a;
+        Cc[t] = (half_t)(p.b3[t] * a + s);
     }
     const float rb0 = p.rgb_b[0], rb1 = p.rgb_b[1], rb2 = p.rgb_b[2];
     __syncthreads();
     const int tpi = tiles_x * tiles_y;
+    h8 nx0, nx1;
+    h4 nsk[4];
+    struct { const half_t* sp; bool inb; } nb = {p.x0, false};
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = tile / tpi, trem = tile - b * tpi;
         const int ty0 = (trem / tiles_x) * BT_TH, tx0 = (trem % tiles_x) * BT_TW;
+        // operands of a 32-pixel block are requested one block ahead (the wave's first block of the NEXT tile included): as plain
+        // load -> use the kernel was a chain of exposed HBM round trips, three per wave and tile
+        auto aim = [&](int tl, int blk, h8& xa, h8& xb, h4 (&sq)[4]) {
+            const int bb = tl / tpi, tr = tl - bb * tpi;
+            const int y0 = (tr / tiles_x) * BT_TH, x0 = (tr % tiles_x) * BT_TW;
+            const int pl = blk * 32 + lr;
+            const int pr = pl / BT_PW, pc = pl - pr * BT_PW;
+            const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+            const int cy = min(max(gy, 0), R - 1), cx = min(max(gx, 0), R - 1);
+            const half_t* hp = p.h + (((long long)bb * R + cy) * R + cx) * 32 + kh * 8;
+            xa = *(const h8*)hp;
+            xb = *(const h8*)(hp + 16);
+            decltype(nb) r;
+            r.sp = p.x0 + (((long long)bb * R2 + (cy >> 1)) * R2 + (cx >> 1)) * 128 + 4 * kh;
+            r.inb = pl < BT_NPX && gy >= 0 && gy < R && gx >= 0 && gx < R;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sq[g] = *(const h4*)(r.sp + 8 * g);
+            return r;
+        };
+        if (tile == (int)blockIdx.x) nb = aim(tile, wave, nx0, nx1, nsk);       // (first tile of this workgroup: nothing was in flight)
 #pragma unroll 1
         for (int blk = wave; blk < BT_NBLK; blk += 4) {
             const int pl = blk * 32 + lr;
-            const int pr = pl / BT_PW, pc = pl - pr * BT_PW;
-            const int gy = ty0 - 1 + pr, gx = tx0 - 1 + pc;
-            const bool inb = pl < BT_NPX && gy >= 0 && gy < R && gx >= 0 && gx < R;
-            const int cy = min(max(gy, 0), R - 1), cx = min(max(gx, 0), R - 1);
-            const half_t* hp = p.h + (((long long)b * R + cy) * R + cx) * 32 + kh * 8;
-            const h8 x0f = *(const h8*)hp, x1f = *(const h8*)(hp + 16);
-            const half_t* sp = p.x0 + (((long long)b * R2 + (cy >> 1)) * R2 + (cx >> 1)) * 128 + 4 * kh;
+            const h8 x0f = nx0, x1f = nx1;
+            const half_t* sp = nb.sp;
+            const bool inb = nb.inb;
             h4 skc[4], skn[4];              // the skip's quads of this pixel, one 32-channel slice ahead of their use
 #pragma unroll
-            for (int g = 0; g < 4; ++g) skc[g] = *(const h4*)(sp + 8 * g);
+            for (int g = 0; g < 4; ++g) skc[g] = nsk[g];
+            if (blk + 4 < BT_NBLK) nb = aim(tile, blk + 4, nx0, nx1, nsk);
+            else if (tile + (int)gridDim.x < n_tiles) nb = aim(tile + gridDim.x, wave, nx0, nx1, nsk);
             f16x pacc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) pacc[q] = 0.f;
@@ -83,13 +107,11 @@ __global__ __launch_bounds__(256, 2) void bg_tail_kernel(BgTailParams p, int til
                 acc = mfma32(w3f[j][1], x1f, acc);
                 h4 zq[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < 4; ++g) {              // packed fp16 from here on (the unfused path rounded this map to fp16 and applied bn there too)
                     const int c0 = j * 32 + 8 * g + 4 * kh;
-                    const f4 a = {acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
-                    const f4 s = {(float)skc[g][0], (float)skc[g][1], (float)skc[g][2], (float)skc[g][3]};
-                    f4 v = (a + s) * *(const f4*)(Ca + c0) + *(const f4*)(Cc + c0);       // bn(conv_3 + bias + skip)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) zq[g][q] = (half_t)(inb ? fmaxf(v[q], 0.f) : 0.f);   // relu; the conv's zero padding outside the image
+                    const h4 a = {(half_t)acc[g * 4], (half_t)acc[g * 4 + 1], (half_t)acc[g * 4 + 2], (half_t)acc[g * 4 + 3]};
+                    const h4 v = a + (skc[g] * *(const h4*)(Ca + c0) + *(const h4*)(Cc + c0));
+                    zq[g] = inb ? __builtin_elementwise_max(v, h4{0, 0, 0, 0}) : h4{0, 0, 0, 0};   // relu; the conv's zero padding outside the image
                 }
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp)
@@ -98,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void bg_tail_kernel(BgTailParams p, int til
 #pragma unroll
                     for (int g = 0; g < 4; ++g) skc[g] = skn[g];
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two slices' chains may interleave (four spilled)
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
