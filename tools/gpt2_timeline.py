@@ -3,7 +3,8 @@
     rocprofv3 --kernel-trace --stats -d <dir> -o gpt2 -- python bench.py --config gpt2 --steps 2 --warmup 1 --no-cpu-baseline
     python tools/gpt2_timeline.py <dir>/gpt2_results.db
 Prints every launch of the last complete step (start relative to the step, start-to-end duration, grid) and the per-kernel sums: inside the
-captured graph a launch starts when its predecessor ends, so a duration includes the dispatch cost (gpt2_advance_kernel: ONE thread)."""
+captured graph a launch starts when its predecessor ends, so a duration includes the dispatch cost (the 64-workgroup helpers' ~5 us are
+almost all dispatch: gpt2_advance_kernel, ONE thread, measured 4.1-4.2 us in the unfused forms)."""
 import collections
 import sqlite3
 import sys
@@ -12,7 +13,10 @@ import sys
 def main(path):
     con = sqlite3.connect(path)
     rows = list(con.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))
-    adv = [i for i, r in enumerate(rows) if "gpt2_advance" in r[0]]
+    # a step ends with the fused pick / embed / advance kernel (round 4) or, in the unfused forms, with gpt2_advance_kernel
+    adv = [i for i, r in enumerate(rows) if "gpt2_pick_embed" in r[0]]
+    if len(adv) < 3:
+        adv = [i for i, r in enumerate(rows) if "gpt2_advance" in r[0]]
     if len(adv) < 3:
         sys.exit("no complete decode step in the trace")
     i0, i1 = adv[-2], adv[-1]
