@@ -238,6 +238,25 @@ def test_conv_tiled_lds_rows():
         assert E.lds_cycles(plain, 16, "read") == 8 and E.lds_cycles(perm, 16, "read") == 4
 
 
+def test_layernorm_row_partials_combine():
+    """gpt2.hip's complete-output products leave each row's (mean, M2) over their 32 columns; the next LayerNorm-fused product combines a
+    row's 24 partials as: mean = mean of the means, M2 = sum of the M2s + 32 * sum of the squared mean offsets.  Restated in float32 numpy
+    and compared with the two-pass statistics of the whole row (what gpt2_finalize_kernel computes) on rows with a large common offset."""
+    rng = np.random.default_rng(3)
+    for offset in (0.0, 7.5, -40.0):
+        x = (rng.standard_normal((5, 768)) * rng.uniform(0.3, 3.0, (5, 1)) + offset).astype(np.float32)
+        blocks = x.reshape(5, 24, 32)
+        pm = blocks.mean(axis=2, dtype=np.float32)
+        pq = ((blocks - pm[:, :, None]) ** 2).sum(axis=2, dtype=np.float32)
+        mean = pm.sum(axis=1, dtype=np.float32) / np.float32(24)
+        m2 = pq.sum(axis=1, dtype=np.float32) + np.float32(32) * ((pm - mean[:, None]) ** 2).sum(axis=1, dtype=np.float32)
+        rstd = 1.0 / np.sqrt(m2 / np.float32(768) + np.float32(1e-5))
+        ref_mean = x.astype(np.float64).mean(axis=1)
+        ref_rstd = 1.0 / np.sqrt(x.astype(np.float64).var(axis=1) + 1e-5)
+        np.testing.assert_allclose(mean, ref_mean, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(rstd, ref_rstd, rtol=5e-6)
+
+
 def _gloo_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
