@@ -106,6 +106,28 @@ def test_biggan_per_block_taps(name):
     e.close()
 
 
+def test_biggan_fused_last_stage_matches_the_three_launch_path():
+    """bg_tail.hip (conv_3 + skip -> bn -> relu -> conv_to_rgb -> tanh in one kernel, the 3x3 as a sum of MFMA partial products) against
+    the three-launch path it replaces, on the SAME engine and inputs at biggan-deep-512 size: a tap request for the last block's output
+    keeps that pass on the unfused kernels (biggan.cpp).  The two differ in where the 128-channel map is rounded to fp16 only."""
+    name = "bg512"
+    c = M.BIGGAN_CONFIGS[name]
+    P = 2
+    sd = M.make_biggan_state(name, 0)
+    x = synth.biggan_population(5, P, c["z_dim"], c["num_classes"])
+    e = M.make_biggan_engine(name, sd, batch_size=P, max_pop=P)
+    fused = np.array(e.generate(x), np.float32)
+    e.biggan_tap(len(c["layers"]) - 1)
+    unfused = np.array(e.generate(x), np.float32)
+    assert e.biggan_tap_result().shape[-1] == c["ch"]          # (the tap was taken: that pass ran conv_3 on its own)
+    again = np.array(e.generate(x), np.float32)                 # one-shot tap: this pass is fused again, and deterministic
+    e.close()
+    np.testing.assert_array_equal(fused, again)
+    err = float(np.abs(fused - unfused).max())
+    diag("[biggan] fused last stage vs three launches at %s: max |diff| = %.3e (images in (-1, 1))" % (name, err))
+    assert err < 4e-3
+
+
 def test_biggan_error_paths():
     from clip_glass_amd.engine import Engine
     c = M.BIGGAN_CONFIGS["bg_mini"]
