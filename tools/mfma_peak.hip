@@ -35,6 +35,47 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float scale)
     out[blockIdx.x * 256 + t] = s;
 }
 
+// the exact-fp32 matrix instruction of the GPT-2 path (v_mfma_f32_32x32x2_f32: 4096 FLOP per instruction)
+template <int NACC>
+__global__ __launch_bounds__(256) void probe_f32(float* out, int iters, float scale) {
+    const int t = threadIdx.x;
+    f16v acc[NACC];
+    for (int i = 0; i < NACC; ++i)
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const float a = scale * 0.01f * (t + 1), b = scale * 0.02f * (t - 7);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i)
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + t] = s;
+}
+template <int NACC>
+void run_f32(const char* name, int blocks) {
+    float* out;
+    hipMalloc(&out, blocks * 256 * 4);
+    const int iters = 10000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int arm = 0; arm < 2; ++arm) {
+        const float scale = arm ? 1.f : 0.f;
+        for (int w = 0; w < 30; ++w) probe_f32<NACC><<<blocks, 256>>>(out, iters, scale);
+        hipDeviceSynchronize();
+        const int launches = 20;
+        hipEventRecord(e0);
+        for (int w = 0; w < launches; ++w) probe_f32<NACC><<<blocks, 256>>>(out, iters, scale);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double fl = (double)launches * blocks * 4 * iters * NACC * 4096.0;
+        printf("%-34s blocks=%5d  %-8s %8.2f ms  %7.1f TFLOP/s\n", name, blocks, arm ? "nonzero" : "zeros", ms, fl / ms * 1e-9);
+    }
+    hipFree(out);
+}
+
 template <int NACC, int LR>
 void run(const char* name, int blocks) {
     float* out;
@@ -68,5 +109,9 @@ int main() {
     run<8, 6>("6 ds_read_b128 / 8 MFMA, 4 w/SIMD", 1024);
     run<4, 4>("4 ds_read_b128 / 4 MFMA, 2 w/SIMD", 512);
     run<4, 4>("4 ds_read_b128 / 4 MFMA, 3 w/SIMD", 768);
+    run_f32<4>("fp32 32x32x2, regs, 1 wave/SIMD", 256);
+    run_f32<4>("fp32 32x32x2, regs, 2 waves/SIMD", 512);
+    run_f32<2>("fp32 32x32x2, 2 accumulators, 1 w", 256);
+    run_f32<1>("fp32 32x32x2, 1 accumulator, 1 w", 256);
     return 0;
 }
