@@ -592,21 +592,42 @@ __global__ __launch_bounds__(64 * HD_NW) void gpt2_head_kernel(const float* A, c
     }
     if (nb >= NB) return;
     const int n = nb * 32 + lr;
+    // Row maxima across the 32 columns of the block (the lanes of one kh half): the xor butterfly runs STEP-major over all 32 rows a
+    // lane holds (r04: row-major, every step waited for its own ds_bpermute round trip — 160 dependent ones, 16 us of the kernel's 87),
+    // values only; the winning column is the lowest lane of the half whose value equals the maximum (one ballot per row).
+    float best[2][16];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int m = i * 32 + mfma32_row(reg, lane);
             if (logits && n < N && m < M) logits[(long long)m * N + n] = acc[i][reg];
-            float best = n < N ? acc[i][reg] : -INFINITY;
-            int idx = n;
+            best[i][reg] = n < N ? acc[i][reg] : -INFINITY;
+        }
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {            // across the 32 columns of this row (the lanes of one kh half)
-                const float v2 = __shfl_xor(best, o);
-                const int i2 = __shfl_xor(idx, o);
-                if (v2 > best || (v2 == best && i2 < idx)) { best = v2; idx = i2; }
+    for (int o = 16; o > 0; o >>= 1) {
+        float other[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) other[i][reg] = __shfl_xor(best[i][reg], o);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) best[i][reg] = fmaxf(best[i][reg], other[i][reg]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = i * 32 + mfma32_row(reg, lane);
+            const float mine = n < N ? acc[i][reg] : -INFINITY;
+            const unsigned long long hit = __ballot(mine == best[i][reg]);             // lanes holding their row's maximum
+            const unsigned half = (unsigned)(hit >> (32 * kh));                          // this half's rows
+            if (lr == 0 && m < M) {
+                pv[(long long)m * NB + nb] = best[i][reg];
+                pi[(long long)m * NB + nb] = nb * 32 + (half ? __builtin_ctz(half) : 0);   // lowest column on exact ties (torch.topk's first maximum)
             }
-            if (lr == 0 && m < M) { pv[(long long)m * NB + nb] = best; pi[(long long)m * NB + nb] = idx; }
         }
 }
 // stage 2: one workgroup per row over its NB (value, index) pairs -> out[step * rows + row]
