@@ -825,18 +825,13 @@ void launch_gemm_f32(const float* A, const float* W, const float* bias, float* o
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long long)M * N + 255) / 256)), dim3(256), 0, st, part, S, bias, out,
                                M, N, ldo, mode);
     } else {
-        // prefill: the tile shape whose grid quantises best on the CUs — rounds x tile area (a workgroup is four waves, one per SIMD:
-        // 288 tiles of 128 x 128 on 256 CUs take two rounds, 576 of 128 x 64 take three of half the size); larger tiles on ties (fewer
-        // LDS bytes per MFMA).  Every shape adds an element's k terms in the same order: the choice never changes a value.
+        // prefill: 64 x 64 tiles for every product.  Measured per shape over the whole decode (M = 64 x 23 rows, GLASS_GPT2_TILE): 128 x 128
+        // everywhere 30.4 ms, 128 x 64 28.3, the shape whose grid quantises best on the CUs 28.2, 64 x 64 27.8 — a 64 x 64 workgroup is 17 KB
+        // of LDS and 32 VGPRs, so a CU holds many of them and their barriers / LDS round trips overlap; the larger tiles run one
+        // workgroup (one wave per SIMD) per CU.  Every shape adds an element's k terms in the same order: the choice never changes a value.
         static const int shapes[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-        const int n_cu = glass_cu_count();
-        int best = 0;
-        long long best_cost = -1;
-        for (int i = 0; i < 3; ++i) {
-            const long long tiles = (long long)((M + shapes[i][0] - 1) / shapes[i][0]) * ((N + shapes[i][1] - 1) / shapes[i][1]);
-            const long long cost = ((tiles + n_cu - 1) / n_cu) * shapes[i][0] * shapes[i][1];
-            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
-        }
+        static const int force = getenv("GLASS_GPT2_TILE") ? atoi(getenv("GLASS_GPT2_TILE")) : -1;   // A/B knob
+        const int best = (force >= 0 && force < 3) ? force : 2;
         const dim3 g((M + shapes[best][0] - 1) / shapes[best][0], (N + shapes[best][1] - 1) / shapes[best][1], 1);
         if (best == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
         else if (best == 1) hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
