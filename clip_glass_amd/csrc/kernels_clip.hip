@@ -174,84 +174,98 @@ __global__ __launch_bounds__(256) void attention_kernel(const half_t* qkv, int L
 //   and V^T goes to LDS once per pair with its keys permuted to match (144-byte rows: conflict-free 16-byte reads);
 //   P is split hi + lo * 2^-11 in fp16 so the product keeps the fp32 softmax (fp16 x fp16 products are exact in the fp32
 //   accumulator: the scores themselves are the scalar kernel's up to summation order).
+// NKB = key (and query) blocks of 32: 2 for L <= 64 — two (image, head) pairs per workgroup, two waves each; 3 for L <= 96 (round 4: the text
+// tower's 77 tokens ran on the scalar kernel above, 111 us per layer) — one pair per workgroup, waves 0..2 own 32 queries each, wave 3
+// only helps staging V^T.
+template <int NKB>
 __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t* qkv, int L, int heads, int n_pairs, int causal,
                                                              half_t* out) {
-    constexpr int VROW = 144;
-    __shared__ __attribute__((aligned(16))) char vts[2][64 * VROW];
+    constexpr int PP = NKB == 2 ? 2 : 1;                // pairs per workgroup
+    constexpr int WP = 4 / PP;                          // waves per pair
+    constexpr int VROW = NKB * 64 + 16;                 // bytes per V^T row: 32 NKB keys + pad (144 / 208: conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) char vts[PP][64 * VROW];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
-    const int pair = blockIdx.x * 2 + (wave >> 1), qb = wave & 1;
+    const int pair = blockIdx.x * PP + wave / WP, qb = wave % WP;
     const int pc = min(pair, n_pairs - 1);
     const int img = pc / heads, h = pc - img * heads, D = heads * 64;
     const half_t* base = qkv + (long long)img * L * 3 * D + h * 64;
     const long long ts = 3LL * D;                       // token stride
     const int query = qb * 32 + lr;
-    h8 qf[4], kf[2][4], vv[4];
-    {
+    const bool qwave = qb < NKB;                        // (NKB = 3: the fourth wave has no queries)
+    h8 qf[4], kf[NKB][4];
+    if (qwave) {
         const half_t* qp = base + min(query, L - 1) * ts + kh * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const h8*)(qp + kk * 16);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             const half_t* kp = base + min(kb * 32 + lr, L - 1) * ts + D + kh * 8;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) kf[kb][kk] = *(const h8*)(kp + kk * 16);
         }
     }
-    const int pt = t & 127;                             // thread within the pair
+    constexpr int TP = 64 * WP;                         // threads of a pair
+    constexpr int NV = NKB * 32 * 8 / TP;               // V vectors per thread (4 / 3)
+    const int pt = t % TP;                              // thread within the pair
+    h8 vv[NV];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = pt + 128 * u, tok = e >> 3, d8 = e & 7;
+    for (int u = 0; u < NV; ++u) {
+        const int e = pt + TP * u, tok = e >> 3, d8 = e & 7;
         vv[u] = *(const h8*)(base + min(tok, L - 1) * ts + 2 * D + d8 * 8);
     }
-    char* vt = vts[wave >> 1];
+    char* vt = vts[wave / WP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = pt + 128 * u, tok = e >> 3, d8 = e & 7;
+    for (int u = 0; u < NV; ++u) {
+        const int e = pt + TP * u, tok = e >> 3, d8 = e & 7;
         // key tok = kb*32 + 8g + 4kh' + q sits at K position (kb*2 + (g>>1))*16 + kh'*8 + (g&1)*4 + q of its row
         const int r = tok & 31, g = r >> 3;
         const int pos = ((tok >> 5) * 2 + (g >> 1)) * 16 + ((r >> 2) & 1) * 8 + (g & 1) * 4 + (r & 3);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *(half_t*)(vt + (d8 * 8 + j) * VROW + pos * 2) = tok < L ? vv[u][j] : (half_t)0.f;
     }
-    f16x s[2];
+    f16x s[NKB];
+    float inv = 0.f;
+    if (qwave) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) s[kb] = mfma32(kf[kb][kk], qf[kk], s[kb]);
+            for (int kk = 0; kk < 4; ++kk) s[kb] = mfma32(kf[kb][kk], qf[kk], s[kb]);
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float v = s[kb][r] * 0.125f;                // hd^-0.5, hd = 64
+                if (key >= L || (causal && key > query)) v = -INFINITY;
+                s[kb][r] = v;
+                m = fmaxf(m, v);
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float z = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e2 = __expf(s[kb][r] - m);
+                s[kb][r] = e2;
+                z += e2;
+            }
+        z += __shfl_xor(z, 32);
+        inv = 1.f / z;
     }
-    float m = -INFINITY;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            float v = s[kb][r] * 0.125f;                // hd^-0.5, hd = 64
-            if (key >= L || (causal && key > query)) v = -INFINITY;
-            s[kb][r] = v;
-            m = fmaxf(m, v);
-        }
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float z = 0.f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e2 = __expf(s[kb][r] - m);
-            s[kb][r] = e2;
-            z += e2;
-        }
-    z += __shfl_xor(z, 32);
-    const float inv = 1.f / z;
-    __syncthreads();                                    // V^T of both pairs is in place
+    __syncthreads();                                    // V^T of the workgroup's pairs is in place
+    if (!qwave) return;
     f16x o[2], ol[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[db][r] = 0.f; ol[db][r] = 0.f; }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 2 * NKB; ++ks) {
         h8 ph, pl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -286,7 +300,12 @@ void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, in
     static const bool no_mfma = getenv("GLASS_NO_ATTN_MFMA") != nullptr;   // A/B knob
     if (L <= 64 && !no_mfma) {
         const int n_pairs = n_img * heads;
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3((n_pairs + 1) / 2), dim3(256), 0, st, qkv, L, heads, n_pairs, causal, out);
+        hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3((n_pairs + 1) / 2), dim3(256), 0, st, qkv, L, heads, n_pairs, causal, out);
+        return;
+    }
+    if (L <= 96 && !no_mfma) {          // the text tower's context (77)
+        const int n_pairs = n_img * heads;
+        hipLaunchKernelGGL(attention_mfma_kernel<3>, dim3(n_pairs), dim3(256), 0, st, qkv, L, heads, n_pairs, causal, out);
         return;
     }
     const size_t lds = (size_t)(3 * L * 65 + L * (L + 1)) * sizeof(float);
