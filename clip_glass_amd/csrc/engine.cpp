@@ -179,12 +179,18 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
 }
 
 static void gpt2_work_free(glass_engine* e);
+static void text_work_free(glass_engine* e) {
+    auto& w = e->twork;
+    hipFree(w.d_tok); hipFree(w.d_rows); hipFree(w.x); hipFree(w.cls); hipFree(w.feat); hipFree(w.ln16); hipFree(w.qkv); hipFree(w.att); hipFree(w.hid);
+    w = glass_engine::TextWork();
+}
 extern "C" void glass_engine_destroy(glass_engine* e) {
     if (!e) return;
     hipSetDevice(e->cfg.device);
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_d) hipStreamSynchronize(e->stream_d);
     gpt2_work_free(e);
+    text_work_free(e);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_pinned) hipHostFree(e->h_pinned);
     for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -1492,27 +1498,34 @@ extern "C" int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, 
         }
         eot[n] = best;
     }
-    int* d_tok = nullptr;
-    float *x = nullptr, *cls = nullptr, *feat = nullptr;
-    half_t *ln16 = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
-    auto cleanup = [&]() {
-        hipFree(d_tok); hipFree(x); hipFree(cls); hipFree(feat); hipFree(ln16); hipFree(qkv); hipFree(att); hipFree(hid);
-    };
-    hipError_t err = hipMalloc(&d_tok, (size_t)M * sizeof(int));
-    if (err == hipSuccess) err = hipMalloc(&x, (size_t)M * W * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&cls, (size_t)n_texts * W * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&feat, (size_t)n_texts * E * sizeof(float));
-    if (err == hipSuccess) err = hipMalloc(&ln16, (size_t)M * W * sizeof(half_t));
-    if (err == hipSuccess) err = hipMalloc(&qkv, (size_t)M * 3 * W * sizeof(half_t));
-    if (err == hipSuccess) err = hipMalloc(&att, (size_t)M * W * sizeof(half_t));
-    if (err == hipSuccess) err = hipMalloc(&hid, (size_t)M * 4 * W * sizeof(half_t));
-    if (err != hipSuccess) {
-        cleanup();
-        glass_set_error(std::string("encode_text: hipMalloc failed: ") + hipGetErrorString(err));
-        return GLASS_ERR_NOMEM;
+    auto& tw = e->twork;
+    auto cleanup = [&]() { text_work_free(e); };
+    hipError_t err = hipSuccess;
+    if (tw.n_texts != n_texts) {          // (re)build the workspace for this batch size
+        text_work_free(e);
+        err = hipMalloc(&tw.d_tok, (size_t)M * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&tw.d_rows, (size_t)n_texts * sizeof(int));
+        if (err == hipSuccess) err = hipMalloc(&tw.x, (size_t)M * W * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&tw.cls, (size_t)n_texts * W * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&tw.feat, (size_t)n_texts * E * sizeof(float));
+        if (err == hipSuccess) err = hipMalloc(&tw.ln16, (size_t)M * W * sizeof(half_t));
+        if (err == hipSuccess) err = hipMalloc(&tw.qkv, (size_t)M * 3 * W * sizeof(half_t));
+        if (err == hipSuccess) err = hipMalloc(&tw.att, (size_t)M * W * sizeof(half_t));
+        if (err == hipSuccess) err = hipMalloc(&tw.hid, (size_t)M * 4 * W * sizeof(half_t));
+        if (err != hipSuccess) {
+            cleanup();
+            glass_set_error(std::string("encode_text: hipMalloc failed: ") + hipGetErrorString(err));
+            return GLASS_ERR_NOMEM;
+        }
+        tw.n_texts = n_texts;
     }
+    int* d_tok = tw.d_tok;
+    float *x = tw.x, *cls = tw.cls, *feat = tw.feat;
+    half_t *ln16 = tw.ln16, *qkv = tw.qkv, *att = tw.att, *hid = tw.hid;
+    for (int n = 0; n < n_texts; ++n) eot[n] += n * ctx;          // row of each text's EOT token in x
     hipStream_t st = e->stream;
     hipMemcpyAsync(d_tok, tokens, (size_t)M * sizeof(int), hipMemcpyHostToDevice, st);
+    hipMemcpyAsync(tw.d_rows, eot.data(), (size_t)n_texts * sizeof(int), hipMemcpyHostToDevice, st);
     launch_embed_text(d_tok, e->t_tok, e->t_pos, M, ctx, W, x, st);
     GemmParams g;
     for (auto& b : e->tblk) {
@@ -1532,14 +1545,14 @@ extern "C" int glass_engine_encode_text(glass_engine* e, const int32_t* tokens, 
         g.a = hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = x; g.ldo = W; g.cand_rows = ctx;
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
     }
-    for (int n = 0; n < n_texts; ++n)   // ln_final on the EOT row of each text only (row-wise op)
-        launch_layernorm(x + ((size_t)n * ctx + eot[n]) * W, W, 1, W, e->t_lnf_g, e->t_lnf_b, nullptr, cls + (size_t)n * W, st);
+    // ln_final on the EOT row of each text only (row-wise op): one launch over the gathered rows (round 4: it was one launch per text)
+    launch_layernorm_rows(x, tw.d_rows, n_texts, W, e->t_lnf_g, e->t_lnf_b, cls, st);
     launch_dense(cls, W, n_texts, W, e->t_proj, E, nullptr, feat, E, 0, 0, nullptr, 0, st);
     err = hipMemcpyAsync(out_feat, feat, (size_t)n_texts * E * sizeof(float), hipMemcpyDeviceToHost, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err == hipSuccess) err = hipGetLastError();
-    cleanup();
     if (err != hipSuccess) {
+        cleanup();
         glass_set_error(std::string("encode_text failed: ") + hipGetErrorString(err));
         return GLASS_ERR_HIP;
     }

@@ -149,6 +149,12 @@ struct glass_engine {
     // text tower (optional)
     std::vector<ClipBlock> tblk;
     float *t_tok = nullptr, *t_pos = nullptr, *t_lnf_g = nullptr, *t_lnf_b = nullptr, *t_proj = nullptr;
+    struct TextWork {      // encode_text's activations, kept between calls of the same size (eight hipMalloc / hipFree pairs per call otherwise)
+        int n_texts = 0;
+        int *d_tok = nullptr, *d_rows = nullptr;
+        float *x = nullptr, *cls = nullptr, *feat = nullptr;
+        half_t *ln16 = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    } twork;
     int t_width = 0, t_ctx = 0, t_vocab = 0;
     float* d_target = nullptr;
 

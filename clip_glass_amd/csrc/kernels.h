@@ -91,6 +91,7 @@ void launch_embed_text(const int* tokens, const float* tok_emb, const float* pos
                        hipStream_t st);
 void launch_layernorm(const float* x, long long row_stride, int M, int D, const float* g, const float* b,
                       half_t* out16, float* out32, hipStream_t st);
+void launch_layernorm_rows(const float* x, const int* rows, int M, int D, const float* g, const float* b, float* out32, hipStream_t st);
 void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,
                       hipStream_t st);
 void launch_cosine(const float* feat, const float* target, int P, int D, float* sim, hipStream_t st);

@@ -97,6 +97,17 @@ void launch_layernorm(const float* x, long long row_stride, int M, int D, const 
                        out32);
 }
 
+// LayerNorm of gathered rows: out[m] = LN(x[rows[m]]) (the text tower's ln_final on each text's EOT row, clip/model.py:316-318)
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* x, const int* rows, int M, int D, const float* g, const float* b, float* o32) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* xr = x + (long long)rows[m] * D;
+    ln_row([&](int i) { return xr[i]; }, D, g, b, nullptr, o32 + (long long)m * D);
+}
+void launch_layernorm_rows(const float* x, const int* rows, int M, int D, const float* g, const float* b, float* out32, hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, rows, M, D, g, b, out32);
+}
+
 // nn.MultiheadAttention forward for one (image, head) per workgroup: softmax(q k^T / sqrt(hd) [+causal]) v.
 // qkv: [n_img*L][3*heads*hd] fp16 (q | k | v), out: [n_img*L][heads*hd] fp16.  hd == 64.
 __global__ __launch_bounds__(256) void attention_kernel(const half_t* qkv, int L, int heads, int causal,
