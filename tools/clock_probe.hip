@@ -30,7 +30,7 @@ int main() {
         chain<<<256, 768>>>(100000, 0.001f, sink, rec);
         hipDeviceSynchronize();
         hipMemcpy(h, rec, 16, hipMemcpyDeviceToHost);
-        printf("long launch : %llu shader ticks in %.1f us -> %.0f MHz; %.1f cycles per MFMA (3 waves per SIMD)\n", h[0], h[1] / 100.0, h[0] / (h[1] / 100.0),
+        printf("long launch : %llu shader ticks in %.1f us -> %.0f MHz; %.1f ticks per MFMA and wave\n", h[0], h[1] / 100.0, h[0] / (h[1] / 100.0),
                (double)h[0] / 100000);
     }
     for (int rep = 0; rep < 2; ++rep) {

@@ -111,6 +111,8 @@ int main() {
     run<4, 4>("4 ds_read_b128 / 4 MFMA, 3 w/SIMD", 768);
     run_f32<4>("fp32 32x32x2, regs, 1 wave/SIMD", 256);
     run_f32<4>("fp32 32x32x2, regs, 2 waves/SIMD", 512);
+    run_f32<4>("fp32 32x32x2, regs, 3 waves/SIMD", 768);
+    run_f32<4>("fp32 32x32x2, regs, 4 waves/SIMD", 1024);
     run_f32<2>("fp32 32x32x2, 2 accumulators, 1 w", 256);
     run_f32<1>("fp32 32x32x2, 1 accumulator, 1 w", 256);
     return 0;
