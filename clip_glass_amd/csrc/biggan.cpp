@@ -432,7 +432,7 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
         // round 4: the LAST block's conv_3 + skip, the final bn - relu, conv_to_rgb[:3] and tanh in one kernel (bg_tail.hip): the
         // 128-channel full-resolution map between them never exists.  Not when that block's output was asked for as a tap; A/B knob
         // GLASS_BG_NO_TAIL.
-        static const bool no_tail = getenv("GLASS_BG_NO_TAIL") != nullptr;
+        static const bool no_tail = glass_knob("GLASS_BG_NO_TAIL") != nullptr;
         if (i + 1 == g.blocks.size() && !no_tail && e->bg_tap != (int)i && ro == g.R &&
             bg_tail_supported(ro, b.mid, b.cout, b.cin, b.up, g.rgb_cpad)) {
             BgTailParams tp;
@@ -467,7 +467,7 @@ int glass_biggan_chunk(glass_engine* e, int c0, int B, float* y) {
         // round 4: tanh(channels 0..2) straight from the conv's accumulators as planar fp32 — the 32-channel fp16 map (1.07 GB at 512 px,
         // P = 64) and the pass that re-read it are gone; A/B knob GLASS_BG_NO_RGB_FUSE.  (Small test geometries the instance does not
         // take keep the two-pass form.)
-        static const bool no_rgb_fuse = getenv("GLASS_BG_NO_RGB_FUSE") != nullptr;
+        static const bool no_rgb_fuse = glass_knob("GLASS_BG_NO_RGB_FUSE") != nullptr;
         BgConv qd = q;
         qd.rgb_tanh = y;
         qd.dry = true;

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void bg_attn_split_vec_kernel(const half_t* __
 void launch_bg_attn_split(const half_t* T, int B, int H, int W, int c8, int c2, half_t* theta, half_t* phi, half_t* gT,
                           hipStream_t st) {
     const int hw = H * W, hq = hw / 4;
-    static const bool scalar_only = getenv("GLASS_BG_SPLIT_SCALAR") != nullptr;      // A/B knob
+    static const bool scalar_only = glass_knob("GLASS_BG_SPLIT_SCALAR") != nullptr;      // A/B knob
     if (!scalar_only && c8 % 8 == 0 && c2 % 64 == 0 && hq % 32 == 0 && W % 2 == 0) {
         const int nb_theta = (int)(((long long)hw * (c8 >> 3) + 255) / 256), nb_phi = (int)(((long long)hq * (c8 >> 3) + 255) / 256);
         const int nb_g = (hq / 32) * (c2 >> 6);

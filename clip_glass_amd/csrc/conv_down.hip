@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_down_kernel(DownParams p, int til
 }
 
 bool conv_down_supported(int R, int Cin, int Cout) {
-    static const bool off = getenv("GLASS_NO_DOWN") != nullptr;   // A/B knob
+    static const bool off = glass_knob("GLASS_NO_DOWN") != nullptr;   // A/B knob
     return !off && glass_lds_fits(LDS_BYTES) && R % 64 == 0 && R >= 64 && Cin == CIN && Cout == NT && (long long)R * R * Cin < (1LL << 31);
 }
 
@@ -331,7 +331,7 @@ const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1
     DownParams p;
     p.h = h; p.xs = xs; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
     p.trace = nullptr;
-    static const bool row_walk = getenv("GLASS_ROW_WALK") != nullptr;
+    static const bool row_walk = glass_knob("GLASS_ROW_WALK") != nullptr;
     p.row_walk = row_walk ? 1 : 0;
     const char* trace_path = nullptr;
 #ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): per-phase shader-clock timestamps of workgroup 0; synchronises, single engine only
@@ -343,10 +343,10 @@ const char* launch_conv_down(const half_t* h, const half_t* xs, const half_t* w1
     const long long tiles = (long long)B * tiles_x * tiles_y;
     if (tiles >= (1LL << 30)) return nullptr;
     static DevOnce once;
-    if (once.first()) {
+    once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_down_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_down_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
+    });
     const int slots = glass_cu_count() * 2;
     const int per_block = (int)((tiles + slots - 1) / slots);
     const int grid = (int)((tiles + per_block - 1) / per_block);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
 
 // cap_a / cap_c: scratch capacity PER CANDIDATE (halfs of A, floats of C); the buffers hold p.B candidates
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
-    static const bool off = getenv("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
+    static const bool off = glass_knob("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
     if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
     if (p.pre_shift && !p.sn) return nullptr;
     if (p.xs_out || p.post_scale16) return nullptr;   // by-products / output transforms this path does not implement: refuse, never ignore
@@ -113,7 +113,7 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
     // split-K (round 3): a 4 x 4 / 8 x 8 grid per candidate is 16 / 64 rows — at 64 candidates the product has 64 / 256 tiles walking
     // 72 K steps each.  S slices (a function of the per-candidate geometry only, like every choice here) of raw sums, added in a fixed
     // order by the finishing pass; the scratch holds them while S x grid x Neff fits its per-candidate capacity.
-    static const bool no_split = getenv("GLASS_CONV_GEMM_NO_SPLIT") != nullptr;   // A/B knob
+    static const bool no_split = glass_knob("GLASS_CONV_GEMM_NO_SPLIT") != nullptr;   // A/B knob
     int S = 1;
     if (!no_split && p.KS == 3) {
         const int px = p.Hc * p.Wc;

@@ -564,13 +564,6 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
         if (TRGB && t < 6 * (NT / 8)) *(h8*)(smem + G::OFF_T + t * 16) = t6v;
         if (has_next && p.sn16 && t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = nsty;
         __syncthreads();
-        if (p.no_tstore == 3) {          // timing experiment (GLASS_GLDS_DBG=3): K loop only, results are garbage
-            if (acc[0][0][0] == 12345.678f) p.y[0] = (half_t)1.f;
-            if (!has_next) break;
-            id = nid;
-            cur = nxt;
-            continue;
-        }
         const int rcs = p.res_cs ? p.res_cs : p.Cout;
         const ActK ak = act_consts(p.act, p.out_scale);
         f16x rgb;
@@ -639,7 +632,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             for (int k = 0; k < 4; ++k) {           // 2 rows x 32 px x four 16-byte pieces of this 32-channel slice
                 const int v = lane + 64 * k, i = v >> 7, pix = (v >> 2) & 31, piece = v & 3;
                 half_t* dst = p.y + (((long long)b * p.Ho + oyb + i) * p.Wo + tx0 + pix) * p.Cout + n0 + j * 32 + piece * 8;
-                if (p.no_tstore != 2) *(h8*)dst = *(const h8*)(Os + (i * 32 + pix) * OP + piece * 16);   // (GLASS_GLDS_DBG=2: no global stores)
+                *(h8*)dst = *(const h8*)(Os + (i * 32 + pix) * OP + piece * 16);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -664,22 +657,22 @@ template <int TW, bool TRGB = false>
 static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const char* name) {
     using G = Geo<TW>;
     static DevOnce once;                       // (one per template instance)
-    if (once.first()) (void)hipFuncSetAttribute((const void*)conv_glds_kernel<TW, TRGB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)conv_glds_kernel<TW, TRGB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); });
     const int tiles_x = p.Wc / TW, tiles_y = p.Hc / G::TH;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
     const int PT8 = (PT + 7) / 8 * 8;
-    static const bool no_persist = getenv("GLASS_NO_GLDS_PERSIST") != nullptr;   // A/B knob: one work item per workgroup
+    static const bool no_persist = glass_knob("GLASS_NO_GLDS_PERSIST") != nullptr;   // A/B knob: one work item per workgroup
     const int n_cu = glass_cu_count() - glass_cu_count() % 8;       // a workgroup keeps its XCD (id % 8) across items
     static DevOnce once_p;
-    if (once_p.first()) {
+    once_p.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_gldsp_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<32>::LDS_BYTES);
-    }
+    });
     // (>= 2 work items per CU at the NOMINAL population, common.h: this branch also decides whether the blur-down by-product exists,
     // so it must be a function of the layer geometry only)
     const long long work_nominal = (long long)GLASS_NOMINAL_POP * tiles_x * tiles_y * NTn;
@@ -705,9 +698,7 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
 
 const char* launch_conv_glds(const ConvParams& p0, hipStream_t st, bool force) {
     ConvParams p = p0;
-    static const int dbg = getenv("GLASS_GLDS_DBG") ? atoi(getenv("GLASS_GLDS_DBG")) : 0;    // timing experiments only (wrong results)
-    if (dbg) p.no_tstore = dbg;
-    static const bool on = getenv("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
+    static const bool on = glass_knob("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
     if (!glass_lds_fits(Geo<32>::LDS_BYTES) || !glass_lds_fits(Geo<16>::LDS_BYTES)) return nullptr;
     if ((!on && !force) || p.up || (p.xs_out && (p.sn || p.trgb_yout || p.Wc % 32 != 0)) || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
 // what this tile shape gives; a bigger tile does not fit 160 KB of LDS / 256 registers.
 
 const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
-    static const bool off = getenv("GLASS_NO_S2DMA") != nullptr;      // A/B knob: the register-staged conv_tiled<3,2,4,128,skip> instead
+    static const bool off = glass_knob("GLASS_NO_S2DMA") != nullptr;      // A/B knob: the register-staged conv_tiled<3,2,4,128,skip> instead
     if ((off && !force) || !p.skip_x || !p.skip_w || p.KS != 3 || p.stride != 2 || p.pad != 0 || p.up || p.y32 || !p.y) return nullptr;
     if (p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.in_up || p.xs_out || p.trgb_yout || p.post_scale16 || p.rgb_y) return nullptr;
     if (p.Neff != p.Cout || p.Neff % NT != 0 || p.Neff > MAX_N || p.Cin % 32 != 0 || p.Hc % TH != 0 || p.Wc % 32 != 0) return nullptr;
@@ -396,13 +396,13 @@ const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
     const int grid = n_work < n_cu ? n_work : n_cu;                     // (n_work is a multiple of 8)
     if (p.dry_run) return "conv_s2_kernel";
     static DevOnce once;
-    if (once.first()) {
+    once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #ifdef GLASS_DEV_TRACE
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
 #endif
         (void)hipFuncSetAttribute((const void*)conv_s2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
+    });
 #ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps to a file; synchronises, single engine only
     if (const char* tp = getenv("GLASS_S2_TRACE")) {          // dev tool: traced instance, stamps to a file
         unsigned long long* dtr = nullptr;
@@ -428,7 +428,7 @@ const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
         return "conv_s2_kernel<trace>";
     }
 #endif
-    static const bool no_il = getenv("GLASS_S2_NO_IL") != nullptr;     // A/B knob: every DMA of a stage issued before its MFMAs
+    static const bool no_il = glass_knob("GLASS_S2_NO_IL") != nullptr;     // A/B knob: every DMA of a stage issued before its MFMAs
     if (no_il) {
         hipLaunchKernelGGL((conv_s2_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
         return "conv_s2_kernel<noil>";

@@ -446,16 +446,16 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
 
 static int stream_slots() {
     static DevOnce once;
-    if (once.first()) {
+    once.run([&] {
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)conv_stream_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    }
+    });
     return glass_cu_count() * 3;      // 168 VGPRs, 51.5 KB of LDS: three workgroups per CU
 }
 
 bool conv_stream_applies(const ConvParams& p) {
-    static const bool off = getenv("GLASS_NO_STREAM") != nullptr;   // experiment knob
+    static const bool off = glass_knob("GLASS_NO_STREAM") != nullptr;   // experiment knob
     const bool trgb = p.trgb_yout != nullptr;
     if (!glass_lds_fits(LDS_BYTES)) return false;
     if (off || p.up || p.xs_out || p.y32 || (!p.y && !trgb) || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return false;
@@ -475,7 +475,7 @@ bool conv_stream_applies(const ConvParams& p) {
 const char* launch_conv_stream(const ConvParams& p0, hipStream_t st) {
     if (!conv_stream_applies(p0)) return nullptr;
     ConvParams p = p0;
-    static const bool row_walk = getenv("GLASS_ROW_WALK") != nullptr;      // A/B knob: round 2's row-major tile walk
+    static const bool row_walk = glass_knob("GLASS_ROW_WALK") != nullptr;      // A/B knob: round 2's row-major tile walk
     // measured (same box, column vs row walk): <torgb> 1821 vs 1844 us, conv_down 1762 vs 1823 us, <fromrgb> 2593 vs 2530 us — the
     // planar fp32 image the fromRGB form reads is friendlier to the row-major walk
     p.row_walk = (row_walk || p.rgb_y) ? 1 : 0;

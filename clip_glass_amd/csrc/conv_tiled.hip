@@ -578,9 +578,11 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
     constexpr int LDS = (LDS_K > LDS_O ? LDS_K : LDS_O) + 3 * NT * 4 + (TRGB ? 64 * NT : 0);
     if (!glass_lds_fits(LDS)) return nullptr;
     static DevOnce once;                       // (one per template instance)
-    if (once.first() && LDS > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (LDS > 64 * 1024)
+        once.run([&] {
+            (void)hipFuncSetAttribute((const void*)conv_tiled_kernel<KS, S, TH, NT, PERSIST, TRGB, SKIP, XS, SPL, B2, DEEP, TR>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        });
     const int tiles_x = p.Wc / 32, tiles_y = p.Hc / TH;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Neff / NT;
@@ -607,10 +609,10 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
 
 const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
-    static const bool no_ts = getenv("GLASS_NO_TSTORE") != nullptr;   // experiment knob
+    static const bool no_ts = glass_knob("GLASS_NO_TSTORE") != nullptr;   // experiment knob
     if (no_ts) p.no_tstore = 1;
     // A/B knob GLASS_DEEP: 0 = round 2's one-stage prefetch distance, 1 = patch three stages ahead, 2 = + two weight register sets (stride 2)
-    static const int deep_on = getenv("GLASS_DEEP") ? atoi(getenv("GLASS_DEEP")) : 1;
+    static const int deep_on = glass_knob("GLASS_DEEP") ? atoi(glass_knob("GLASS_DEEP")) : 1;
     if (p.rgb_tanh_out) {   // planar tanh(channels 0..2) from the accumulators: the one-n-tile 3x3 instance's fast path only
         if (p.y32 || p.trgb_yout || p.xs_out || p.up || p.KS != 3 || p.stride != 1 || p.pad != 1 || p.no_tstore || p.Neff != 32 || p.Cout != 32 ||
             p.Hc % 8 != 0 || p.Wc % 32 != 0 || p.Cin % 32 != 0 || (p.sn && !p.sn16) || (p.pre_shift && !p.pre_shift16) || p.res || p.noise ||
@@ -641,11 +643,11 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     const int KS = p.KS, S = p.stride;
     if (KS == 3 && S == 1 && p.pad == 1) {
-        static const int th4 = getenv("GLASS_TH4") ? atoi(getenv("GLASS_TH4")) : 0;   // experiment knob
-        static const bool nt64 = getenv("GLASS_NT64") != nullptr;   // experiment knob
+        static const int th4 = glass_knob("GLASS_TH4") ? atoi(glass_knob("GLASS_TH4")) : 0;   // experiment knob
+        static const bool nt64 = glass_knob("GLASS_NT64") != nullptr;   // experiment knob
         if (!nt64 && p.Neff % 128 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 128>(p, st, "conv_tiled_kernel<3,1,8,128>");
         if ((th4 & 2) && p.Neff % 64 == 0 && p.Hc % 4 == 0) return launch_inst<3, 1, 4, 64>(p, st, "conv_tiled_kernel<3,1,4,64>");
-        static const bool persist = getenv("GLASS_PERSIST") != nullptr;   // measured slower (more live registers -> lower occupancy): off
+        static const bool persist = glass_knob("GLASS_PERSIST") != nullptr;   // measured slower (more live registers -> lower occupancy): off
         if (persist && p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64, true>(p, st, "conv_tiled_kernel<3,1,8,64,persist>");
         if (p.Neff % 64 == 0 && p.Hc % 8 == 0) return launch_inst<3, 1, 8, 64>(p, st, "conv_tiled_kernel<3,1,8,64>");
         // memory-bound, tiny K: small tiles = more workgroups per CU = more bytes in flight
@@ -665,7 +667,7 @@ const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
 #endif
         if (!tiled_trace)
             if (const char* k = launch_conv_s2(p, st)) return k;        // LDS-DMA ring kernel where its geometry applies
-        static const bool spl = getenv("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
+        static const bool spl = glass_knob("GLASS_NO_S2_SPLIT") == nullptr;  // 2 x 2 wave grid (A/B knob: GLASS_NO_S2_SPLIT=1 -> 4 x 1; measured -4.4 % on the four stride-2 layers)
         if (spl && deep_on == 2 && p.Neff % 128 == 0) return launch_inst<3, 2, 4, 128, false, false, true, false, true, true, true>(p, st, "conv_tiled_kernel<3,2,4,128,skip,spl,b2,deep>");
 #ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps of one mid-grid workgroup to a file; synchronises, single engine only
         if (const char* tp = getenv("GLASS_TILED_TRACE")) {      // dev tool: traced instance, stamps of one mid-grid workgroup to a file

@@ -157,11 +157,11 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     e->chunk = chunk;
     // two-stream overlap is worth +3 % throughput but stretches every co-running kernel ~2x, which makes
     // per-kernel profiles (rocprof, roofline) meaningless: opt-in (GLASS_OVERLAP=1 / glass_engine_set_overlap)
-    e->overlap = getenv("GLASS_OVERLAP") != nullptr;
+    e->overlap = glass_knob("GLASS_OVERLAP") != nullptr;
     // CLIP's image tower (short, latency-bound launches: 2.2 ms of a mostly idle GPU) on the second stream next to the
     // discriminator, which only shares the finished image with it
     // (default; GLASS_NO_CLIP_OVERLAP=1 / glass_engine_set_overlap(e, 0) put everything on one stream)
-    e->clip_overlap = getenv("GLASS_NO_CLIP_OVERLAP") == nullptr;
+    e->clip_overlap = glass_knob("GLASS_NO_CLIP_OVERLAP") == nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream_d, hipStreamNonBlocking);
     e->cur = e->stream;
@@ -567,7 +567,7 @@ static int alloc_buffers(glass_engine* e) {
             if ((rc = dev_alloc(e, &e->ws_a2, (size_t)(e->cap_a * P)))) return rc;
             if ((rc = dev_alloc(e, &e->ws_c2, (size_t)(e->cap_c * P)))) return rc;
         }
-    } else if (e->cfg.generator == GLASS_GEN_BIGGAN_DEEP && !getenv("GLASS_BG_NO_CONV_GEMM")) {
+    } else if (e->cfg.generator == GLASS_GEN_BIGGAN_DEEP && !glass_knob("GLASS_BG_NO_CONV_GEMM")) {
         // BigGAN-deep's 4 x 4 .. 16 x 16 layers (3 x 3 on ch * 4 = 512 channels, 1 x 1 up to ch * 16 outputs) on the same path (round 3:
         // they ran on conv_direct at 64 - 220 TFLOP/s); the walk over the population is chunked, so the scratch holds one chunk
         const int cmax = 4 * e->cfg.bg_ch;
@@ -583,8 +583,8 @@ static int alloc_buffers(glass_engine* e) {
         const bool fused_ok = g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in >= 16;
         const bool tiled_ok = !g.up && g.cin % 32 == 0 && g.cout % 32 == 0 && g.res_in % 32 == 0;
         g.welems = 9LL * g.cin * g.cout;
-        static const long long premod_kb = getenv("GLASS_PREMOD_MAX_KB") ? atoll(getenv("GLASS_PREMOD_MAX_KB")) : 500;   // A/B knob (round 3: the 256 -> 128 up-conv, 590 KB per sample, runs 4 % faster on the shared-weight image grid, and its consumer 5 % faster on the pre-styled output; 1200 was round 2's value)
-        g.premod = (fused_ok || tiled_ok) && g.welems * 2 <= (premod_kb << 10) && !getenv("GLASS_NO_PREMOD");
+        static const long long premod_kb = glass_knob("GLASS_PREMOD_MAX_KB") ? atoll(glass_knob("GLASS_PREMOD_MAX_KB")) : 500;   // A/B knob (round 3: the 256 -> 128 up-conv, 590 KB per sample, runs 4 % faster on the shared-weight image grid, and its consumer 5 % faster on the pre-styled output; 1200 was round 2's value)
+        g.premod = (fused_ok || tiled_ok) && g.welems * 2 <= (premod_kb << 10) && !glass_knob("GLASS_NO_PREMOD");
         if (g.premod && (rc = dev_alloc(e, &g.wm, (size_t)P * g.welems))) return rc;
     }
     if (c.noise_mode != 0) {
@@ -858,7 +858,7 @@ static void run_styles(glass_engine* e, int P) {
     const int L = c.latent_size;
     {
         Prof pr(e, "mapping", 2.0 * P * L * L * c.mapping_layers, 4.0 * L * L * c.mapping_layers);
-        static const bool no_fused = getenv("GLASS_NO_MAP_FUSE") != nullptr;   // A/B knob
+        static const bool no_fused = glass_knob("GLASS_NO_MAP_FUSE") != nullptr;   // A/B knob
         if (no_fused || c.mapping_layers < 1 ||
             !launch_mapping_fused(e->d_z, e->d_w0, P, L, 1e-8f, e->map_wt.data(), e->map_b.data(), c.mapping_layers, e->cur)) {
             launch_pixelnorm(e->d_z, e->d_w0, P, L, 1e-8f, e->cur);
@@ -908,15 +908,15 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     char tag[48];
     int gi = b_lo == 0 ? 0 : 1 + 2 * (b_lo - 1);
     int yi = 0;
-    static const bool no_trgb_fuse = getenv("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
-    static const bool no_trgb_mid = getenv("GLASS_NO_TRGB_MID") != nullptr;
-    static const bool no_pre_style = getenv("GLASS_NO_PRE_STYLE") != nullptr;
+    static const bool no_trgb_fuse = glass_knob("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
+    static const bool no_trgb_mid = glass_knob("GLASS_NO_TRGB_MID") != nullptr;
+    static const bool no_pre_style = glass_knob("GLASS_NO_PRE_STYLE") != nullptr;
     // A block's SEPARATE toRGB pass (blocks wider than 128 channels) is a bandwidth-bound read of the map the next block's
     // up-conv reads too; in the two-stream mode it runs on the second stream next to that (issue-bound) up-conv.  The main
     // stream joins before the next block's last conv: that launch overwrites the map toRGB reads and consumes its skip image.
     // Measured (round 3): 33.77 vs 33.74 ms per population — no gain, co-running kernels share the CUs they would have had
     // anyway (the late-CLIP variant, GLASS_CLIP_LATE, loses 0.3 ms).  Opt-in knob only.
-    static const bool rgb_side_on = getenv("GLASS_TRGB_SIDE") != nullptr;
+    static const bool rgb_side_on = glass_knob("GLASS_TRGB_SIDE") != nullptr;
     const bool rgb_side = e->clip_overlap && e->cur == e->stream && rgb_side_on;
     bool rgb_pending = false;
     for (int b = b_lo; b < b_hi; ++b) {
@@ -1097,7 +1097,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         }
         const bool fuse_down = conv_down_supported(r, d.cin, d.cout);   // blur + skip + stride-2 conv + merge as one kernel
         if (i == 0 && rgb_y) {
-            static const bool no_fuse = getenv("GLASS_NO_FRGB_FUSE") != nullptr;   // A/B knob
+            static const bool no_fuse = glass_knob("GLASS_NO_FRGB_FUSE") != nullptr;   // A/B knob
             ConvParams q = p;
             q.rgb_y = rgb_y; q.rgb_w = e->d_frgb_w; q.rgb_b = e->d_frgb_b;
             q.rgb_x_out = fuse_down ? nullptr : X;       // the fused second half reads the down-sampled skip input only
@@ -1118,7 +1118,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         if (i == 0 && rgb_y && !fused_rgb) run_fromrgb(e, B, rgb_y, X);
         snprintf(tag, sizeof tag, "D.conv0.r%d.%dx%d", r, d.cin, d.cin);
         if (!fused_rgb) {
-            static const bool no_xs = getenv("GLASS_NO_XS_FUSE") != nullptr;   // A/B knob
+            static const bool no_xs = glass_knob("GLASS_NO_XS_FUSE") != nullptr;   // A/B knob
             ConvParams qx = p;
             qx.xs_out = XS; qx.dry_run = 1;
             if (!no_xs && !have_xs && (launch_conv_glds(qx, e->cur) || launch_conv_tiled(qx, e->cur))) {   // the skip branch's blur-down rides in the first conv
@@ -1158,7 +1158,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         snprintf(tag, sizeof tag, "D.conv1.r%d.%dx%d", r2, d.cin, d.cout);
         const double f1 = 2.0 * B * (double)r2 * r2 * 9 * d.cin * d.cout, fs = 2.0 * B * (double)r2 * r2 * d.cin * d.cout;
         {   // skip branch as extra K stages of the stride-2 conv (conv_tiled<3,2,4,N,skip>) where that kernel applies
-            static const bool no_skip_fuse = getenv("GLASS_NO_SKIP_FUSE") != nullptr;   // A/B knob
+            static const bool no_skip_fuse = glass_knob("GLASS_NO_SKIP_FUSE") != nullptr;   // A/B knob
             ConvParams qs = q;
             qs.skip_x = XS; qs.skip_w = d.wskip; qs.dry_run = 1;
             if (!no_skip_fuse && launch_conv_tiled(qs, e->cur)) {
@@ -1211,7 +1211,7 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     g.out32 = e->d_dh; g.ldo = CL; g.cand_rows = 1;
     // M = P rows, K = 16 CL = 8192: the 128 x 64 tiles are 8 workgroups walking 128 K steps each (97 us for 0.5 GFLOP).  Split K into 16
     // slices (blockIdx.z) with raw partial sums, finished in a fixed order with bias + activation: 128+ workgroups, 8 steps each.
-    static const bool no_d0_split = getenv("GLASS_NO_DENSE0_SPLIT") != nullptr;   // A/B knob
+    static const bool no_d0_split = glass_knob("GLASS_NO_DENSE0_SPLIT") != nullptr;   // A/B knob
     const int S0 = 16;
     if (!no_d0_split && e->d_dh_part && g.K % (S0 * 64) == 0 && P <= e->cfg.max_pop) {
         GemmParams q = g;
@@ -1333,7 +1333,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     }
     // device-generated noise planes depend on nothing but (seed, generation, minibatch, layer): their 17 short launches run on the
     // second stream next to the mapping network / style / demodulation chain instead of ahead of it
-    static const bool no_noise_ov = getenv("GLASS_NO_NOISE_OVERLAP") != nullptr;      // A/B knob, read once
+    static const bool no_noise_ov = glass_knob("GLASS_NO_NOISE_OVERLAP") != nullptr;      // A/B knob, read once
     const bool noise_ov = e->clip_overlap && c.noise_mode == 1 && !no_noise_ov;
     int rc;
     if (noise_ov) {
@@ -1381,7 +1381,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
     }
     const bool overlap = e->overlap && out_F;
     const bool clip_ov = e->clip_overlap && !overlap && out_F && want_d;
-    static const bool clip_late = getenv("GLASS_CLIP_LATE") != nullptr;      // A/B knob
+    static const bool clip_late = glass_knob("GLASS_CLIP_LATE") != nullptr;      // A/B knob
     hipStream_t sd = overlap ? e->stream_d : e->stream;
     for (int c0 = 0, k = 0; c0 < P; c0 += e->chunk, ++k) {
         const int B = std::min(e->chunk, P - c0);
@@ -1661,22 +1661,22 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     // product from row statistics, products with complete outputs (no split-K reduce launch) except the MLP's second one, whose
     // split-K slices of the residual products finished together with the residual add and the next statistics: 9 launches per layer
     // instead of 11 (complete-output products — 72 / 24 / 96 workgroups walking three chunks each — were 21 us against 9 + 4: dropped)
-    static const bool no_fuse = getenv("GLASS_GPT2_NO_FUSE") != nullptr;
+    static const bool no_fuse = glass_knob("GLASS_GPT2_NO_FUSE") != nullptr;
     // (the launcher's own shape conditions, asked through the launcher's predicate: a product it refuses returns 0 slices and nothing written)
     const bool fuse_ok = !no_fuse && gemm_f32_step_supported(P, D, D, true) && gemm_f32_step_supported(P, 4 * D, 4 * D, false);
     bool step_refused = false;
-    static const bool no_attn_step = getenv("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
+    static const bool no_attn_step = glass_knob("GLASS_GPT2_NO_ATTN_STEP") != nullptr;   // A/B knob
     // fused step tail (round 4): the pick also writes the NEXT step's embedding + first LayerNorm statistics and advances the state — a step
     // starts at layer 0's qkv product; the first step's embedding is one eager launch after the prefill.  A/B knob: GLASS_GPT2_NO_TAIL.
-    static const bool no_head = getenv("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
-    static const bool no_tail = getenv("GLASS_GPT2_NO_TAIL") != nullptr;
+    static const bool no_head = glass_knob("GLASS_GPT2_NO_HEAD") != nullptr;   // A/B knob: generic product + two-stage arg-max
+    static const bool no_tail = glass_knob("GLASS_GPT2_NO_TAIL") != nullptr;
     const bool tail_fused = fuse_ok && !no_head && !no_tail && D <= 1024 && gpt2_head_supported(P, V, D, D);
     auto pass = [&](int nd, int past, const int* step_state) {
         const int M = P * nd;
         // round 4 (gpt2.hip): the attention output product and the MLP's first product in the complete-output form — no slices, so no
         // gpt2_finalize / splitk_reduce launch behind them: 6 launches per layer instead of 8.  (The qkv product and the MLP's second one
         // stay split: complete, they were 12-14 us against 9.5 and 34 against 12 + 5.)  A/B knob: GLASS_GPT2_NO_ROWBLK.
-        static const bool no_rowblk = getenv("GLASS_GPT2_NO_ROWBLK") != nullptr;
+        static const bool no_rowblk = glass_knob("GLASS_GPT2_NO_ROWBLK") != nullptr;
         const bool rowblk = step_state && fuse_ok && !no_rowblk && D % 32 == 0 && D / 32 <= 24 &&
                             gemm_f32_rowblk_supported(P, D, D, D, false, true) && gemm_f32_rowblk_supported(P, 4 * D, D, D, true, false);
         if (step_state) { if (!tail_fused) launch_gpt2_embed_step(w.d_gen, step_state, P, e->g_wte, e->g_wpe, D, w.x, st, fuse_ok ? w.stats : nullptr); }
@@ -1755,7 +1755,7 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     if (length > 1) {
         // the 29 single-token steps are the same ~190 launches each: capture one step once, replay it (launch latency, not work,
         // is what the un-graphed loop spent its time on)
-        static const bool no_graph = getenv("GLASS_GPT2_NO_GRAPH") != nullptr;   // A/B knob
+        static const bool no_graph = glass_knob("GLASS_GPT2_NO_GRAPH") != nullptr;   // A/B knob
         if (!w.exec && !no_graph) {
             err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
             if (err == hipSuccess) {

@@ -144,7 +144,7 @@ const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     const unsigned gx = (unsigned)((p.M + 127) / 128), gz = p.batch > 1 ? p.batch : 1;
     // 128-wide n tiles under-fill the chip on the N = 768 CLIP linears (25 x 6 = 150 workgroups for 256 CUs): take 64-wide
     // tiles whenever the 128-wide grid has fewer workgroups than CUs
-    static const bool wide_only = getenv("GLASS_GEMM_BN128") != nullptr;   // A/B knob
+    static const bool wide_only = glass_knob("GLASS_GEMM_BN128") != nullptr;   // A/B knob
     // (evaluated at the nominal population where the caller says how M / the batch scale with it — the instances are bit-identical
     // per output element, the rule just never looks at the launch size)
     const long long gx_n = p.cand_rows ? ((long long)p.cand_rows * GLASS_NOMINAL_POP + 127) / 128 : gx;

@@ -748,7 +748,7 @@ int launch_gemm_f32_step(const float* A, const float* W, const float* bias, floa
     // {1, 2, 4, 6} take the one with the most workgroups that still fit the chip in ONE round (nb * S <= CUs: 288 workgroups on 256 CUs
     // ran the MLP products at 14 us against 9.7 us for the 216 of the qkv product), fewest slices among equals; a product too small to
     // fill the CUs either way takes the most slices its scratch allows.
-    static const bool old_rule = getenv("GLASS_GPT2_OLD_SPLIT") != nullptr;     // A/B knob
+    static const bool old_rule = glass_knob("GLASS_GPT2_OLD_SPLIT") != nullptr;     // A/B knob
     const int C = K / GS_KC, n_cu = glass_cu_count();
     int S = 0, NK = 1;
     if (!old_rule && nb < 1024) {
@@ -789,7 +789,7 @@ void launch_gpt2_reduce(const float* part, int S, const float* bias, float* out,
 // `part`: scratch for split-K partial sums (nullable = never split); sized by the caller for GPT2_SPLITK_MAX slices of M x N.
 void launch_gemm_f32(const float* A, const float* W, const float* bias, float* out, int M, int N, int K, int lda, int ldo,
                      int mode, hipStream_t st, float* part, size_t part_elems, bool prefill) {
-    static const bool no_stream = getenv("GLASS_GPT2_NO_STREAM") != nullptr;      // A/B knob: round 2's gemm_f32_kernel<64,64> for the steps
+    static const bool no_stream = glass_knob("GLASS_GPT2_NO_STREAM") != nullptr;      // A/B knob: round 2's gemm_f32_kernel<64,64> for the steps
     if (!prefill && M <= 64 && K % GS_KC == 0 && lda % 4 == 0 && !no_stream) {
         // a workgroup per 32 weight rows; global K split S (small: the partial sums are traffic) x NK K parts inside the workgroup so
         // that a wave's share is one or two 64-deep chunks; the vocabulary projection (1571 workgroups) is not split globally
@@ -830,7 +830,7 @@ void launch_gemm_f32(const float* A, const float* W, const float* bias, float* o
         // of LDS and 32 VGPRs, so a CU holds many of them and their barriers / LDS round trips overlap; the larger tiles run one
         // workgroup (one wave per SIMD) per CU.  Every shape adds an element's k terms in the same order: the choice never changes a value.
         static const int shapes[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-        static const int force = getenv("GLASS_GPT2_TILE") ? atoi(getenv("GLASS_GPT2_TILE")) : -1;   // A/B knob
+        static const int force = glass_knob("GLASS_GPT2_TILE") ? atoi(glass_knob("GLASS_GPT2_TILE")) : -1;   // A/B knob
         const int best = (force >= 0 && force < 3) ? force : 2;
         const dim3 g((M + shapes[best][0] - 1) / shapes[best][0], (N + shapes[best][1] - 1) / shapes[best][1], 1);
         if (best == 0) hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), g, dim3(256), 0, st, A, W, bias, out, M, N, K, lda, ldo, mode, part);
@@ -907,7 +907,7 @@ void launch_gpt2_attention(const float* qkv, float* kc, float* vc, int P, int nd
     const int ns = past_dev ? Tmax : past + nd;      // graph replay: LDS sized for the longest history
     const size_t lds = (size_t)(nd * 65 + 2 * ns * 65 + nd * (ns + 1)) * sizeof(float);
     static DevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)gpt2_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)gpt2_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(gpt2_attention_kernel, dim3(P * heads), dim3(256), lds, st, qkv, kc, vc, nd, past, Tmax, heads, out, past_dev);
 }
 

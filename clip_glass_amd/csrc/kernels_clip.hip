@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t* qkv, 
 void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, int causal, half_t* out,
                       hipStream_t st) {
     (void)hd;  // 64 (asserted by the engine)
-    static const bool no_mfma = getenv("GLASS_NO_ATTN_MFMA") != nullptr;   // A/B knob
+    static const bool no_mfma = glass_knob("GLASS_NO_ATTN_MFMA") != nullptr;   // A/B knob
     if (L <= 64 && !no_mfma) {
         const int n_pairs = n_img * heads;
         hipLaunchKernelGGL(attention_mfma_kernel<2>, dim3((n_pairs + 1) / 2), dim3(256), 0, st, qkv, L, heads, n_pairs, causal, out);
@@ -321,8 +321,8 @@ void launch_attention(const half_t* qkv, int n_img, int L, int heads, int hd, in
     }
     const size_t lds = (size_t)(3 * L * 65 + L * (L + 1)) * sizeof(float);
     static DevOnce once;
-    if (once.first())   // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS
-        (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // text tower (L = 77) needs > 64 KiB of the 160 KiB LDS
+    once.run([&] { (void)hipFuncSetAttribute((const void*)attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     hipLaunchKernelGGL(attention_kernel, dim3(n_img * heads), dim3(256), lds, st, qkv, L, heads, causal, out);
 }
 

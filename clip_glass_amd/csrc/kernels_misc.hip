@@ -233,10 +233,10 @@ bool launch_mapping_fused(const float* z, float* out, int P, int L, float eps, c
     for (int i = 0; i < n_layers; ++i) { d.wt[i] = wt[i]; d.b[i] = b[i]; }
     const size_t lds = (size_t)(4 + 64) * L * sizeof(float);
     static DevOnce once;
-    if (once.first()) {
+    once.run([&] {
         (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 256 * sizeof(float)));
         (void)hipFuncSetAttribute((const void*)mapping_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 + 64) * 512 * sizeof(float)));
-    }
+    });
     if (L == 256) hipLaunchKernelGGL(mapping_fused_kernel<1>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
     else hipLaunchKernelGGL(mapping_fused_kernel<2>, dim3((P + 3) / 4), dim3(1024), lds, st, z, out, P, eps, d);
     return true;
@@ -812,7 +812,7 @@ __global__ __launch_bounds__(1024) void mbstd_vec_kernel(const half_t* x, int hw
 void launch_mbstd(const half_t* x, int B, int hw, int C, int Cpad, int batch_size, int group, float eps,
                   half_t* out, hipStream_t st) {
     const int nsub = batch_size / group;
-    static const bool scalar = getenv("GLASS_MBSTD_SCALAR") != nullptr;      // A/B knob
+    static const bool scalar = glass_knob("GLASS_MBSTD_SCALAR") != nullptr;      // A/B knob
     if ((C & 7) == 0 && (Cpad & 7) == 0 && group <= 8 && !scalar) {
         hipLaunchKernelGGL(mbstd_vec_kernel, dim3((B / batch_size) * nsub), dim3(1024), 0, st, x, hw, C, Cpad, batch_size, group, eps, out);
         return;

@@ -774,13 +774,13 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     constexpr int LDS = U_LDS;
     if (!glass_lds_fits(LDS)) return nullptr;                 // (the caller falls through to upfir_kernel / the folded form)
     static DevOnce once;
-    if (once.first()) {
+    once.run([&] {
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)upfir2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    }
-    static const int env_ng = getenv("GLASS_UPFIR_NG") ? atoi(getenv("GLASS_UPFIR_NG")) : 0;      // A/B knobs
-    static const int env_s = getenv("GLASS_UPFIR_S") ? atoi(getenv("GLASS_UPFIR_S")) : 0;
-    static const bool no_grid = getenv("GLASS_UPFIR_NO_GRID") != nullptr;
+    });
+    static const int env_ng = glass_knob("GLASS_UPFIR_NG") ? atoi(glass_knob("GLASS_UPFIR_NG")) : 0;      // A/B knobs
+    static const int env_s = glass_knob("GLASS_UPFIR_S") ? atoi(glass_knob("GLASS_UPFIR_S")) : 0;
+    static const bool no_grid = glass_knob("GLASS_UPFIR_NO_GRID") != nullptr;
     UpGeo g;
     g.NTn = p.Cout / 32;
     // candidates per virtual grid: per-sample weights -> one (its tiles share a weight set); shared weights -> up to 8 x 8
@@ -818,7 +818,7 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     g.ngroups = ng;
     // measured (round 3, same box): prefetch on 2298 / 1476 / 1217 us vs off 2183 / 1496 / 1235 us on the r1024 / r512 / r256
     // layers — a wash, as round 2's persistent-prefetch experiment was: the step is issue-bound, not latency-bound.  Off.
-    static const bool prefetch = getenv("GLASS_UPFIR_PREFETCH") != nullptr;
+    static const bool prefetch = glass_knob("GLASS_UPFIR_PREFETCH") != nullptr;
     g.prefetch = prefetch ? 1 : 0;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
     // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
@@ -836,7 +836,7 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     if (!p.up || !p.w_up || p.y32 || !p.y || p.res || (p.sn && !p.sn16)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.KS != 3) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;
-    static const bool v1 = getenv("GLASS_UPFIR_V1") != nullptr;      // A/B knob: round 2's one-tile-per-workgroup kernel
+    static const bool v1 = glass_knob("GLASS_UPFIR_V1") != nullptr;      // A/B knob: round 2's one-tile-per-workgroup kernel
     if (!v1) {
         const char* k = launch_upfir2(p, st);
         if (k) return k;
@@ -847,7 +847,7 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     constexpr int LDS = 64 * 1024;  // T tile (16*64*32*2 B); staging (31.5 KB) lives inside it
     if (!glass_lds_fits(LDS)) return nullptr;
     static DevOnce once;
-    if (once.first()) (void)hipFuncSetAttribute((const void*)upfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    once.run([&] { (void)hipFuncSetAttribute((const void*)upfir_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
     const int tiles_y = (p.Ho + 11) / 12, tiles_x = (p.Wo + 59) / 60;
     const int PT = p.B * tiles_x * tiles_y;
     const int NTn = p.Cout / 32;

@@ -6,7 +6,7 @@ os.environ["GLASS_D0_TRACE"] = path
 if os.path.exists(path):
     os.remove(path)
 from clip_glass_amd import engine
-engine.load_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "clip_glass_amd", "libglass_trace.so"))   # conv_d0.o built with -DGLASS_DEV_TRACE
+engine.load_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lib", "libglass_trace.so"))   # conv_d0.o built with -DGLASS_DEV_TRACE
 from clip_glass_amd import ops, synth
 B, R = 16, 1024
 rs = np.random.RandomState(0)
