@@ -152,11 +152,14 @@ def run_legs(args):
     JSON results, trimmed to what identifies and prices the leg."""
     import subprocess
     legs = {}
+    # the children must not inherit the parent's detail-dump path (the biggan512 leg would write its own table over the headline's;
+    # ADVICE r4) — and a leg that hangs may cost the driver's line 4 minutes, not 10
+    child_env = {k: v for k, v in os.environ.items() if k not in ("GLASS_BENCH_DETAIL", "GLASS_BENCH_UNIFORM_POP", "GLASS_BENCH_FULLPROF")}
     for name, extra in (("biggan512", ["--warmup", "2", "--no-cpu-baseline"]), ("gpt2", ["--warmup", "1"])):
         t0 = time.time()
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.leg_steps), "--no-legs"] + extra,
-                               capture_output=True, text=True, timeout=600)
+                               capture_output=True, text=True, timeout=240, env=child_env)
             line = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
             if r.returncode != 0 or not line:
                 legs[name] = dict(error=(r.stderr or r.stdout)[-400:], returncode=r.returncode)

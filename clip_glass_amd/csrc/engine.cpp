@@ -190,6 +190,8 @@ extern "C" void glass_engine_destroy(glass_engine* e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     if (e->stream_d) hipStreamSynchronize(e->stream_d);
     gpt2_work_free(e);
+    std::swap(e->gwork, e->gwork_alt);
+    gpt2_work_free(e);
     text_work_free(e);
     for (void* p : e->allocs) hipFree(p);
     if (e->h_pinned) hipHostFree(e->h_pinned);
@@ -1627,7 +1629,10 @@ static int gpt2_decode_group(glass_engine* e, const int32_t* context, int32_t P,
     const size_t rows = (size_t)P * nctx;
     auto& w = e->gwork;
     hipStream_t st = e->stream;
-    if (w.P != P || w.nctx != nctx || w.length != length) {      // (re)build the workspace for this geometry
+    auto fits = [&](const glass_engine::Gpt2Work& g) { return g.P == P && g.nctx == nctx && g.length == length; };
+    if (!fits(w)) std::swap(e->gwork, e->gwork_alt);   // second slot: a ragged population alternates between a 64-row group and its
+                                                       // remainder — each keeps its buffers and its captured step graph
+    if (!fits(w)) {      // (re)build the workspace for this geometry
         gpt2_work_free(e);
         // split-K scratch for the single-token steps (M = P <= 64 rows: each weight is streamed once per step, so the number
         // of workgroups pulling on HBM is what matters), device-resident tokens and step state {past length, step index}

@@ -145,7 +145,7 @@ struct glass_engine {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         float last_ms = 0.f;      // device time of the last decode (hipEvents around the passes)
-    } gwork;
+    } gwork, gwork_alt;       // current workspace + the previous geometry's (glass_engine_gpt2_decode's row groups: 64 rows and a remainder)
     // text tower (optional)
     std::vector<ClipBlock> tblk;
     float *t_tok = nullptr, *t_pos = nullptr, *t_lnf_g = nullptr, *t_lnf_b = nullptr, *t_proj = nullptr;

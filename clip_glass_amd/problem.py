@@ -5,6 +5,8 @@ Same class name, constructor and `_evaluate(x, out)` contract: `out["F"]` float3
 class is pymoo's Problem when pymoo is importable (0.4.2.1 layout first), otherwise a
 minimal stand-in with the attributes pymoo reads.
 """
+import warnings
+
 import numpy as np
 
 try:
@@ -45,7 +47,14 @@ class GenerationProblem(Problem):
             # (run.py:65) can shrink generation 0 below pop_size, which kills the reference run.  SURVEY 8a note 8: pad instead.
             # The last row is repeated up to the next minibatch boundary and the padding rows' fitness is dropped; the real rows of
             # that last minibatch share its noise plane / minibatch-stddev group with the copies.
-            x = np.concatenate([x, np.repeat(x[-1:], (-P) % self.config.batch_size, axis=0)])
+            pad = (-P) % self.config.batch_size
+            if not getattr(self, "_pad_warned", False):
+                self._pad_warned = True
+                warnings.warn("GenerationProblem._evaluate: population of %d rows is not a multiple of batch_size %d; padding with %d "
+                              "copies of the last row (the reference asserts here, models.py:112).  The real rows of the last "
+                              "minibatch share its minibatch-stddev group with the copies, so their hinge objective is not "
+                              "comparable with a full minibatch's." % (P, self.config.batch_size, pad), RuntimeWarning, stacklevel=2)
+            x = np.concatenate([x, np.repeat(x[-1:], pad, axis=0)])
         ls.set_from_population(x)
         F = self.generator.evaluate(ls)[:P]
         if self.config.problem_args["n_obj"] == 2 and self.config.use_discriminator:

@@ -143,7 +143,8 @@ def test_generation_problem_contract_with_stub_generator(monkeypatch):
         # P % batch_size != 0: the reference asserts (models.py:112); SURVEY 8a note 8 asks to pad instead (pymoo's duplicate
         # elimination can shrink generation 0): the last row is repeated to the minibatch boundary, its copies' F dropped
         out6 = {}
-        p._evaluate(x[:6], out6)
+        with pytest.warns(RuntimeWarning, match="not a multiple of batch_size"):      # said once, not silently
+            p._evaluate(x[:6], out6)
         assert out6["F"].shape == ((6, 2) if n_obj == 2 else (6,)) and out6["G"].shape == (6,)
         np.testing.assert_array_equal(out6["F"], out["F"][:6])
 
