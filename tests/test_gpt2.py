@@ -72,6 +72,27 @@ def test_parse_out_semantics():
     assert gpt2_ref.parse_out([[1, 2, 3] + list(range(100, 140))], 3, 99, dec, 10)[0] == "100 101 10"
 
 
+def _assert_token_parity(tag, got, ora, margins, n_ctx):
+    """Greedy decode is an INDEX result: the bar is token-for-token equality with the oracle on every row.  The one
+    escape is a near-tie: a row may leave the oracle's sequence only at a step where the oracle's own top-2 logit margin is below
+    1e-4 (fp32 summation order decides such a pick); every such row is logged with its step and margin.  Returns the excepted rows."""
+    assert got.shape == ora.shape
+    excepted = []
+    for p in range(got.shape[0]):
+        same = got[p] == ora[p]
+        if same.all():
+            continue
+        first = int(np.argmin(same)) - n_ctx
+        assert first >= 0, "%s: row %d differs inside its context" % (tag, p)
+        m = float(margins[p, first])
+        diag("[gpt2] %s NEAR-TIE EXCEPTION: row %d leaves the oracle at step %d, oracle top-2 margin %.3e" % (tag, p, first, m))
+        assert m < 1e-4, "%s: row %d diverged at step %d with a clear margin %.3e" % (tag, p, first, m)
+        excepted.append(p)
+    diag("[gpt2] %s: %d/%d rows token-identical to the oracle, %d near-tie exception(s); min top-2 margin over all steps %.3e"
+         % (tag, got.shape[0] - len(excepted), got.shape[0], len(excepted), float(np.min(margins))))
+    return excepted
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("geo,P,n_ctx,length", [(MINI, 8, 23, 10), (dict(n_embd=256, n_layer=3, vocab=5000), 16, 23, 30)])
 def test_engine_gpt2_decode_matches_oracle(geo, P, n_ctx, length):
@@ -90,17 +111,7 @@ def test_engine_gpt2_decode_matches_oracle(geo, P, n_ctx, length):
     detail = {}
     ora = gpt2_ref.sample_sequence(_t(sd), torch.tensor(ctx), length, detail=detail).numpy()
     assert got.shape == ora.shape and np.array_equal(got[:, :n_ctx], ctx)
-    same = got == ora
-    n_seq_ok = int(same.all(axis=1).sum())
-    diag("[gpt2] decode P=%d L=%d: %d/%d sequences token-identical; min top-2 logit margin %.3e"
-         % (P, length, n_seq_ok, P, float(detail["margins"].min())))
-    # a sequence may only diverge at a step whose top-2 margin is within fp32 summation noise (near-tie)
-    for p in range(P):
-        if not same[p].all():
-            first = int(np.argmin(same[p])) - n_ctx
-            m = float(detail["margins"][p, first])
-            assert m < 1e-4, "sequence %d diverged at step %d with a clear margin %.3e" % (p, first, m)
-    assert n_seq_ok >= P - 1
+    _assert_token_parity("decode P=%d L=%d" % (P, length), got, ora, detail["margins"].numpy() if hasattr(detail["margins"], "numpy") else detail["margins"], n_ctx)
 
 
 @pytest.mark.gpu
@@ -193,17 +204,21 @@ def test_img2txt_generation_problem_end_to_end(assets, tmp_path):
     # decode parity of the same population against the oracle (tokens, then texts through parse_out)
     sdg = synth.make_state(synth.gpt2_spec(128, 2, gvocab), 2)
     ctx = np.concatenate([x, np.tile(prob.generator.model.init_tokens, (8, 1))], axis=1)
-    ora = gpt2_ref.sample_sequence(_t(sdg), torch.tensor(ctx), cfg.max_tokens_len).numpy()
+    dd = {}
+    ora = gpt2_ref.sample_sequence(_t(sdg), torch.tensor(ctx), cfg.max_tokens_len, detail=dd).numpy()
     bpe_dec = prob.generator.model.enc
     ref_texts = gpt2_ref.parse_out(ora, cfg.dim_z, bpe_dec.eot, bpe_dec.decode, cfg.max_text_len)
-    assert sum(a == b for a, b in zip(texts, ref_texts)) >= 7
+    got_tok = prob.generator.engine.gpt2_decode(ctx, cfg.max_tokens_len)
+    mg = dd["margins"].numpy() if hasattr(dd["margins"], "numpy") else dd["margins"]
+    excepted = _assert_token_parity("img2txt (%s vocab)" % assets, got_tok, ora, mg, ctx.shape[1])
+    assert all(a == b for i, (a, b) in enumerate(zip(texts, ref_texts)) if i not in excepted)
     prob.generator.engine.close()
 
 
 @pytest.mark.gpu
 def test_gpt2_small_full_size_decode_and_timing():
     """GPT-2 small at true size (12 x 768, vocab 50257): P=64 x 23-token context, 30 greedy steps (config C5 shape);
-    token parity on a subset against the oracle + wall time of the device decode."""
+    token parity of ALL 64 rows against the oracle + wall time of the device decode."""
     import time
     import glass_models as M
     from clip_glass_amd.engine import Engine
@@ -221,16 +236,11 @@ def test_gpt2_small_full_size_decode_and_timing():
     e.close()
     t = time.time()
     detail = {}
-    ora = gpt2_ref.sample_sequence(_t(sd), torch.tensor(ctx[:8]), 30, detail=detail).numpy()
+    ora = gpt2_ref.sample_sequence(_t(sd), torch.tensor(ctx), 30, detail=detail).numpy()
     dto = time.time() - t
-    ok = int((got[:8] == ora).all(axis=1).sum())
-    diag("[gpt2] GPT-2 small P=64 x 30 steps: device %.3f s (%.0f candidates/s); oracle 8 candidates %.2f s; %d/8 sequences "
-         "token-identical, min margin %.2e" % (dt, 64 / dt, dto, ok, float(detail["margins"].min())))
-    for p in range(8):
-        if not (got[p] == ora[p]).all():
-            first = int(np.argmin(got[p] == ora[p])) - 23
-            assert float(detail["margins"][p, first]) < 1e-4
-    assert ok >= 7
+    diag("[gpt2] GPT-2 small P=64 x 30 steps: device %.3f s (%.0f candidates/s); oracle 64 candidates %.2f s" % (dt, 64 / dt, dto))
+    mg = detail["margins"].numpy() if hasattr(detail["margins"], "numpy") else detail["margins"]
+    _assert_token_parity("GPT-2 small P=64", got, ora, mg, 23)
 
 
 @pytest.mark.gpu
@@ -275,6 +285,10 @@ def test_engine_reproduces_reference_gpt2_golden():
     e.finalize()
     got = e.gpt2_decode(g["context"], 30)
     e.close()
-    ok = int((got == g["tokens"]).all(axis=1).sum())
-    diag("[gpt2] golden (reference sampler) %d/%d sequences token-identical" % (ok, got.shape[0]))
-    assert ok >= got.shape[0] - 1
+    # the fixture holds the reference sampler's tokens; the oracle reproduces them exactly (test_oracle_reproduces_... on the CPU) and
+    # supplies the per-step top-2 margins the near-tie escape needs
+    dd = {}
+    ora = gpt2_ref.sample_sequence(_t(sd), torch.tensor(g["context"]), 30, detail=dd).numpy()
+    assert np.array_equal(ora, g["tokens"])
+    mg = dd["margins"].numpy() if hasattr(dd["margins"], "numpy") else dd["margins"]
+    _assert_token_parity("golden (reference sampler)", got, g["tokens"], mg, g["context"].shape[1])

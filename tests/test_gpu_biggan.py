@@ -71,6 +71,45 @@ def test_biggan_512_two_candidates():
     _run_case("bg512", 2, 2)
 
 
+def test_biggan_512_full_population():
+    """BASELINE.json configs[2] at its real size: biggan-deep-512, pop = 64, batch_size = 8 (config.py:66) in ONE engine call —
+    the launch sizes bench.py's `biggan512` leg times.  BigGAN candidates are independent (no minibatch statistics at inference),
+    so the oracle scores 16 of the 64 rows (the first and the last minibatch: 2 x ~25 s of CPU instead of 8 x) and those rows of the
+    64-row launch must meet it: image, CLIP features, similarity within 1e-3 relative."""
+    name, P, bs = "bg512", 64, 8
+    c = M.BIGGAN_CONFIGS[name]
+    sd = M.make_biggan_state(name, 0)
+    x = synth.biggan_population(11, P, c["z_dim"], c["num_classes"])
+    rows = np.r_[0:8, 56:64]
+    detail = {}
+    fitness_ref.evaluate_biggan(_t(sd), x[rows], np.ones(c["clip"][5], np.float32), c["z_dim"], bs, 1.0, c["layers"],
+                                clip_size=c["clip"][4], detail=detail, attention_pos=c["attention_pos"], ch=c["ch"])
+    feats = detail["features"].numpy()
+    target = M.make_target(feats)
+    sim_o = torch.cosine_similarity(detail["features"], torch.tensor(target)[None]).numpy()
+    e = M.make_biggan_engine(name, sd, batch_size=bs, max_pop=P)
+    e.set_target(target)
+    Fe = e.evaluate(x)
+    det = e.details(P)
+    img = e.generate(x)
+    # the same rows scored as their own 8-row launches: rows do not depend on the launch they ride in
+    F_first, F_last = e.evaluate(x[:8]), e.evaluate(x[56:])
+    e.close()
+    assert Fe.shape == (P, 1) and np.isfinite(Fe).all()
+    ref_img = detail["image"].numpy()
+    rms = float(np.sqrt(((img[rows] - ref_img) ** 2).mean()))
+    rel = np.abs(det["sim"][rows] - sim_o) / np.abs(sim_o)
+    diag("[biggan] bg512 P=64 bs=8 one launch, rows 0-7 + 56-63 vs oracle: image rms err %.3e max %.3e; sim range [%.3f, %.3f] max rel err %.3e"
+         % (rms, np.abs(img[rows] - ref_img).max(), sim_o.min(), sim_o.max(), rel.max()))
+    assert rms < 2e-3, "image rms error %.3e" % rms
+    check("bg512 P=64 clip features", det["features"][rows], feats, 5e-3)
+    assert rel.max() < 1e-3, "CLIP similarity relative error %.3e > 1e-3" % rel.max()
+    np.testing.assert_allclose(Fe[:, 0], -det["sim"], rtol=0, atol=1e-7)
+    d_launch = float(np.abs(np.concatenate([F_first, F_last]) - Fe[rows]).max())
+    diag("[biggan] bg512 rows 0-7 / 56-63 as their own 8-row launches vs inside the 64-row launch: max |dF| %.3e" % d_launch)
+    assert d_launch <= 1e-5      # (same kernel instances at every launch size: expected 0)
+
+
 def test_biggan_512_eight_candidates_streaming_kernels():
     """P = 8 makes the 512^2 layers large enough (>= 4096 tiles) for conv_stream (nearest-up input addressing and the
     fused bn shift + relu epilogue), which the two-candidate case leaves to conv_tiled."""

@@ -323,12 +323,14 @@ def test_full_size_ffhq_full_population():
 
 
 def test_full_size_offset_shards():
-    """BASELINE.json configs[3] at the real architecture: ffhq-1024 G + D + CLIP ViT-B/32, P = 128 in ONE call against the two
-    64-row shard calls ranks 0 and 1 of a 2-GPU job make (first_minibatch = 0 and 16: the rank-1 shard reads noise planes 16-31 and
-    forms its own minibatch-stddev groups) — bitwise equal rows; rows 0-7 are the reference-generated fixture's population."""
+    """BASELINE.json configs[3] at the REAL architecture and the REAL population: ffhq-1024 G + D + CLIP ViT-B/32, P = 512 in ONE call
+    against the eight 64-row shard calls the ranks of an 8-GPU job make (first_minibatch = 0, 16, ..., 112: rank r reads noise planes
+    16 r .. 16 r + 15 and forms its own minibatch-stddev groups) — bitwise equal rows; rows 0-7 are the reference-generated fixture's
+    population, checked against the fixture in the whole call AND in shard 0."""
     import os
+    from clip_glass_amd.parallel import shard_bounds
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ffhq_modules.npz"))
-    name, P, bs = "ffhq", 128, 4
+    name, P, bs = "ffhq", 512, 4
     c = M.CONFIGS[name]
     Pg = int(g["P"])
     sd = M.make_state(name, int(g["seed"]))
@@ -337,12 +339,19 @@ def test_full_size_offset_shards():
     e.set_target(g["target"])
     gen = int(g["generation"])
     F_whole = e.evaluate(x, generation=gen)
-    rel = np.abs(-F_whole[:Pg, 0] - g["sim"]) / np.abs(g["sim"])
-    assert rel.max() < 1e-3
-    parts = [e.evaluate(x[lo:lo + 64], generation=gen, first_minibatch=lo // bs) for lo in (0, 64)]
-    diag("[e2e] ffhq P=128 one call vs two offset shards: max |dF| %.3e; rows 0-%d sim rel err vs fixture %.3e"
-         % (np.abs(np.concatenate(parts) - F_whole).max(), Pg - 1, rel.max()))
+    det = e.details(P)
+    bounds = shard_bounds(P, 8, bs)
+    assert bounds == [(64 * r, 64 * r + 64) for r in range(8)]
+    parts = [e.evaluate(x[lo:hi], generation=gen, first_minibatch=lo // bs) for lo, hi in bounds]
+    for tag, Fx in (("whole", F_whole), ("shard 0", parts[0])):
+        rel = np.abs(-Fx[:Pg, 0] - g["sim"]) / np.abs(g["sim"])
+        diag("[e2e] ffhq P=512 %s rows 0-%d vs reference fixture: sim rel err %.3e, hinge abs err %.3e"
+             % (tag, Pg - 1, rel.max(), np.abs(Fx[:Pg, 1] - g["hinge"]).max()))
+        assert rel.max() < 1e-3
+        check_logits("ffhq P=512 %s hinge rows 0-%d" % (tag, Pg - 1), Fx[:Pg, 1], g["hinge"], case="ffhq")
+    check_logits("ffhq P=512 D logits rows 0-%d" % (Pg - 1), det["dis"][:Pg], g["dis"], case="ffhq")
+    diag("[e2e] ffhq P=512 one call vs eight offset shards of 64: max |dF| %.3e" % np.abs(np.concatenate(parts) - F_whole).max())
     np.testing.assert_array_equal(np.concatenate(parts), F_whole)
-    # the rank-1 shard evaluated with the WRONG offset differs (its noise planes are the rank-0 ones): the offset is live
+    # a shard evaluated with the WRONG offset differs (its noise planes are another rank's): the offset is live
     assert np.abs(e.evaluate(x[64:128], generation=gen, first_minibatch=0) - parts[1]).max() > 1e-6
     e.close()
