@@ -30,12 +30,12 @@ def make_state(name, seed=0, with_d=True):
     return sd
 
 
-def make_engine(name, sd, *, batch_size=4, use_discriminator=True, max_pop=8, noise_mode=2, noise_seed=0, chunk=0):
+def make_engine(name, sd, *, batch_size=4, use_discriminator=True, max_pop=8, noise_mode=2, noise_seed=0, chunk=0, device=0):
     from clip_glass_amd.engine import Engine
     c = CONFIGS[name]
     e = Engine(c["channels"][::-1], latent_size=c["latent"], mapping_layers=c["mapping"], batch_size=batch_size,
                use_discriminator=use_discriminator, n_obj=2 if use_discriminator else 1, max_pop=max_pop,
-               chunk=chunk, clip=c["clip"], noise_mode=noise_mode, noise_seed=noise_seed)
+               chunk=chunk, clip=c["clip"], noise_mode=noise_mode, noise_seed=noise_seed, device=device)
     e.load_state(sd)
     e.finalize()
     return e

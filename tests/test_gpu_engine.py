@@ -355,3 +355,33 @@ def test_full_size_offset_shards():
     # a shard evaluated with the WRONG offset differs (its noise planes are another rank's): the offset is live
     assert np.abs(e.evaluate(x[64:128], generation=gen, first_minibatch=0) - parts[1]).max() > 1e-6
     e.close()
+
+
+def test_rccl_two_ranks_all_gather():
+    """The N > 1 product path on the REAL backend: two ranks, one GPU each, `nccl` (= RCCL) — shard scoring + the one all-gather of
+    `[P/N, n_obj]` (parallel.py) against the whole population on one GPU, bitwise.  RCCL refuses two ranks on one device, so this
+    runs on multi-GPU boxes only; the 1-GPU test boxes skip it WITH the reason (the gloo twin in tests/test_host.py and the offset-shard
+    tests above cover the same arithmetic there)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs >= 2 GPUs (this box has %d): RCCL cannot place two ranks on one device; covered on 1-GPU boxes by the "
+                    "gloo 2-rank tests and the bitwise offset-shard tests" % n)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tests", "rccl_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][-1])
+    diag("[e2e] RCCL 2-rank all-gather: %r" % out)
+    assert out["ok"] and out["backend"] == "nccl" and out["world"] == 2 and out["rows"] == 16
