@@ -88,61 +88,106 @@ def cpu_baseline(sd, cfg, target, pop=BATCH, budget_s=75.0):
 
 
 def bench_gpt2(args):
-    """BASELINE.json configs[4] (not the headline): GPT-2-small token-latent decode (20 latent + 3 prompt tokens, 30 greedy
-    steps, gpt2/sample.py:21-36) + CLIP text tower + cosine against an image feature, pop = 64, 1 GPU.  The host BPE
-    round trip between the two towers (detokenise / re-tokenise) needs the reference's vocabulary files, which are not on
-    the box: the decoded ids are mapped to CLIP ids by a fixed rule instead — same device work, said so in `config`."""
+    """BASELINE.json configs[4] (not the headline): the GPT2 img2txt config through `GenerationProblem._evaluate` — the path run.py
+    drives (problem.py:14-29 -> models.py:32-62 -> generator.py:52-59): GPT-2-small token-latent decode on the device (20 latent + 3
+    prompt tokens, 30 greedy steps, gpt2/sample.py:21-36), `parse_out` (ids -> text, cut at <|endoftext|> / 50 characters) and
+    `clip.tokenize` on the host, CLIP text tower + cosine against the image feature on the device; pop = 64, 1 GPU.  The reference's
+    vocabulary FILES are not on the box: BPE assets of the real sizes (50257 / 49408 ids) in the reference's formats are generated
+    (synth.write_bpe_assets), so the host stage is the real code on real-sized tables; its ms are reported separately."""
+    import tempfile
+    import types
     import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    from clip_glass_amd import config as gconfig
     from clip_glass_amd import synth
-    from clip_glass_amd.engine import Engine, device_info
+    from clip_glass_amd.engine import device_info
+    from clip_glass_amd.problem import GenerationProblem
     P = args.pop
     clipg = (768, 12, 12, 32, 224, 512)
-    sd = synth.make_state(synth.gpt2_spec(), 5)
-    sd.update(synth.make_state(synth.clip_visual_spec(*[clipg[i] for i in (0, 1, 3, 4, 5)]), 0))
-    sd.update(synth.make_state(synth.clip_text_spec(), 0))
-    sd.pop("clip.logit_scale", None)
-    eng = Engine([], latent_size=4, mapping_layers=0, batch_size=1, use_discriminator=False, n_obj=1, max_pop=P, clip=clipg, noise_mode=0)
-    eng.load_state(sd)
-    eng.finalize()
-    target = synth.normal(3, "imgfeat", (512,)).astype(np.float64)
+    tmp = tempfile.mkdtemp(prefix="glass_bpe_")
+    enc, voc, bpe = synth.write_bpe_assets(tmp)
+    cfg = types.SimpleNamespace(config="GPT2", device="cuda:0", target="unused")
+    vars(cfg).update(gconfig.get_config("GPT2"))
+    vars(cfg).update(weights="synthetic:5", clip_weights="synthetic:0", clip_geometry=clipg, clip_text_geometry=dict(width=512, layers=12),
+                     encoder=enc, vocab=voc, bpe_path=bpe, target_features=synth.normal(3, "imgfeat", (512,)), pop_size=P, max_pop=P)
+    prob = GenerationProblem(cfg)
+    gen = prob.generator
+    eng = gen.engine
+    assert len(gen.model.init_tokens) == 3, "the prompt must be 3 tokens (config.py:25 'the picture of')"
+    # stage clocks around the product's own methods (wall, host side); the device decode reports its hipEvent time itself
+    clock = dict(decode=0.0, parse=0.0, tokenize=0.0, text=0.0, dec_gpu_ms=0.0, tok_fail=0)
+
+    def timed(obj, name, key, after=None):
+        fn = getattr(obj, name)
+
+        def wrap(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            clock[key] += time.perf_counter() - t0
+            if after:
+                after()
+            return r
+        setattr(obj, name, wrap)
+    timed(gen.model, "decode_tokens", "decode", after=lambda: clock.__setitem__("dec_gpu_ms", clock["dec_gpu_ms"] + eng.last_gpu_ms()))
+    timed(gen.model, "parse_out", "parse")
+    timed(eng, "encode_text", "text")
+    tok_fn = gen.tokenizer.tokenize
+
+    def tok_wrap(texts):
+        t0 = time.perf_counter()
+        try:
+            return tok_fn(texts)
+        except Exception:
+            clock["tok_fail"] += 1          # generator.py:53-56: the whole population then scores 0 and the text tower is skipped
+            raise
+        finally:
+            clock["tokenize"] += time.perf_counter() - t0
+    gen.tokenizer.tokenize = tok_wrap
 
     def step(seed):
-        z = np.random.RandomState(seed).randint(0, 50257, size=(P, 20))
-        ctx = np.concatenate([z, np.tile([1169, 4286, 286], (P, 1))], axis=1)           # "the picture of" (config.py:25)
-        out = eng.gpt2_decode(ctx, 30)
-        dec_ms = eng.last_gpu_ms()
-        tok = np.zeros((P, 77), np.int64)
-        tok[:, 0] = 49406
-        tok[:, 1:31] = out[:, 23:] % 49406
-        tok[:, 31] = 49407
-        tf = eng.encode_text(tok).astype(np.float64)
-        sim = tf @ target / np.maximum(np.linalg.norm(tf, axis=1) * np.linalg.norm(target), 1e-8)
-        return -sim, dec_ms
+        x = np.random.RandomState(seed).randint(0, 50257, size=(P, 20))
+        out = {}
+        prob._evaluate(x, out)
+        return out["F"]
     for s in range(max(args.warmup, 1)):
         step(s)
     torch.cuda.synchronize()
+    for k in clock:
+        clock[k] = 0 if k == "tok_fail" else 0.0
     t0 = time.perf_counter()
-    dec_ms = 0.0
     for s in range(args.steps):
-        F, ms = step(100 + s)
-        dec_ms += ms
+        F = step(100 + s)
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert F.shape == (P,) and np.isfinite(F).all()
+    assert clock["tok_fail"] == 0, "clip.tokenize refused a decoded text: the timed steps skipped the text tower"
+    assert np.abs(F).max() > 0
+    dec_ms = clock["dec_gpu_ms"]
     # decode = weight streaming: every fp32 weight of the 12 blocks + the tied lm_head is read once per step
     n_w = 12 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 50257 * 768
     bytes_per_decode = 4.0 * n_w * 30
     gbs = bytes_per_decode * args.steps / (dec_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest_gpt2.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        traffic = tj.get("bytes_per_decode")
+        traffic_src = tj.get("source")
+    per = lambda k: clock[k] / args.steps * 1e3
     out = dict(metric="candidate token-latents scored/sec (GPT2 decode -> CLIP text score), GPT2 pop=%d" % P, value=P * args.steps / dt,
                unit="candidates/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="GPT2: GPT-2-small greedy decode (23-token context, 30 steps, fp32, KV cache, one hipGraph per single-"
-                                    "token step) + CLIP ViT-B/32 text tower + cosine, pop=%d; host BPE round trip replaced by a fixed id "
-                                    "mapping (no vocabulary files on the box)" % P, pop_per_gpu=P, device=device_info(0)["name"]),
+               config=dict(workload="GPT2: GenerationProblem._evaluate of the GPT2 img2txt config — GPT-2-small greedy decode (23-token "
+                                    "context, 30 steps, fp32, KV cache, one hipGraph per single-token step), parse_out + clip.tokenize "
+                                    "on the host (generated BPE tables of the real sizes, 50257 / 49408 ids), CLIP ViT-B/32 text tower "
+                                    "+ cosine, pop=%d" % P, pop_per_gpu=P, device=device_info(0)["name"]),
+               stage_ms=dict(decode_wall=per("decode"), decode_gpu=dec_ms / args.steps, parse_out_host=per("parse"),
+                             clip_tokenize_host=per("tokenize"), text_tower_wall=per("text"),
+                             other_host=(dt - clock["decode"] - clock["parse"] - clock["tokenize"] - clock["text"]) / args.steps * 1e3),
                gpu_active_s=dec_ms * 1e-3,      # device time of the decodes (hipEvents; the text tower's launches are not in it)
                roofline=dict(bound="hbm", kernel="gemm_f32_stream_kernel / gpt2_head_kernel (weight streaming, 30 steps)", achieved=gbs, peak=HBM_PEAK_GBS,
-                             unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=None, decode_ms_per_population=dec_ms / args.steps,
-                             algorithmic_bytes_per_decode=bytes_per_decode))
+                             unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                             decode_ms_per_population=dec_ms / args.steps, algorithmic_bytes_per_decode=bytes_per_decode))
     print(json.dumps(out))
     eng.close()
 
@@ -165,11 +210,11 @@ def run_legs(args):
                 legs[name] = dict(error=(r.stderr or r.stdout)[-400:], returncode=r.returncode)
                 continue
             d = json.loads(line[-1])
-            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "gpu_active_s")
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "gpu_active_s", "stage_ms")
             leg = {k: d[k] for k in keep if k in d}
             leg["config"] = d["config"]
             rf = d.get("roofline", {})
-            leg["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_ms",
+            leg["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "launches", "avg_ms",
                                                   "whole_pass_frac_of_mfma_peak", "whole_pass_tflops", "decode_ms_per_population",
                                                   "algorithmic_bytes_per_decode") if k in rf}
             leg["leg_wall_s"] = time.time() - t0

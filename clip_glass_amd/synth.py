@@ -360,3 +360,80 @@ def biggan_population(seed, pop, dim_z=128, num_classes=1000, p_class=5 / 1000):
     z = truncnorm.rvs(-2, 2, size=(pop, dim_z), random_state=rs).astype(np.float32)
     bits = rs.random_sample((pop, num_classes)) < p_class
     return np.concatenate([z.astype(np.float64), bits.astype(np.float64)], axis=1)
+
+
+# --------------------------------------------------------------------------
+# Synthetic BPE assets at the REAL vocabulary sizes (GPT-2: 50257 ids, CLIP: 49408 ids) in the reference's file formats
+# (gpt2/encoder.py:107-115 reads encoder.json + vocab.bpe, clip/simple_tokenizer.py:66-72 reads the gzipped merge list).
+# The reference's own data files are not on the GPU box; config C5's host stage (decode ids -> text -> CLIP ids) needs SOME
+# vocabulary of the right size and shape to be the real path: seeded merges over lower-case words, so decoded texts are plain
+# ASCII that clip.tokenize accepts.  Used by `bench.py --config gpt2` and tests/test_gpt2.py.
+def write_bpe_assets(out_dir, gpt2_vocab=50257, clip_vocab=49408, seed=0, init_text="the picture of"):
+    """Writes encoder.json, vocab.bpe, clip_bpe.txt.gz under out_dir; returns their paths.  GPT-2 ids: the 256 byte symbols, then
+    one id per merge, then <|endoftext|> (= gpt2_vocab - 1, config.py:28).  The words of `init_text` are single tokens (their merge
+    chains come first), so the decode context has the reference's length (20 latent + 3 prompt tokens, models.py:30,45-60)."""
+    import gzip
+    import json
+    import os
+    from .tokenizer import _byte_alphabet
+    b2c, order = _byte_alphabet()
+    sp = b2c[32]                                         # the byte alphabet's symbol for " " (U+0120)
+    rs = np.random.RandomState(seed + 7919)
+    letters = [chr(c) for c in range(97, 123)]
+
+    def grow(n_merges, chains, prefix_pool, suffix):
+        """n_merges unique merges (a, b) over lower-case letters.  Token classes: word-initial (GPT-2: sp + letters), letter-only,
+        word-final (CLIP: letters + '</w>').  Only tokens of <= 4 letters are merged further (the pools stay dense: no rejection
+        sampling on length), so no token exceeds 8 letters."""
+        nlet = lambda tok: len(tok.replace("</w>", "").replace(sp, ""))
+        merges, seen = [], set(letters) | set(prefix_pool)
+        mid, head = list(letters), list(prefix_pool)
+        tail = [c + suffix for c in letters] if suffix else []
+        seen |= set(tail)
+
+        def add(a, b):
+            tok = a + b
+            if tok in seen:
+                return False
+            seen.add(tok)
+            merges.append((a, b))
+            if nlet(tok) <= 4:
+                (head if tok.startswith(sp) else tail if suffix and tok.endswith(suffix) else mid).append(tok)
+            return True
+        for chain in chains:                             # words that must end up as ONE token: left-to-right merge chains
+            cur = chain[0]
+            for nxt in chain[1:]:
+                add(cur, nxt)
+                cur = cur + nxt
+        while len(merges) < n_merges:
+            kind = rs.randint(0, 3)
+            if kind == 0 and head:
+                add(head[rs.randint(len(head))], mid[rs.randint(len(mid))])
+            elif kind == 1 and tail:
+                add(mid[rs.randint(len(mid))], tail[rs.randint(len(tail))])
+            else:
+                add(mid[rs.randint(len(mid))], mid[rs.randint(len(mid))])
+        return merges
+
+    os.makedirs(out_dir, exist_ok=True)
+    # ---- GPT-2: words carry their leading space (sp + letters) ----
+    words = init_text.split(" ")
+    chains = []
+    for i, w in enumerate(words):
+        chains.append(([sp] if i else []) + list(w))
+    g_merges = grow(gpt2_vocab - 256 - 1, chains, [sp], None)
+    enc = {b2c[b]: i for i, b in enumerate(order)}
+    for a, b in g_merges:
+        enc[a + b] = len(enc)
+    enc["<|endoftext|>"] = len(enc)
+    assert len(enc) == gpt2_vocab
+    ej, vb, cb = os.path.join(out_dir, "encoder.json"), os.path.join(out_dir, "vocab.bpe"), os.path.join(out_dir, "clip_bpe.txt.gz")
+    with open(ej, "w") as f:
+        json.dump(enc, f)
+    with open(vb, "w", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(a + " " + b for a, b in g_merges) + "\n")
+    # ---- CLIP: 256 symbols + 256 word-final symbols + merges + 2 specials; words end in '</w>' ----
+    c_merges = grow(clip_vocab - 512 - 2, [], [], "</w>")
+    with gzip.open(cb, "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic\n" + "\n".join(a + " " + b for a, b in c_merges) + "\n")
+    return ej, vb, cb

@@ -63,6 +63,24 @@ def test_gpt2_bpe_known_answers():
         pass
 
 
+def test_generated_bpe_assets_have_the_real_sizes_and_round_trip(tmp_path):
+    """synth.write_bpe_assets: the vocabularies `bench.py --config gpt2` runs the host stage on where the reference's data files are
+    absent — 50257 GPT-2 ids (<|endoftext|> = 50256, config.py:28) and 49408 CLIP ids in the reference's file formats; the prompt is
+    3 tokens (models.py:30); text -> ids -> text round-trips; a decoded 30-token sample fits clip.tokenize's 77-token context."""
+    from clip_glass_amd.gpt2_bpe import Gpt2Bpe
+    from clip_glass_amd.tokenizer import ClipTokenizer
+    ej, vb, cb = synth.write_bpe_assets(str(tmp_path))
+    g, c = Gpt2Bpe(ej, vb), ClipTokenizer(cb)
+    assert len(g.token_id) == 50257 and g.eot == 50256 and len(c.token_id) == 49408 and c.eot == 49407 and c.sot == 49406
+    assert len(g.encode("the picture of")) == 3
+    for s in ["the picture of", "a wolf at night with the moon", "hello world"]:
+        assert g.decode(g.encode(s)) == s
+    toks = np.random.RandomState(0).randint(0, 50256, (16, 30))
+    texts = [g.decode(r)[:50] for r in toks]
+    tk = c.tokenize(texts)
+    assert tk.shape == (16, 77) and (tk[:, 0] == c.sot).all() and ((tk == c.eot).sum(1) == 1).all()
+
+
 def test_parse_out_semantics():
     """models.py:32-42: latent tokens dropped, cut at <|endoftext|>, empty text when EOT sits in the latent part."""
     dec = lambda toks: " ".join(str(t) for t in toks)
