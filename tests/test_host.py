@@ -463,3 +463,29 @@ def test_conv_down_index_emulation(B, R, Cin, Cout):
     assert err.max() < 8e-3 * np.abs(ref).max(), "max err %.3e at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
     for sl in (np.s_[:, :, :2, :], np.s_[:, :, -2:, :], np.s_[:, :, :, :2], np.s_[:, :, :, -2:]):
         assert np.abs(got[sl] - ref[sl]).max() < 8e-3 * np.abs(ref).max()
+
+
+def test_bench_kernel_labels_resolve_to_pmc_rows():
+    """bench.py match_kernel: every engine kernel label of the stored per-layer profile resolves to its rocprofv3 symbol in the stored
+    PMC table (`conv_stream_kernel<torgb>`, `conv_tiled_kernel<...,torgb,deep>`, `<...,xs,deep>` and the `D.blur.*` tags
+    found no row and `traffic` would have become null silently).  The one composite label is three kernels and has no single row."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    table = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))["per_kernel"]
+    assert bench._canon_symbol("_Z11blur_kernelILi2ELi1ELi16EEvPKDF16_iiiiiPDF16_") == ("blur_kernel", ["2", "1", "16"])
+    assert bench._canon_label("conv_tiled_kernel<3,1,8,64,xs,deep>")[1] == "3,1,8,64,false,false,false,true,false,false,true,false".split(",")
+    assert bench._canon_label("conv_stream_kernel<torgb>")[1] == ["false", "true", "false"]
+    labels = ["conv_gldsp_kernel<false,true,false>", "dblock0_kernel", "upfir2_kernel<false>", "upfir2_kernel<true>", "conv_s2_kernel",
+              "conv_gldsp_kernel<false,false,false>", "conv_stream_kernel<torgb>", "conv_tiled_kernel<3,1,8,64,torgb,deep>",
+              "conv_tiled_kernel<3,1,8,64,xs,deep>", "conv_gldsp_kernel<true,false,false>", "gemm_tiled_kernel<64>", "gemm_tiled_kernel<128>",
+              "D.blur.r512", "D.blur.r64", "G.torgb.r128", "G.torgb.r64", "clip.layernorm", "clip.attention", "noise", "mapping",
+              "conv_glds_kernel<16>"]
+    for name in labels:
+        row = bench.match_kernel(name, table)
+        assert row is not None and row["bytes_per_launch"] > 0, name
+    assert bench.match_kernel("D.blur.r512", table) is not bench.match_kernel("D.blurdown.r16", table)
+    fam = bench.family_table({"upfir2_kernel<false>": dict(launches=2, total_ms=3.4, flops=1.2e12, bytes=9.6e9),
+                              "D.blur.r512": dict(launches=1, total_ms=0.8, flops=0.0, bytes=4.3e9)}, 31.0, table)
+    assert [r["kernel"] for r in fam["rows"]] == ["upfir2_kernel<false>", "D.blur.r512"] and all(r["traffic_ratio"] for r in fam["rows"])

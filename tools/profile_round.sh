@@ -15,7 +15,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o
 ls $OUT/prof | head
 bash tools/measure_traffic.sh $TAG > $OUT/traffic.log 2>&1
 bash tools/measure_sq.sh $TAG > $OUT/sq.log 2>&1
-for b in mfma_peak hbm_peak inflight_probe; do   # (tools/_bin does not travel: built on the box)
+bash tools/measure_traffic.sh $TAG biggan512 > $OUT/traffic_biggan512.log 2>&1      # the legs' `roofline.traffic` (was null)
+bash tools/measure_traffic.sh $TAG gpt2 > $OUT/traffic_gpt2.log 2>&1
+for b in mfma_peak hbm_peak inflight_probe launch_boundary grid_barrier; do   # (tools/_bin does not travel: built on the box)
   hipcc --offload-arch=gfx950 -O3 tools/$b.hip -o /tmp/$b 2>/dev/null && timeout 180 /tmp/$b > $OUT/$b.txt 2>&1
 done
 python bench.py --config biggan512 --steps 20 --warmup 3 > $OUT/bench_biggan512.json 2>/dev/null
