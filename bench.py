@@ -119,10 +119,11 @@ def cpu_baseline(sd, cfg, target, pop=BATCH, budget_s=150.0, threads=(8, 16, 32,
     from clip_glass_amd import synth
     from oracle import fitness_ref
     tsd = {k: torch.as_tensor(v) for k, v in sd.items()}
-    x = synth.latents(123, pop, cfg["latent"])
+    x_all = synth.latents(123, pop, cfg["latent"])
     planes = synth.g_noise_planes(9, 0, 0, cfg["channels"])
 
-    def one_call():
+    def one_call(rows=None):
+        x = x_all if rows is None else x_all[:rows]
         with torch.no_grad():
             t0 = time.time()
             img = fitness_ref.generate(tsd, x, BATCH, lambda i: planes)
@@ -139,10 +140,10 @@ def cpu_baseline(sd, cfg, target, pop=BATCH, budget_s=150.0, threads=(8, 16, 32,
         phys = None
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    counts = sorted({n for n in threads if n <= ncpu} | {min(default_threads, ncpu)})
+    counts = sorted({n for n in threads if n <= ncpu} | ({min(default_threads, ncpu)} if len(threads) > 1 else set())) or [ncpu]
     t_begin = time.time()
     torch.set_num_threads(counts[-1])
-    one_call()                                            # warm-up (allocator, thread pool, oneDNN primitive caches)
+    one_call(BATCH)                                       # warm-up on one minibatch (allocator, thread pool, oneDNN primitive caches)
     sweep = {}
     for n in counts:
         torch.set_num_threads(n)
@@ -312,6 +313,7 @@ def main():
     ap.add_argument("--pop", type=int, default=POP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-pop", type=int, default=BATCH, help="candidates in the CPU baseline sample (multiple of 4; 64 = the whole headline population, ~4 min)")
+    ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="torch intra-op threads of the CPU baseline (0 = sweep 8/16/32/64/128 and report the best)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-legs", action="store_true", help="headline only: skip the biggan512 / gpt2 legs attached to the default line")
     ap.add_argument("--leg-steps", type=int, default=5)
@@ -555,7 +557,8 @@ def main():
                    # ... D2H of F): checkable against `ms_per_step` even when an smi sampler misses the ~1 s window
                    gpu_active_s=gpu_ms * 1e-3, gpu_active_frac_of_timed_region=gpu_ms * 1e-3 / dt)
         if world == 1 and not args.no_cpu_baseline and not biggan:
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH))
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH),
+                                               threads=((args.cpu_baseline_threads,) if args.cpu_baseline_threads else (8, 16, 32, 64, 128)))
         if world == 1 and args.config == "ffhq" and not args.no_legs and dist is None:
             # the other single-GPU configs of BASELINE.json (configs[2] DeepMindBigGAN512, configs[4] GPT2) as short legs of the
             # same driver-run line, each with its own roofline; the headline engine is closed first
