@@ -40,6 +40,9 @@ def check(name, got, ref, rtol_scale, atol=0.0):
 # (~4.5e-3 absolute at |D| ~ 0.5): an order-of-magnitude regression would have passed.  The fp16-storage engine delivers
 # 3e-4 .. 1.4e-3 absolute over the mini / mid / ffhq cases (gpurun_out/diag.log), so the bar sits at 1.5e-3 + 1.5e-3 |ref|.
 D_ATOL, D_RTOL = 1.5e-3, 1.5e-3
+# WHAT THESE BARS ARE: a REGRESSION GUARD, not a parity bar.  north_star states a tolerance for the CLIP similarity only
+# (1e-3 relative; asserted as such wherever `sim` is compared); for the second objective it states none, so the bar below is derived from
+# the engine's own measured error against the oracle / the reference-generated fixtures and exists to catch the D path getting WORSE.
 # Per-architecture bars: ~1.35 x the largest error the engine delivers on that architecture over every case of the GPU
 # suite (gpurun_out/diag.log of the r04 run; the runs are bitwise reproducible), so that a 2 x regression of the D path fails on
 # the architecture where it happens instead of hiding under the loosest case's bar.  north_star states no D tolerance.
