@@ -126,7 +126,11 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 W0f[tap][kk] = *(const h8*)(p.w0 + ((long long)tap * 32 + lr) * 32 + kk * 16 + kh * 8);
-                W1f[tap][kk] = *(const h8*)(p.w1 + ((long long)tap * 64 + nh * 32 + lr) * 32 + kk * 16 + kh * 8);
+                // conv0's activation gain sqrt2 rides in conv1's weights (h feeds nothing but FIR -> conv1, both linear): the conv0 epilogue
+                // is max(v, 0.2 v), two packed ops per register instead of three (r05)
+                const h8 w1v = *(const h8*)(p.w1 + ((long long)tap * 64 + nh * 32 + lr) * 32 + kk * 16 + kh * 8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) W1f[tap][kk][q] = (half_t)((float)w1v[q] * GLASS_SQRT2);
             }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -226,9 +230,12 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 const int iy = y0 + fr, ix = x0 + fc;
                 const bool ok = kh1 == 0 && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
                 h8 cf = zero;                                                          // (r, g, b, 1, 0, 0, 0, 0) or all zero
-                cf[0] = (half_t)(fminf(fmaxf((yv[u][0] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
-                cf[1] = (half_t)(fminf(fmaxf((yv[u][1] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
-                cf[2] = (half_t)(fminf(fmaxf((yv[u][2] + 1.f) * 0.5f, 0.f), 1.f) * 2.f - 1.f);
+                // biggan_denorm(biggan_norm(y)) = clamp((y + 1) / 2, 0, 1) * 2 - 1 = clamp(y, -1, 1) (utils.py:14-21): ONE v_med3_f32 per value
+                // where the literal form took five VALU instructions (r05; the two differ by fp32 rounding of (y + 1), <= 6e-8, before
+                // the value is rounded to its fp16 MFMA operand anyway)
+                cf[0] = (half_t)__builtin_amdgcn_fmed3f(yv[u][0], -1.f, 1.f);
+                cf[1] = (half_t)__builtin_amdgcn_fmed3f(yv[u][1], -1.f, 1.f);
+                cf[2] = (half_t)__builtin_amdgcn_fmed3f(yv[u][2], -1.f, 1.f);
                 cf[3] = (half_t)1.f;
                 if (!ok) cf = zero;
                 const f16x z = mfma32(Wrgb, cf, zacc);                                 // z[4g + q] = x[channel 8g + 4kh + q] of pixel lr, fp32
@@ -319,8 +326,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 D0TRACE(5);
-                // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
-                const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
+                // bias + lrelu: fp32 sum -> fp16 -> max(v, 0.2 v) in packed fp16 (the activation's sqrt2 gain is in conv1's weights)
+                const half_t k2 = (half_t)0.2f;
                 const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
                 auto epi0 = [&](bool masked) {
 #pragma unroll
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                             h4 v;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] = (half_t)acc[blk][g * 4 + q];
-                            h4 hq = __builtin_elementwise_max(v * k1, v * k2);
+                            h4 hq = __builtin_elementwise_max(v, v * k2);
                             if (masked && !colok) hq = h4{0, 0, 0, 0};
                             *(h4*)(smem + rtw + ((g ^ ((lr >> 2) & 3)) << 4) + blk * 2048) = hq;    // chunk XOR-swizzled by the column group: the
                             // 32 lanes of a half-wave write 8 bytes each at the SAME offset of 32 different pixels — 8-way conflicts unswizzled
@@ -406,8 +413,15 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 __builtin_amdgcn_sched_barrier(0);
             }
             D0TRACE(10);
+            // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2.  As f4 arithmetic: v_pk_mul_f32 + v_max_f32 (24 instructions; the
+            // scalar fmaxf form compiled to 48: a canonicalising v_max per operand)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = fmaxf(acc[q], 0.2f * acc[q]);        // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2
+            for (int g = 0; g < 4; ++g) {
+                f4 v4 = {acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
+                v4 = __builtin_elementwise_max(v4, v4 * 0.2f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[g * 4 + q] = v4[q];
+            }
             const int xslot = uni((2 * k + r) % 3);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);

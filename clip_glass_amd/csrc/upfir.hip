@@ -613,7 +613,10 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 h8 hs[4];
                 hs[1] = *(const h8*)(hs_slot); hs[2] = *(const h8*)(hs_slot + 16); hs[3] = *(const h8*)(hs_slot + 32);   // rows 13, 14, 15 of the previous step
                 const half_t f3 = (half_t)3.f, fq4 = (half_t)0.0625f, ft4 = (half_t)0.1875f;   // [1,3,3,1]/4 per axis: horizontal pass unscaled (x 4), vertical / 16
-                const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+                // (activation as max(v, slope v) * (gain * consumer style): see the single-image instance below)
+                const half_t slope = (half_t)(p.act ? 0.2f : 1.f);
+                const half_t gain = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale);
+                const h8 kpsa = psa * gain, kpsb = psb * gain;
                 const char* tr[4];
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     const h8 bn = bias8 + (half_t)nzr[r];
                     const h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
                     half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
-                    if (emit) *(h8*)yp = __builtin_elementwise_max(v * k1, v * k2) * (second ? psb : psa);
+                    if (emit) *(h8*)yp = __builtin_elementwise_max(v, v * slope) * (second ? kpsb : kpsa);
                     __builtin_amdgcn_sched_barrier(0);
                     if (r + 1 < 16) {
 #pragma unroll
@@ -720,7 +723,11 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 h8 bias8;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { bias8[j] = (half_t)bq0[j]; bias8[j + 4] = (half_t)bq1[j]; }
-                const half_t k1 = (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale), k2 = (half_t)((p.act ? 0.2f * GLASS_SQRT2 : 1.f) * p.out_scale);
+                // activation + output gain + consumer style as  max(v, slope v) * (gain * style)  (r05): three packed ops per register where
+                // max(v k1, v k2) * style  took four plus a select (the optional style multiply was compiled as multiply + v_cndmask: 8 of the
+                // row's ~60 VALU instructions in a loop that is bound by VALU issue).  ps8 is all ones without a consumer style.
+                const half_t slope = (half_t)(p.act ? 0.2f : 1.f);
+                const h8 kps = ps8 * (half_t)((p.act ? GLASS_SQRT2 : 1.f) * p.out_scale);
                 const char* tr[4];
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
@@ -748,8 +755,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     hs[r & 3] = (cv[1] + cv[2]) * f3 + (cv[0] + cv[3]);   // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
                     const h8 bn = bias8 + (half_t)cnz;
                     h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
-                    v = __builtin_elementwise_max(v * k1, v * k2);
-                    if (p.post_scale16) v = v * ps8;                // (uniform: per-sample-weight layers feed a conv whose weights carry its style)
+                    v = __builtin_elementwise_max(v, v * slope) * kps;
                     if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);

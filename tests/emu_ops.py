@@ -517,11 +517,16 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
                             nz = 0.0 if noise is None else noise_strength * float(np.asarray(noise, np.float32)[img // batch_size, oy, ox])
                             bn = pk((0.0 if bias is None else np.asarray(bias, np.float32)).astype(f16).astype(np.float32) + np.float32(f16(nz)))
                             vv = pk(a[oxl].astype(np.float32) * 0.0625 + pk(m[oxl].astype(np.float32) * 0.1875 + bn.astype(np.float32)).astype(np.float32))
-                            o = np.maximum(pk(vv.astype(np.float32) * np.float32(k1)), pk(vv.astype(np.float32) * np.float32(k2)))
+                            # upfir.hip (r05): max(v, slope v) * (gain * consumer style), gain * style rounded once to fp16
+                            slope = np.float32(f16(0.2 if act else 1.0))
+                            o = np.maximum(vv.astype(np.float32), pk(vv.astype(np.float32) * slope).astype(np.float32))
                             sx = (ixo - ixi0) & 3
                             if ps16 is not None:
-                                o = pk(o.astype(np.float32) * ps16[sel_img((4 if second else 0) + sx)].astype(np.float32))
+                                kps = pk(ps16[sel_img((4 if second else 0) + sx)].astype(np.float32) * np.float32(k1))
                                 assert sel_img((4 if second else 0) + sx) == img
+                            else:
+                                kps = np.full(o.shape, k1, f16)
+                            o = pk(o * kps.astype(np.float32))
                             out[img, oy, ox] = o.astype(np.float32)
                             written[img, oy, ox] += 1
     assert (written == 1).all(), "every output pixel is written exactly once (%d .. %d)" % (written.min(), written.max())
@@ -562,6 +567,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
     tiles_x, tiles_y = (Ro + 29) // 30, R // 4
     pk0 = real_ops.host_pack_conv(w0, False).astype(f16)        # [9][32][32]
     pk1 = real_ops.host_pack_conv(w1, False).astype(f16)        # [9][64][32]
+    pk1 = (pk1.astype(f32) * f32(math.sqrt(2))).astype(f16)     # conv_d0.hip (r05): conv0's activation gain rides in conv1's fragments
     pks = (real_ops.host_pack_conv(wskip, False).astype(f32) * f32(0.70710678118654752440)).astype(f16)[0]   # [64][32]
     Cf = np.concatenate([(np.asarray(frgb_w, f32)[:, c] * f32(math.sqrt(2))).astype(f16) for c in range(3)] +
                         [(np.asarray(frgb_b, f32) * f32(math.sqrt(2))).astype(f16)]).reshape(4, 32)
@@ -600,7 +606,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
             fr, fc = px // _D0_FC, px % _D0_FC
             iy, ix = y0 + fr, x0 + fc
             v = y[b][:, np.clip(iy, 0, R - 1), np.clip(ix, 0, R - 1)].T             # [n, 3] clamped loads
-            c3 = (np.clip((v + f32(1)) * f32(0.5), 0, 1) * f32(2) - f32(1)).astype(f16)
+            c3 = np.clip(v, f32(-1), f32(1)).astype(f16)                                  # conv_d0.hip (r05): denorm(norm(y)) as one med3
             ok = (iy >= 0) & (iy < R) & (ix >= 0) & (ix < R)
             for part in range(4):
                 fw = Cf[:, part * 8:part * 8 + 8].astype(np.float64)
@@ -647,7 +653,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                     quad = np.stack([acc[blk, 8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)]).astype(f32)
                     bq = np.stack([b0[8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4] for i in range(64)])
                     v = (quad + bq).astype(f16)
-                    hq = np.maximum((v.astype(f32) * f32(f16(math.sqrt(2)))).astype(f16), (v.astype(f32) * f32(f16(0.2 * math.sqrt(2)))).astype(f16))
+                    hq = np.maximum(v, (v.astype(f32) * f32(f16(0.2))).astype(f16))          # (r05: the sqrt2 gain rides in conv1's weights)
                     hq = np.where(colok[:, None], hq, f16(0))
                     wr(rt + _vaddr(0, col, g ^ ((col >> 2) & 3)) + kh * 8, hq, n=4)
             v = []
