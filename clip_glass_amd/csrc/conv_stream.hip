@@ -219,10 +219,7 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
                     const int ch = 8 * (2 * (hidx >> 4) + (j >> 2)) + 4 * ((hidx >> 3) & 1) + (j & 3);
                     half_t val = (half_t)0.f;
                     if (col < 3 && ((n >> 2) & 1) == tab) {
-                        // (r05) the activation's positive gain k1 rides in the toRGB weights — the activated tile feeds nothing but this
-                        // 1x1 conv — so the epilogue's activation is max(v, slope v): two packed ops per register instead of three
-                        const float w = p.trgb_w[col * 32 + ch] * p.trgb_sn[(long long)b * p.trgb_sn_stride + ch] * sm *
-                                        ((p.act == 1 ? GLASS_SQRT2 : 1.f) * p.out_scale);
+                        const float w = p.trgb_w[col * 32 + ch] * p.trgb_sn[(long long)b * p.trgb_sn_stride + ch] * sm;
                         const half_t hv = (half_t)w;
                         val = (n & 8) ? (half_t)((w - (float)hv) * 2048.f) : hv;
                     }
@@ -359,7 +356,6 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
         const half_t k1 = (half_t)((p.act == 1 ? GLASS_SQRT2 : 1.f) * p.out_scale);
         const half_t k2 = (half_t)((p.act == 1 ? 0.2f * GLASS_SQRT2 : p.act == 2 ? 0.f : 1.f) * p.out_scale);
         if (TRGB) {
-            const half_t slope = (half_t)(p.act == 1 ? 0.2f : p.act == 2 ? 0.f : 1.f);      // k2 / k1
             f16x rgb;
 #pragma unroll
             for (int q = 0; q < 16; ++q) rgb[q] = 0.f;
@@ -374,7 +370,7 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
                     h4 v;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = (half_t)(acc[i][g * 4 + q] * d[q] + (nz + bb[q]));
-                    va[g] = __builtin_elementwise_max(v, v * slope);
+                    va[g] = __builtin_elementwise_max(v * k1, v * k2);
                 }
                 const char* Tt = Tw + i * 1024 + (lr & 15) * 64 + kh * 16;
                 rgb = mfma32(*(const h8*)Tt, __builtin_shufflevector(va[0], va[1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
