@@ -286,7 +286,15 @@ struct UpGeo {
     unsigned invPX, invPY;     // ceil(2^32 / (W + 1)), ceil(2^32 / (H + 1)): exact n / pitch for the ranges used here
     unsigned inv2PX, inv2PY;   // same for the output pitches 2 (W + 1), 2 (H + 1)
     int prefetch;              // GRID = false: fetch the next step's stage-0 operands under this step's FIR (A/B knob)
+    int ablate;                // developer build only (make AB=1, GLASS_UPFIR_ABLATE): timing experiments that switch phases of the single-image
+                               // instance off — 1 MFMAs, 2 T write + FIR + stores, 4 global stores, 8 FIR arithmetic, 16 operand loads, 32 weight loads after a
+                               // segment's first step, 64 patch loads, 128 weight LDS writes after the first step.  WRONG RESULTS.
 };
+#ifdef GLASS_AB_KNOBS
+#define U_ABL(bit) (!GRID && (g.ablate & (bit)))
+#else
+#define U_ABL(bit) false
+#endif
 
 namespace {
 constexpr int U_PH = 9, U_PW = 33;
@@ -399,10 +407,12 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         const bool plain = !GRID && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
 
         auto load_a = [&](int c0) {
+            if (U_ABL(16) || U_ABL(64)) return;
 #pragma unroll
             for (int k = 0; k < NA; ++k) ra[k] = *(const h8*)(p.x + a_goff[k] + c0);
         };
         auto load_b = [&](int c0) {
+            if (U_ABL(16) || (U_ABL(32) && step > 0)) return;
             const half_t* wp = wb + u_opaque(b_goff0) + c0;       // (opaque: five hoisted 64-bit pointers would be spilled)
 #pragma unroll
             for (int k = 0; k < NB; ++k) rb[k] = *(const h8*)(wp + ((k == NB - 1 && threadIdx.x >= 128) ? k - 1 : k) * b_step);
@@ -429,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             }
         };
         auto store_b = [&]() {
+            if (U_ABL(128) && step > 0) return;
             const int t = threadIdx.x, part = t & 3;
             char* bb = Bs + u_stage_row(t >> 2) * ROWB + part * 16;
 #pragma unroll
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         // tap (ky,kx) feeds parity class (ky&1, kx&1) and reads x[m - (ky>>1), n - (kx>>1)] (see upfir_kernel)
         auto mfma_block = [&]() {
+            if (U_ABL(1)) return;
             const int tm = u_opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, wave = tm >> 6;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
@@ -690,6 +702,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 for (int r = 0; r < 16; ++r) *(float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4) = p.noise_strength * nzr[r];
             }
             __syncthreads();   // everyone is done with the staging area: overlay T
+            if (U_ABL(2)) { if (acc[0][0][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
             {
                 char* tw = (char*)T + ((2 * wave * 2) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
                 int so[4];
@@ -756,7 +769,8 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     const h8 bn = bias8 + (half_t)cnz;
                     h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
                     v = __builtin_elementwise_max(v, v * slope) * kps;
-                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho) *(h8*)yp = v;
+                    if (U_ABL(8)) v = cv[0];
+                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);
                     if (r + 1 < 16) {
@@ -826,6 +840,8 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     // layers — a wash, as round 2's persistent-prefetch experiment was: the step is issue-bound, not latency-bound.  Off.
     static const bool prefetch = glass_knob("GLASS_UPFIR_PREFETCH") != nullptr;
     g.prefetch = prefetch ? 1 : 0;
+    static const int ablate = glass_knob("GLASS_UPFIR_ABLATE") ? atoi(glass_knob("GLASS_UPFIR_ABLATE")) : 0;
+    g.ablate = ablate;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
     // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
     const bool lean = p.w_bstride && !p.sn16 && !p.dscale && g.NXI * g.NYI == 1;
