@@ -126,11 +126,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 W0f[tap][kk] = *(const h8*)(p.w0 + ((long long)tap * 32 + lr) * 32 + kk * 16 + kh * 8);
-                // conv0's activation gain sqrt2 rides in conv1's weights (h feeds nothing but FIR -> conv1, both linear): the conv0 epilogue
-                // is max(v, 0.2 v), two packed ops per register instead of three (r05)
-                const h8 w1v = *(const h8*)(p.w1 + ((long long)tap * 64 + nh * 32 + lr) * 32 + kk * 16 + kh * 8);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) W1f[tap][kk][q] = (half_t)((float)w1v[q] * GLASS_SQRT2);
+                W1f[tap][kk] = *(const h8*)(p.w1 + ((long long)tap * 64 + nh * 32 + lr) * 32 + kk * 16 + kh * 8);
             }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -326,8 +322,10 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 D0TRACE(5);
-                // bias + lrelu: fp32 sum -> fp16 -> max(v, 0.2 v) in packed fp16 (the activation's sqrt2 gain is in conv1's weights)
-                const half_t k2 = (half_t)0.2f;
+                // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
+                // (r05: moving the sqrt2 gain into conv1's weight fragments saves 16 of the step's ~880 VALU instructions, changes no
+                // timing — the kernel is not bound by VALU issue, DESIGN section 5 — and re-rounds the weights: D error 5.4e-4 -> 8.1e-4; not kept)
+                const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
                 const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
                 auto epi0 = [&](bool masked) {
 #pragma unroll
@@ -338,7 +336,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                             h4 v;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) v[q] = (half_t)acc[blk][g * 4 + q];
-                            h4 hq = __builtin_elementwise_max(v, v * k2);
+                            h4 hq = __builtin_elementwise_max(v * k1, v * k2);
                             if (masked && !colok) hq = h4{0, 0, 0, 0};
                             *(h4*)(smem + rtw + ((g ^ ((lr >> 2) & 3)) << 4) + blk * 2048) = hq;    // chunk XOR-swizzled by the column group: the
                             // 32 lanes of a half-wave write 8 bytes each at the SAME offset of 32 different pixels — 8-way conflicts unswizzled

@@ -567,7 +567,6 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
     tiles_x, tiles_y = (Ro + 29) // 30, R // 4
     pk0 = real_ops.host_pack_conv(w0, False).astype(f16)        # [9][32][32]
     pk1 = real_ops.host_pack_conv(w1, False).astype(f16)        # [9][64][32]
-    pk1 = (pk1.astype(f32) * f32(math.sqrt(2))).astype(f16)     # conv_d0.hip (r05): conv0's activation gain rides in conv1's fragments
     pks = (real_ops.host_pack_conv(wskip, False).astype(f32) * f32(0.70710678118654752440)).astype(f16)[0]   # [64][32]
     Cf = np.concatenate([(np.asarray(frgb_w, f32)[:, c] * f32(math.sqrt(2))).astype(f16) for c in range(3)] +
                         [(np.asarray(frgb_b, f32) * f32(math.sqrt(2))).astype(f16)]).reshape(4, 32)
@@ -653,7 +652,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                     quad = np.stack([acc[blk, 8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)]).astype(f32)
                     bq = np.stack([b0[8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4] for i in range(64)])
                     v = (quad + bq).astype(f16)
-                    hq = np.maximum(v, (v.astype(f32) * f32(f16(0.2))).astype(f16))          # (r05: the sqrt2 gain rides in conv1's weights)
+                    hq = np.maximum((v.astype(f32) * f32(f16(math.sqrt(2)))).astype(f16), (v.astype(f32) * f32(f16(0.2 * math.sqrt(2)))).astype(f16))
                     hq = np.where(colok[:, None], hq, f16(0))
                     wr(rt + _vaddr(0, col, g ^ ((col >> 2) & 3)) + kh * 8, hq, n=4)
             v = []
