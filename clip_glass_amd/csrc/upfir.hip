@@ -298,9 +298,25 @@ struct UpGeo {
 
 namespace {
 constexpr int U_PH = 9, U_PW = 33;
-constexpr int U_NVA = U_PH * U_PW * 4, U_NA = (U_NVA + 255) / 256;     // 1188 -> 5
+constexpr int U_NVA = U_PH * U_PW * 4;                                 // 1188 vectors -> 5 per thread
 constexpr int U_NVB = 9 * 32 * 4, U_NB = (U_NVB + 255) / 256;          // 1152 -> 5
 constexpr int U_A_BYTES = ((U_PH * U_PW * ROWB + 15) / 16) * 16;       // 23760
+// Step geometry by RW = m rows per wave (r05).  RW = 2 is the round-3 / round-4 kernel: 8 m rows per step, T tile [16][64], 81.6 KB of LDS and
+// ~250 VGPRs -> TWO workgroups per CU.  RW = 1 halves the step (4 m rows, T [8][64], 64 accumulator registers): 51 KB and <= 168 VGPRs ->
+// THREE workgroups per CU, for the single-image instance whose step is made of exposed memory phases ("Round 5": a
+// third workgroup is one more chance that somebody computes while the others wait); it pays with the weights staged per 4 rows instead of 8.
+template <int RW>
+struct UStep {
+    static constexpr int MR = 4 * RW, TR = 2 * MR, PH = MR + 1;
+    static constexpr int NVA = PH * U_PW * 4, NA = (NVA + 255) / 256;                   // RW 2: 1188 -> 5;  RW 1: 660 -> 3
+    static constexpr int A_BYTES = ((PH * U_PW * ROWB + 15) / 16) * 16;                 // 23760 / 13200
+    static constexpr int T_BYTES = TR * 64 * 64;                                        // 65536 / 32768
+    static constexpr int STAGE = A_BYTES + 9 * 32 * ROWB;                               // 46800 / 36240
+    static constexpr int R0 = ((T_BYTES > STAGE ? T_BYTES : STAGE) + 1023) / 1024 * 1024;   // 65536 / 36864: T overlays the staging images
+    static constexpr int OFF_LNZ = R0;                                                  // GRID = false: noise table [TR][60] fp32 behind the T tile
+    static constexpr int OFF_HS = OFF_LNZ + TR * 60 * 4;                                // [256 threads][3 rows] h8: the FIR window between steps
+    static constexpr int LDS = OFF_HS + 256 * 48;                                       // 81664 / 51072
+};
 // per-step constant tables live in the tail of the T tile that the staging images do not reach (46800 ..): they are read
 // into registers before the T tile is written
 constexpr int U_OFF_STY = 46848;                   // [8 images][Cin] fp16 style rows (Cin <= 512)
@@ -308,10 +324,8 @@ constexpr int U_OFF_DS = U_OFF_STY + 8 * 1024;     // [8][32] fp32 demodulation
 constexpr int U_OFF_PS = U_OFF_DS + 8 * 128;       // [8][32] fp16 consumer style
 constexpr int U_OFF_BI = U_OFF_PS + 8 * 64;        // [32] fp32 bias
 constexpr int U_OFF_NZ = U_OFF_BI + 128;           // [16 rows][60 cols] fp32 noise * strength
-constexpr int U_OFF_LNZ = 65536;                   // GRID = false: the same noise table, behind the T tile (it is read during the FIR)
-constexpr int U_OFF_HS = U_OFF_LNZ + 16 * 60 * 4;  // [256 threads][3 rows] h8: the FIR window between steps
-constexpr int U_LDS = U_OFF_HS + 256 * 48;         // 81664 B: two workgroups per CU (163328 of 163840)
-static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32 * ROWB, "constant tables fit behind the staging images");
+static_assert(UStep<2>::LDS == 81664 && 2 * UStep<2>::LDS <= 163840 && 3 * UStep<1>::LDS <= 163840, "two / three workgroups per CU");
+static_assert(U_OFF_NZ + 16 * 60 * 4 <= 65536 && U_OFF_STY >= U_A_BYTES + 9 * 32 * ROWB && UStep<2>::A_BYTES == U_A_BYTES, "constant tables fit behind the staging images");
 __device__ __forceinline__ int u_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // T tile of upfir2 (r04): a row's 64 columns sit de-interleaved — column x at position (x & 1) * 32 + (x >> 1), 64 B each, the 16-byte
 // chunk index XORed with (x >> 2) & 3.  The MFMA lanes write columns 2 lr + c: with the columns in order, the 16 lanes of one ds_write_b64
@@ -329,13 +343,17 @@ __device__ __forceinline__ int u_fir_col(int ci) { return ci ^ (((ci >> 2) ^ (ci
 // GRID = true: shared weights, candidates on a virtual grid, per-image operands through the LDS tables.
 // GRID = false: per-sample weights (which carry style and demodulation): one candidate per grid, no tables, no index
 // divisions — the 512^2 / 1024^2 layers are instruction-issue bound, every instruction per step counts.
-template <bool GRID>
-__global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
-    constexpr int PW = U_PW, NA = U_NA, NVB = U_NVB, NB = U_NB, A_BYTES = U_A_BYTES;
+template <bool GRID, int RW = 2>
+__global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo g) {
+    static_assert(RW == 2 || !GRID, "the half-height step exists for the single-image instance only");
+    using US = UStep<RW>;
+    constexpr int MR = US::MR, TR = US::TR;
+    constexpr int PW = U_PW, NA = US::NA, NVB = U_NVB, NB = U_NB, A_BYTES = US::A_BYTES;
+    constexpr int U_OFF_LNZ = US::OFF_LNZ, U_OFF_HS = US::OFF_HS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;
     char* Bs = smem + A_BYTES;
-    half_t* T = (half_t*)smem;                  // [16][64][32] fp16, overlays the staging area afterwards
+    half_t* T = (half_t*)smem;                  // [TR][64][32] fp16, overlays the staging area afterwards
 
     // ---- work item: XCD xcd owns n-tile group xcd % G and pixel slice xcd / G ---------------------------------------
     const int id = blockIdx.x;
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     const int img0 = gi * g.NXI * g.NYI;
     const int PX = p.W + 1, PY = p.H + 1;
     const int mx0 = txi * 30 - 1;                           // virtual m column of lane 0
-    const int Y0 = seg * (12 + 16 * (g.S - 1));             // first virtual output row of the segment
+    const int Y0 = seg * ((TR - 4) + TR * (g.S - 1));       // first virtual output row of the segment
     const int out_rows = 2 * PY * g.NYI - 2;                // virtual output rows that exist
     const int ixi0 = GRID ? (int)__umulhi((unsigned)max(mx0 - 1, 0), g.invPX) : 0;     // first image column the tile's patch touches
 
@@ -367,9 +385,9 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
     h8 ra[NA], rb[NB];
     bool have = false;          // (uniform) stage 0 of this step was fetched during the previous step's FIR phase (GRID = false)
     for (int step = 0; step < g.S; ++step) {
-        const int o_first = Y0 + (step ? 16 * step - 4 : 0);   // first output row this step emits
+        const int o_first = Y0 + (step ? TR * step - 4 : 0);   // first output row this step emits
         if (o_first >= out_rows) break;                         // (uniform) the segment runs off the grid
-        const int my0 = (Y0 >> 1) - 1 + 8 * step;               // virtual m row of the step's first computed row
+        const int my0 = (Y0 >> 1) - 1 + MR * step;              // virtual m row of the step's first computed row
         const int iyi0 = GRID ? (int)__umulhi((unsigned)max(my0 - 1, 0), g.invPY) : 0;
         // table entry sel = dy * 4 + dx  <->  image (iyi0 + dy, ixi0 + dx), clamped to an image that exists (its values then
         // only ever meet masked operands, but they must be finite)
@@ -392,19 +410,19 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     const int iyi = (int)__umulhi((unsigned)max(vy, 0), g.invPY), ixi = (int)__umulhi((unsigned)max(vx, 0), g.invPX);
                     const int iy = vy - iyi * PY, ix = vx - ixi * PX;
                     const int img = img0 + iyi * g.NXI + ixi;
-                    const bool ok = pix < U_PH * U_PW && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
+                    const bool ok = pix < US::PH * U_PW && vy >= 0 && vx >= 0 && iy < p.H && ix < p.W && iyi < g.NYI && ixi < g.NXI && img < p.B;
                     a_goff[k] = ok ? img * (int)p.x_bstride + (iy * p.W + ix) * p.Cin + part * 8 : part * 8;
                     okm |= (ok ? 1 : 0) << k;
                     selm |= ((((iyi - iyi0) << 2) + (ixi - ixi0)) & 7) << (3 * k);
                 } else {
-                    const bool ok = pix < U_PH * U_PW && vy >= 0 && vx >= 0 && vy < p.H && vx < p.W;
+                    const bool ok = pix < US::PH * U_PW && vy >= 0 && vx >= 0 && vy < p.H && vx < p.W;
                     a_goff[k] = ok ? img0 * (int)p.x_bstride + (vy * p.W + vx) * p.Cin + part * 8 : part * 8;
                     okm |= (ok ? 1 : 0) << k;
                 }
             }
         };
         // interior tile of a single-image grid whose weights carry the style: registers -> LDS as they are
-        const bool plain = !GRID && my0 >= 1 && mx0 >= 1 && my0 + 7 < p.H && mx0 + 31 < p.W;
+        const bool plain = !GRID && my0 >= 1 && mx0 >= 1 && my0 + MR - 1 < p.H && mx0 + 31 < p.W;
 
         auto load_a = [&](int c0) {
             if (U_ABL(16) || U_ABL(64)) return;
@@ -424,13 +442,13 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             if (plain) {
 #pragma unroll
                 for (int k = 0; k < NA; ++k)
-                    if (k < NA - 1 || trow + 64 * k < U_PH * U_PW) *(h8*)(ab + k * 64 * ROWB) = ra[k];
+                    if (k < NA - 1 || trow + 64 * k < US::PH * U_PW) *(h8*)(ab + k * 64 * ROWB) = ra[k];
             } else {
                 const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
                 const char* sty = smem + U_OFF_STY + (c0 + part * 8) * 2;
 #pragma unroll
                 for (int k = 0; k < NA; ++k) {
-                    if (k < NA - 1 || trow + 64 * k < U_PH * U_PW) {
+                    if (k < NA - 1 || trow + 64 * k < US::PH * U_PW) {
                         h8 a = ((okm >> k) & 1) ? ra[k] : zero;
                         if (GRID && p.sn16) a = a * *(const h8*)(sty + ((selm >> (3 * k)) & 7) * 1024);   // the vector's own image's style
                         *(h8*)(ab + k * 64 * ROWB) = a;
@@ -481,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 if (p.noise) {
                     const int e = min(t + 256 * u, 959);
                     const int r = e / 60, c = e - r * 60;
-                    const int ovy = max(Y0 + 16 * step + r - 4, 0), ovx = txi * 60 + c;
+                    const int ovy = max(Y0 + TR * step + r - 4, 0), ovx = txi * 60 + c;
                     const int iyi = (int)__umulhi((unsigned)ovy, g.inv2PY), ixi = (int)__umulhi((unsigned)ovx, g.inv2PX);
                     const int oy = min(ovy - iyi * 2 * PY, p.Ho - 1), ox = min(ovx - ixi * 2 * PX, p.Wo - 1);
                     const int img = min(img0 + min(iyi, g.NYI - 1) * g.NXI + min(ixi, g.NXI - 1), p.B - 1);
@@ -513,9 +531,9 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         }
         have = false;
 
-        f16x acc[2][4];   // [m-row of this wave][parity class ry*2+rx]
+        f16x acc[RW][4];   // [m-row of this wave][parity class ry*2+rx]
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < RW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -537,8 +555,8 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                             for (int kx = ax * 2; kx < (ax ? 3 : 2); ++kx)
                                 wf[ky & 1][kx & 1] = *(const h8*)(Bs + ((ky * 3 + kx) * 32 + lr) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            const int prow = wave * 2 + i + 1 - ay;
+                        for (int i = 0; i < RW; ++i) {
+                            const int prow = wave * RW + i + 1 - ay;
                             const h8 xf = *(const h8*)(As + (prow * PW + lr + 1 - ax) * ROWB + kk * 32 + kh * 16);
 #pragma unroll
                             for (int ky = ay * 2; ky < (ay ? 3 : 2); ++ky)
@@ -565,18 +583,18 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
         store_b();
         __syncthreads();
 
-        const int ovy0 = Y0 + 16 * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
+        const int ovy0 = Y0 + TR * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
         if (GRID) {
             mfma_block();
             // ---- this step's constants: LDS tables -> registers (the T tile is about to cover them) -------------------------
             const int t = u_opaque(threadIdx.x), lane = t & 63, wave = t >> 6, lr = lane & 31, kh = lane >> 5;
             const int cg = t & 3, oxl = u_fir_col(t >> 2);   // FIR phase: 8-channel group, local output column 0..59 (oxl < 60)
-            f4 dq[2][4];
+            f4 dq[RW][4];
             {
                 const int ixl = (int)__umulhi((unsigned)max(mx0 + lr, 0), g.invPX) - ixi0;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int iyl = (int)__umulhi((unsigned)max(my0 + 2 * wave + i, 0), g.invPY) - iyi0;
+                for (int i = 0; i < RW; ++i) {
+                    const int iyl = (int)__umulhi((unsigned)max(my0 + RW * wave + i, 0), g.invPY) - iyi0;
                     const char* dp = smem + U_OFF_DS + (((iyl << 2) + ixl) & 7) * 128 + kh * 16;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) dq[i][gq] = *(const f4*)(dp + gq * 32);
@@ -595,19 +613,19 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 psa = *(const h8*)(smem + U_OFF_PS + sx * 64 + cg * 16);
                 psb = *(const h8*)(smem + U_OFF_PS + (4 + sx) * 64 + cg * 16);
             }
-            float nzr[16];
+            float nzr[TR];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nzr[r] = *(const float*)(smem + U_OFF_NZ + (r * 60 + min(oxl, 59)) * 4);
+            for (int r = 0; r < TR; ++r) nzr[r] = *(const float*)(smem + U_OFF_NZ + (r * 60 + min(oxl, 59)) * 4);
             __syncthreads();   // everyone is done with the staging area and the tables: overlay T
 
             // ---- t tile -> LDS (demod applied; it commutes with the FIR); layout as in upfir_kernel --------------------------
             {
-                char* tw = (char*)T + ((2 * wave * 2) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
+                char* tw = (char*)T + ((2 * wave * RW) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
                 int so[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ ((lr >> 1) & 3)) * 16;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RW; ++i)
 #pragma unroll
                     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
@@ -643,9 +661,9 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) cv[jx] = *(const h8*)(tr[jx]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < TR; ++r) {
                     h8 nv[4];
-                    if (r + 1 < 16) {
+                    if (r + 1 < TR) {
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx) nv[jx] = *(const h8*)(tr[jx] + (r + 1) * 4096);
                     }
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     half_t* yp = p.y + (((long long)img * p.Ho + oy) * p.Wo + ox) * p.Cout + n0 + cg * 8;
                     if (emit) *(h8*)yp = __builtin_elementwise_max(v, v * slope) * (second ? kpsb : kpsa);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (r + 1 < 16) {
+                    if (r + 1 < TR) {
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx) cv[jx] = nv[jx];
                     }
@@ -685,13 +703,13 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ps8[j] = (half_t)1.f;
             if (p.post_scale16) ps8 = *(const h8*)(p.post_scale16 + (long long)img0 * p.post_stride + n0 + cg * 8);
-            float nzr[16];
+            float nzr[TR];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) nzr[r] = 0.f;
+            for (int r = 0; r < TR; ++r) nzr[r] = 0.f;
             if (p.noise) {
                 const float* nzp = p.noise + (long long)(img0 / p.batch_size) * p.Ho * p.Wo + pxc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nzr[r] = nzp[(long long)min(max(ovy0 + r, 0), p.Ho - 1) * p.Wo];
+                for (int r = 0; r < TR; ++r) nzr[r] = nzp[(long long)min(max(ovy0 + r, 0), p.Ho - 1) * p.Wo];
             }
             mfma_block();
             // the step's noise values park in LDS behind the T tile (one column per cg == 0 thread): as registers they would be live
@@ -699,17 +717,17 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             // op that waits for every older prefetch load (in-order vmcnt)
             if (cg == 0 && t < 240) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) *(float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4) = p.noise_strength * nzr[r];
+                for (int r = 0; r < TR; ++r) *(float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4) = p.noise_strength * nzr[r];
             }
             __syncthreads();   // everyone is done with the staging area: overlay T
             if (U_ABL(2)) { if (acc[0][0][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
             {
-                char* tw = (char*)T + ((2 * wave * 2) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
+                char* tw = (char*)T + ((2 * wave * RW) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
                 int so[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) so[gq] = (gq ^ ((lr >> 1) & 3)) * 16;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < RW; ++i)
 #pragma unroll
                     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
@@ -723,8 +741,8 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
             __syncthreads();
             // stage 0 of the NEXT step: its operands travel while this step's FIR runs (the step is latency-bound: two exposed
             // global round trips + the store drain at the step barrier were ~2/3 of its 14 us on the two-stage 1024^2 layer)
-            if (g.prefetch && step + 1 < g.S && Y0 + 16 * (step + 1) - 4 < out_rows) {
-                aim(my0 + 8, 0);
+            if (g.prefetch && step + 1 < g.S && Y0 + TR * (step + 1) - 4 < out_rows) {
+                aim(my0 + MR, 0);
                 load_a(0);
                 load_b(0);
                 have = true;
@@ -760,10 +778,10 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                 };
                 rdrow(0, cv, cnz);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < TR; ++r) {
                     h8 nv[4];
                     float nnz;
-                    if (r + 1 < 16) rdrow(r + 1, nv, nnz);
+                    if (r + 1 < TR) rdrow(r + 1, nv, nnz);
                     __builtin_amdgcn_sched_barrier(0);
                     hs[r & 3] = (cv[1] + cv[2]) * f3 + (cv[0] + cv[3]);   // 4 x the filtered row: the 1/4 rides in the vertical pass's weights
                     const h8 bn = bias8 + (half_t)cnz;
@@ -773,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
                     if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (r + 1 < 16) {
+                    if (r + 1 < TR) {
 #pragma unroll
                         for (int jx = 0; jx < 4; ++jx) cv[jx] = nv[jx];
                         cnz = nnz;
@@ -787,16 +805,16 @@ __global__ __launch_bounds__(256, 2) void upfir2_kernel(ConvParams p, UpGeo g) {
 
 static unsigned u_inv(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
-static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
-    if (p.Cin > 512 || p.H < 8 || p.W < 16) return nullptr;
-    if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
-    if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
-    constexpr int LDS = U_LDS;
+// RW = m rows per wave: 2 = the two-workgroup step (8 m rows), 1 = the half-height step of the single-image instance (three workgroups per CU)
+template <int RW>
+static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lean) {
+    using US = UStep<RW>;
+    constexpr int LDS = US::LDS, TR = US::TR;
     if (!glass_lds_fits(LDS)) return nullptr;                 // (the caller falls through to upfir_kernel / the folded form)
     static DevOnce once;
     once.run([&] {
-        (void)hipFuncSetAttribute((const void*)upfir2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)upfir2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (RW == 2) (void)hipFuncSetAttribute((const void*)upfir2_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)upfir2_kernel<false, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
     static const int env_ng = glass_knob("GLASS_UPFIR_NG") ? atoi(glass_knob("GLASS_UPFIR_NG")) : 0;      // A/B knobs
     static const int env_s = glass_knob("GLASS_UPFIR_S") ? atoi(glass_knob("GLASS_UPFIR_S")) : 0;
@@ -816,15 +834,16 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     const int out_rows = 2 * PY * g.NYI - 2;
     // steps per segment: as long as possible (only a segment's first step recomputes the t halo) while the launch still has
     // >= 8 workgroups per CU-slot pair to balance (2048); never longer than the grid
-    int S = 8;
+    int S = 16 / RW;
     for (; S > 1; --S) {
-        const int R = 12 + 16 * (S - 1);
+        const int R = (TR - 4) + TR * (S - 1);
         const long long wgs = (long long)g.n_grids * g.tiles_x * ((out_rows + R - 1) / R) * g.NTn;
-        if (wgs >= 2048 && R <= out_rows + 15) break;
+        if (wgs >= 2048 && R <= out_rows + TR - 1) break;
     }
+    if (RW == 2 && S > 8) S = 8;
     if (env_s > 0) S = env_s;
     g.S = S;
-    const int R = 12 + 16 * (S - 1);
+    const int R = (TR - 4) + TR * (S - 1);
     g.n_seg = (out_rows + R - 1) / R;
     g.WT = g.n_grids * g.n_seg * g.tiles_x;
     // n tiles per XCD group: the group's weights (9 * 32 * Cin * 2 B per n tile) should stay resident in a 4 MiB L2 next to the
@@ -837,21 +856,38 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     if (env_ng > 0 && 8 % env_ng == 0 && g.NTn % env_ng == 0) ng = env_ng;
     g.ngroups = ng;
     // measured (round 3, same box): prefetch on 2298 / 1476 / 1217 us vs off 2183 / 1496 / 1235 us on the r1024 / r512 / r256
-    // layers — a wash, as round 2's persistent-prefetch experiment was: the step is issue-bound, not latency-bound.  Off.
+    // layers — a wash, as round 2's persistent-prefetch experiment was (round 5: 2127 vs 2016 us).  Off.
     static const bool prefetch = glass_knob("GLASS_UPFIR_PREFETCH") != nullptr;
     g.prefetch = prefetch ? 1 : 0;
     static const int ablate = glass_knob("GLASS_UPFIR_ABLATE") ? atoi(glass_knob("GLASS_UPFIR_ABLATE")) : 0;
     g.ablate = ablate;
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
-    // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
-    const bool lean = p.w_bstride && !p.sn16 && !p.dscale && g.NXI * g.NYI == 1;
-    const char* name = lean ? "upfir2_kernel<false>" : "upfir2_kernel<true>";
+    const char* name = !lean ? "upfir2_kernel<true>" : RW == 2 ? "upfir2_kernel<false>" : "upfir2_kernel<false,1>";
     if (p.dry_run) return name;
     const int Pp = 8 / ng;
     const int grid = 8 * ((g.WT + Pp - 1) / Pp) * (g.NTn / ng);
-    if (lean) hipLaunchKernelGGL(upfir2_kernel<false>, dim3(grid), dim3(256), LDS, st, p, g);
-    else hipLaunchKernelGGL(upfir2_kernel<true>, dim3(grid), dim3(256), LDS, st, p, g);
+    if (lean) hipLaunchKernelGGL((upfir2_kernel<false, RW>), dim3(grid), dim3(256), LDS, st, p, g);
+    else if (RW == 2) hipLaunchKernelGGL((upfir2_kernel<true, 2>), dim3(grid), dim3(256), LDS, st, p, g);
+    else return nullptr;
     return name;
+}
+
+static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
+    if (p.Cin > 512 || p.H < 8 || p.W < 16) return nullptr;
+    if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
+    if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
+    static const bool no_grid = glass_knob("GLASS_UPFIR_NO_GRID") != nullptr;
+    // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
+    const bool lean = p.w_bstride && !p.sn16 && !p.dscale;
+    (void)no_grid;
+#ifdef GLASS_AB_KNOBS
+    // half-height steps (4 m rows, 51 KB of LDS, 156 VGPRs: THREE workgroups per CU) for the single-image instance — developer build only.
+    // Measured (r05, same box, parity-green on the op tests and the goldens): r1024 1997 -> 2193 us, r512 1393 -> 1575 us: a third workgroup
+    // does not pay for weights staged per 4 rows instead of 8 and a 5-rows-for-4 patch.  Not in the release library.
+    static const int rw1 = glass_knob("GLASS_UPFIR_RW1") ? atoi(glass_knob("GLASS_UPFIR_RW1")) : 0;
+    if (lean && rw1) return launch_upfir2_t<1>(p, st, true);
+#endif
+    return launch_upfir2_t<2>(p, st, lean);
 }
 
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
