@@ -298,7 +298,6 @@ struct UpGeo {
 
 namespace {
 constexpr int U_PH = 9, U_PW = 33;
-constexpr int U_NVA = U_PH * U_PW * 4;                                 // 1188 vectors -> 5 per thread
 constexpr int U_NVB = 9 * 32 * 4, U_NB = (U_NVB + 255) / 256;          // 1152 -> 5
 constexpr int U_A_BYTES = ((U_PH * U_PW * ROWB + 15) / 16) * 16;       // 23760
 // Step geometry by RW = m rows per wave (r05).  RW = 2 is the round-3 / round-4 kernel: 8 m rows per step, T tile [16][64], 81.6 KB of LDS and
