@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #define ROWB 80
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void upfir_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int PH = 9, PW = 33;              // x patch: rows my0-1 .. my0+7, cols mx0-1 .. mx0+31
@@ -342,9 +343,10 @@ __device__ __forceinline__ int u_fir_col(int ci) { return ci ^ (((ci >> 2) ^ (ci
 // GRID = true: shared weights, candidates on a virtual grid, per-image operands through the LDS tables.
 // GRID = false: per-sample weights (which carry style and demodulation): one candidate per grid, no tables, no index
 // divisions — the 512^2 / 1024^2 layers are instruction-issue bound, every instruction per step counts.
-template <bool GRID, int RW = 2>
+template <bool GRID, int RW = 2, bool BS = false>
 __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo g) {
     static_assert(RW == 2 || !GRID, "the half-height step exists for the single-image instance only");
+    static_assert(!BS || !GRID, "the buffer-store form exists for the single-image instance only");
     using US = UStep<RW>;
     constexpr int MR = US::MR, TR = US::TR;
     constexpr int PW = U_PW, NA = US::NA, NVB = U_NVB, NB = U_NB, A_BYTES = US::A_BYTES;
@@ -353,6 +355,17 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
     char* As = smem;
     char* Bs = smem + A_BYTES;
     half_t* T = (half_t*)smem;                  // [TR][64][32] fp16, overlays the staging area afterwards
+    // workgroup barrier of the K loop / T overlay.  BS (r05 experiment, single-image instance): LDS-only — a __syncthreads() also waits
+    // vmcnt(0), i.e. for the previous step's 16 row stores, at the FIRST barrier of the next step; the counted waits hipcc places in front
+    // of each operand's first use are all the K loop needs from global memory
+    auto kbar = [&]() {
+        if (BS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
+    };
 
     // ---- work item: XCD xcd owns n-tile group xcd % G and pixel slice xcd / G ---------------------------------------
     const int id = blockIdx.x;
@@ -569,18 +582,18 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
         };
         const int n_stages = p.Cin >> 5;
         for (int s = 0; s + 1 < n_stages; ++s) {
-            if (s > 0) __syncthreads();
+            if (s > 0) kbar();
             store_a(s * 32);
             store_b();
-            __syncthreads();
+            kbar();
             load_a((s + 1) * 32);
             load_b((s + 1) * 32);
             mfma_block();
         }
-        if (n_stages > 1) __syncthreads();
+        if (n_stages > 1) kbar();
         store_a((n_stages - 1) * 32);
         store_b();
-        __syncthreads();
+        kbar();
 
         const int ovy0 = Y0 + TR * step - 4;                       // virtual output row of T row 0 (negative / not emitted in step 0)
         if (GRID) {
@@ -718,7 +731,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
 #pragma unroll
                 for (int r = 0; r < TR; ++r) *(float*)(smem + U_OFF_LNZ + (r * 60 + oxl) * 4) = p.noise_strength * nzr[r];
             }
-            __syncthreads();   // everyone is done with the staging area: overlay T
+            kbar();            // everyone is done with the staging area: overlay T
             if (U_ABL(2)) { if (acc[0][0][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
             {
                 char* tw = (char*)T + ((2 * wave * RW) * 64 + lr) * 64 + kh * 8;          // column 2 lr + (ph & 1) -> position (ph & 1) * 32 + lr
@@ -737,7 +750,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                             *(h4*)(tw + so[gq] + ((2 * i + (ph >> 1)) * 64 + (ph & 1) * 32) * 64) = o;
                         }
             }
-            __syncthreads();
+            kbar();
             // stage 0 of the NEXT step: its operands travel while this step's FIR runs (the step is latency-bound: two exposed
             // global round trips + the store drain at the step barrier were ~2/3 of its 14 us on the two-stage 1024^2 layer)
             if (g.prefetch && step + 1 < g.S && Y0 + TR * (step + 1) - 4 < out_rows) {
@@ -766,6 +779,10 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                 }
                 const long long rowpitch = (long long)p.Wo * p.Cout;
                 half_t* yp = p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)
+                // buffer form: descriptor over this image's output map (uniform), 32-bit byte offset per lane
+                const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)img0 * p.Ho * p.Wo * p.Cout), 0,
+                                                                                      (int)((long long)p.Ho * p.Wo * p.Cout * 2), 0x00020000);
+                unsigned yoff = (unsigned)((((long long)ovy0 * p.Wo + ox) * p.Cout + n0 + cg * 8) * 2);   // (wraps for the rows of step 0 that are not written)
                 // (software-pipelined like the grid instance's loop above: row r + 1's T vectors and noise value are requested before row r
                 // is filtered, only the store is predicated — the plain loop had TWO exposed LDS round trips per row)
                 h8 cv[4];
@@ -787,7 +804,14 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                     h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
                     v = __builtin_elementwise_max(v, v * slope) * kps;
                     if (U_ABL(8)) v = cv[0];
-                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
+                    if (BS) {
+                        // UNCONDITIONAL buffer store, rows that must not be written get an out-of-range offset (the hardware drops them): the
+                        // number of memory operations in flight is then static, so the wait in front of the next step's prefetched operands is a
+                        // counted vmcnt(16) that lets the row stores keep draining (a store under a branch forces vmcnt(0))
+                        const unsigned off = ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) ? yoff : 0xFFFFFFF0u;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), yrsrc, off, 0, 0);
+                        yoff += (unsigned)rowpitch * 2u;
+                    } else if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);
                     if (r + 1 < TR) {
@@ -860,6 +884,19 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
     g.prefetch = prefetch ? 1 : 0;
     static const int ablate = glass_knob("GLASS_UPFIR_ABLATE") ? atoi(glass_knob("GLASS_UPFIR_ABLATE")) : 0;
     g.ablate = ablate;
+#ifdef GLASS_AB_KNOBS
+    // (r05 experiment, developer build) bit 0: unconditional buffer stores + LDS-only barriers (template instance BS), bit 1: operand prefetch
+    static const int bstore = glass_knob("GLASS_UPFIR_BSTORE") ? atoi(glass_knob("GLASS_UPFIR_BSTORE")) : 0;
+    if (lean && (bstore & 2)) g.prefetch = 1;
+    if (lean && RW == 2 && (bstore & 1)) {
+        static DevOnce once_bs;
+        once_bs.run([&] { (void)hipFuncSetAttribute((const void*)upfir2_kernel<false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+        if (p.dry_run) return "upfir2_kernel<false,2,true>";
+        const int Pp_ = 8 / ng;
+        hipLaunchKernelGGL((upfir2_kernel<false, 2, true>), dim3(8 * ((g.WT + Pp_ - 1) / Pp_) * (g.NTn / ng)), dim3(256), LDS, st, p, g);
+        return "upfir2_kernel<false,2,true>";
+    }
+#endif
     g.invPX = u_inv(PX); g.invPY = u_inv(PY); g.inv2PX = u_inv(2 * PX); g.inv2PY = u_inv(2 * PY);
     const char* name = !lean ? "upfir2_kernel<true>" : RW == 2 ? "upfir2_kernel<false>" : "upfir2_kernel<false,1>";
     if (p.dry_run) return name;
