@@ -85,7 +85,16 @@ struct D0Params {
     half_t* y;            // [B][R/2][R/2][64]
     int B, R;
     unsigned long long* trace;   // dev build (make TRACE=1, GLASS_D0_TRACE): phase timestamps of workgroup 0
+    int skew;             // start delay (units of ~1000 clocks) of the second half of the grid: de-synchronises the two workgroups of a CU
+    int ablate;           // developer build only (make AB=1, GLASS_D0_ABLATE): timing experiments that switch phases off — 1 image loads,
+                          // 2 P1 (fromRGB MFMA + lrelu + patch writes), 4 P2 (skip-input FIR), 8 conv0 MFMAs, 16 conv0 epilogue + horizontal FIR,
+                          // 32 P4 (vertical FIR), 64 conv1 + skip MFMAs, 128 output stores.  WRONG RESULTS.
 };
+#ifdef GLASS_AB_KNOBS
+#define D0_ABL(bit) (p.ablate & (bit))
+#else
+#define D0_ABL(bit) false
+#endif
 // phases: 0 top, 1 after B0, 2 patch written, 3 after B1, 4 P2 done, 5 conv0 MFMAs done, 6 ring written, 7 after B2, 8 P4 done, 9 after B3,
 // 10 conv1 MFMAs done, 11 stores issued
 #define D0TRACE(ph)                                                                                          \
@@ -190,6 +199,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     // when the operand is built)
     float yv[4][3];
     auto load_image = [&](const Item& c) {
+        if (D0_ABL(1)) return;
         const int t = opaque(threadIdx.x);
         const int y0 = 4 * c.k + 1, x0 = 60 * c.tx - 3;
         const long long hw = (long long)R * R;
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
         D0TRACE(1);
         // ---- P1: fromRGB of this wave's patch blocks -> F: one MFMA per 32 pixels, lrelu in packed fp16, four 8-byte stores per lane -------
-        {
+        if (!D0_ABL(2)) {
             const int t = opaque(threadIdx.x), lr1 = t & 31, kh1 = (t >> 5) & 1, wv = uni(t >> 6);
             f16x zacc;
 #pragma unroll
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         // pixels x 2 chunks are dealt (pixel = lane / 2, chunk = nh * 2 + lane % 2): a stride-2 pixel walk touches every other 64-byte
         // window, so sixteen consecutive lanes must bring two chunks each to cover all sixteen 16-byte bank groups (the image goes
         // through LDS to the skip MFMAs anyway, so this phase's lane mapping is free) ----
-        {
+        if (!D0_ABL(4)) {
             const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + (lane & 1), lrx = lane >> 1;
             h8 hr[4];
             const int fc0 = min(2 * lrx + 2, FC - 4);
@@ -310,9 +320,10 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
                         for (int blk = 0; blk < 2; ++blk) d[kk * 2 + blk] = *(const h8*)(smem + fb[kx][kk] + ky * (FP * 64) + blk * 2048);
                 };
-                rd4(0, xq[0]);
+                if (!D0_ABL(8)) rd4(0, xq[0]);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    if (D0_ABL(8)) break;
                     if (tap + 1 < 9) rd4(tap + 1, xq[(tap + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -343,6 +354,9 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                         }
                     }
                 };
+                if (D0_ABL(16)) {
+                    if (acc[0][0] == 12345.678f) p.y[0] = (half_t)1.f;
+                } else {
                 if (edge) epi0(true);
                 else epi0(false);
                 D0TRACE(12);
@@ -360,6 +374,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int i = 0; i < 4; ++i)
                     if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
                 __builtin_amdgcn_wave_barrier();
+                }
             }
         }
         D0TRACE(6);
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 4 = blurred rows 4k .. 4k + 4) -----------------------------------
         {
             const int t = opaque(threadIdx.x);
-            if (t < 244) {
+            if (t < 244 && !D0_ABL(32)) {
                 const int base = uni((4 * k + RING) & (RING - 1));                      // ring slot of window row 0 (h row 4k - 2)
                 h8 v[8];
 #pragma unroll
@@ -400,10 +415,10 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) d[kk] = *(const h8*)(smem + sb[kx][kk] + ky * ROWB);
             };
-            rd2(0, xq[0]);
-            rd2(1, xq[1]);
+            if (!D0_ABL(64)) { rd2(0, xq[0]); rd2(1, xq[1]); }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                if (D0_ABL(64)) break;
                 if (tap + 2 < 9) rd2(tap + 2, xq[(tap + 2) % 3]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -422,7 +437,8 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             }
             const int xslot = uni((2 * k + r) % 3);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);
+            for (int kk = 0; kk < 2; ++kk)
+                if (!D0_ABL(64)) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);
             // transposition through the wave's row image (32 px x 64 B), then 16-byte stores in row order
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -438,7 +454,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
                 const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
-                if (pix < TW && 30 * tx + pix < Ro && orow < Ro) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
+                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && !D0_ABL(128)) *(h8*)(yrow + (long long)pix * 64 + chv * 8) = d;
             }
             __builtin_amdgcn_wave_barrier();
             D0TRACE(11);
@@ -447,6 +463,12 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     };
 
     __syncthreads();           // constants staged
+    if (p.skew > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+        // the two workgroups of a CU start together and run identical phases: in lock-step their MFMA phases meet on the same matrix pipe
+        // and their VALU phases on the same issue port; the second half of the grid (the second workgroup of every CU under round-robin
+        // placement) starts half a step late
+        for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(16);     // 16 x 64 clocks
+    }
     Item cur = next_item();
     load_image(cur);
     for (;;) {
@@ -470,6 +492,10 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     D0Params p;
     p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
     p.trace = nullptr;
+    static const int ablate = glass_knob("GLASS_D0_ABLATE") ? atoi(glass_knob("GLASS_D0_ABLATE")) : 0;
+    p.ablate = ablate;
+    static const int skew = glass_knob("GLASS_D0_SKEW") ? atoi(glass_knob("GLASS_D0_SKEW")) : 0;
+    p.skew = skew;
     const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 4;
     const long long n_steps = (long long)B * tiles_x * tiles_y;
     if (n_steps >= (1LL << 30)) return nullptr;
