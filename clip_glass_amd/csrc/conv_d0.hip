@@ -501,7 +501,19 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     if (n_steps >= (1LL << 30)) return nullptr;
     static DevOnce once;
     once.run([&] { (void)hipFuncSetAttribute((const void*)dblock0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
-    const int slots = 2 * glass_cu_count();       // two 256-thread workgroups per CU (79 KB of LDS each)
+    int slots = 2 * glass_cu_count();             // two 256-thread workgroups per CU (79 KB of LDS each)
+    int lds_bytes = LDS_BYTES;
+#ifdef GLASS_AB_KNOBS
+    // developer build: ONE workgroup per CU (LDS request raised so that a second one cannot be placed) — does a workgroup's step get
+    // shorter when it has the CU to itself (the pipes are contended) or not (each workgroup is latency-bound and co-residency is free)?
+    static const bool one_wg = glass_knob("GLASS_D0_ONE_WG") != nullptr;
+    if (one_wg) {
+        slots = glass_cu_count();
+        lds_bytes = 120 * 1024;
+        static DevOnce once1;
+        once1.run([&] { (void)hipFuncSetAttribute((const void*)dblock0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); });
+    }
+#endif
     const int per_block = (int)((n_steps + slots - 1) / slots);
     const int grid = (int)((n_steps + per_block - 1) / per_block);
 #ifdef GLASS_DEV_TRACE      // dev build (make TRACE=1): traced instance, stamps of workgroup 0 to a file; synchronises, single engine only
@@ -528,6 +540,6 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
         return "dblock0_kernel<trace>";
     }
 #endif
-    hipLaunchKernelGGL(dblock0_kernel<false>, dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
+    hipLaunchKernelGGL(dblock0_kernel<false>, dim3(grid), dim3(NTHR), lds_bytes, st, p, tiles_x, tiles_y, (int)n_steps, per_block);
     return "dblock0_kernel";
 }

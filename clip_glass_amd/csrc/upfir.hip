@@ -902,7 +902,17 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
     if (p.dry_run) return name;
     const int Pp = 8 / ng;
     const int grid = 8 * ((g.WT + Pp - 1) / Pp) * (g.NTn / ng);
-    if (lean) hipLaunchKernelGGL((upfir2_kernel<false, RW>), dim3(grid), dim3(256), LDS, st, p, g);
+    int lds_req = LDS;
+#ifdef GLASS_AB_KNOBS
+    // developer build: one workgroup per CU (LDS request raised): is a workgroup's step shorter when it has the CU to itself?
+    static const bool one_wg = glass_knob("GLASS_UPFIR_ONE_WG") != nullptr;
+    if (one_wg && lean) {
+        lds_req = 120 * 1024;
+        static DevOnce once1;
+        once1.run([&] { (void)hipFuncSetAttribute((const void*)upfir2_kernel<false, RW>, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024); });
+    }
+#endif
+    if (lean) hipLaunchKernelGGL((upfir2_kernel<false, RW>), dim3(grid), dim3(256), lds_req, st, p, g);
     else if (RW == 2) hipLaunchKernelGGL((upfir2_kernel<true, 2>), dim3(grid), dim3(256), LDS, st, p, g);
     else return nullptr;
     return name;
