@@ -269,6 +269,8 @@ def bench_gpt2(args):
                              decode_ms_per_population=dec_ms / args.steps, algorithmic_bytes_per_decode=bytes_per_decode))
     print(json.dumps(out))
     eng.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)          # the generated BPE tables
 
 
 def run_legs(args):
