@@ -489,3 +489,16 @@ def test_bench_kernel_labels_resolve_to_pmc_rows():
     fam = bench.family_table({"upfir2_kernel<false>": dict(launches=2, total_ms=3.4, flops=1.2e12, bytes=9.6e9),
                               "D.blur.r512": dict(launches=1, total_ms=0.8, flops=0.0, bytes=4.3e9)}, 31.0, table)
     assert [r["kernel"] for r in fam["rows"]] == ["upfir2_kernel<false>", "D.blur.r512"] and all(r["traffic_ratio"] for r in fam["rows"])
+
+
+def test_release_library_has_no_environment_knobs():
+    """VERDICT r4 / release hygiene: the product library reads NO environment variable — the GLASS_* A/B knobs, the phase-ablation and
+    experiment switches exist in the developer build only (`make -C clip_glass_amd/csrc AB=1` -> tools/lib/libglass_ab.so).  The release
+    binary therefore contains no knob name and does not import getenv."""
+    import subprocess
+    blob = open(engine.LIB_PATH, "rb").read()
+    assert b"GLASS_" not in blob, "a GLASS_* knob name is compiled into the release library"
+    syms = subprocess.run(["nm", "-D", "--undefined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    assert not os.path.exists(os.path.join(os.path.dirname(engine.LIB_PATH), "libglass_a.so"))          # developer libraries live under
+    assert not os.path.exists(os.path.join(os.path.dirname(engine.LIB_PATH), "libglass_trace.so"))      # tools/lib/, never in the package
