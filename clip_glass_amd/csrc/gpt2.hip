@@ -207,6 +207,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, i
 // factor (part[z][M][N], fixed-order sum in splitk_reduce_kernel) stays small; the NK partial blocks meet through LDS in a fixed order.
 // Operands are ordered (a = activations, b = weights): a lane holds ONE column n for rows m = mfma32_row, stores are coalesced along n.
 #define GS_KC 64
+// Weight fragments of the single-token steps.  Non-temporal loads (MI355X_MICROARCH.md price list, row nt-weights: for weights that ONE CU
+// reads once) were measured here and LOSE (r05, same box: decode 27.7 -> 32.1 ms per population): the two row-block waves of a workgroup
+// read the same fragments, and the second one finds them in the L1 only with the default policy.  -DGLASS_GPT2_NT rebuilds the experiment.
+#ifdef GLASS_GPT2_NT
+#define GS_WLOAD(p) __builtin_nontemporal_load((const f4*)(p))
+#else
+#define GS_WLOAD(p) (*(const f4*)(p))
+#endif
 // LNX: the activation operand is LayerNorm(A) (model.py:15-28), applied to the fragments in registers: (a - mean[m]) * rstd[m] * g[k] + b[k] with
 // the row statistics from gpt2_finalize_kernel (same arithmetic as layernorm_kernel) and g / b of the workgroup's K slice parked in LDS —
 // the separate LayerNorm launch and its [M][D] round trip are gone.
@@ -228,7 +236,7 @@ __global__ __launch_bounds__(128 * NK) void gemm_f32_stream_kernel(const float* 
     auto load = [&](int c, int set) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+            wr[set][b] = GS_WLOAD(wrow + c * GS_KC + 8 * b);
             xr[set][b] = *(const f4*)(xrow + c * GS_KC + 8 * b);
         }
     };
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(64 * NK) void gemm_f32_rowblk_kernel(const float* A
     auto load = [&](int c, int set) {
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+            wr[set][b] = GS_WLOAD(wrow + c * GS_KC + 8 * b);
             xr[set][b] = *(const f4*)(xrow + c * GS_KC + 8 * b);
         }
     };
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(64 * HD_NW) void gpt2_head_kernel(const float* A, c
     f4 wr[2][8];
     auto load_w = [&](int c, int set) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b) wr[set][b] = *(const f4*)(wrow + c * GS_KC + 8 * b);
+        for (int b = 0; b < 8; ++b) wr[set][b] = GS_WLOAD(wrow + c * GS_KC + 8 * b);
     };
     f16x acc[2];
 #pragma unroll
