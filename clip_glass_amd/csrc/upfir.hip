@@ -289,7 +289,8 @@ struct UpGeo {
     int prefetch;              // GRID = false: fetch the next step's stage-0 operands under this step's FIR (A/B knob)
     int ablate;                // developer build only (make AB=1, GLASS_UPFIR_ABLATE): timing experiments that switch phases of the single-image
                                // instance off — 1 MFMAs, 2 T write + FIR + stores, 4 global stores, 8 FIR arithmetic, 16 operand loads, 32 weight loads after a
-                               // segment's first step, 64 patch loads, 128 weight LDS writes after the first step.  WRONG RESULTS.
+                               // segment's first step, 64 patch loads, 128 weight LDS writes after the first step (WRONG RESULTS); 256: no request of the next step's stage 0
+                               // behind the FIR (correct results: the r04 order, addresses derived and loads issued after the step barrier).
 };
 #ifdef GLASS_AB_KNOBS
 #define U_ABL(bit) (!GRID && (g.ablate & (bit)))
@@ -821,6 +822,25 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                     }
                 }
                 *(h8*)(hs_slot) = hs[1]; *(h8*)(hs_slot + 16) = hs[2]; *(h8*)(hs_slot + 32) = hs[3];
+            }
+            // (r05) stage 0 of the NEXT step is requested HERE, behind the FIR and ahead of the step barrier: the loads go to registers
+            // that are free from here on, travel across the barrier, and their addresses cost five adds — an interior step follows an
+            // interior step MR rows further down, so the full address derivation (aim(): ~300 VALU instructions with divisions, which
+            // sat between the barrier and the first load of every step) only runs at the image borders.  Weights first: their addresses
+            // do not depend on the step.
+            if (!have && step + 1 < g.S && Y0 + TR * (step + 1) - 4 < out_rows && !U_ABL(256)) {
+                const int my0n = my0 + MR;
+                const bool plain_n = mx0 >= 1 && my0n >= 1 && my0n + MR - 1 < p.H && mx0 + 31 < p.W;
+                load_b(0);
+                if (plain && plain_n) {
+                    const int dstep = MR * p.W * p.Cin;
+#pragma unroll
+                    for (int k = 0; k < NA; ++k) a_goff[k] += dstep;
+                } else {
+                    aim(my0n, 0);
+                }
+                load_a(0);
+                have = true;
             }
         }
     }
