@@ -36,7 +36,9 @@ struct Geo {
     static constexpr int OFF_C = OFF_B + 3 * (3 * NT * 64);      // epilogue constants [3][NT] floats
     static constexpr int OFF_S = OFF_C + 3 * NT * 4;             // this sample's style row, Cin <= 1024 halfs
     static constexpr int OFF_T = OFF_S + 2048;                   // TRGB: compact toRGB weight rows [hi r,g,b | lo r,g,b][NT] fp16
-    static constexpr int LDS_BYTES = OFF_T + 6 * NT * 2;
+    static constexpr int OFF_N = OFF_T + 6 * NT * 2;             // persistent form: the tile's noise values [8 waves][2 rows][32 px] fp32
+    static constexpr int LDS_BYTES = OFF_N + 8 * 64 * 4;
+    static_assert(LDS_BYTES <= 163840, "one workgroup per CU");
 };
 constexpr int NB = 3 * NT * 4 / NTHR;                    // 3 DMA loads per thread per stage
 constexpr int B_BYTES = 3 * NT * 64;                     // 24576
@@ -50,6 +52,10 @@ typedef __attribute__((address_space(1))) const void gbl_void;
 __device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base) {
     // LDS destination = wave-uniform base + lane * 16
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void dma4(const float* src, char* lds_wave_base) {     // LDS destination = wave-uniform base + lane * 4
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 4, 0, 0);
 }
 
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
@@ -314,8 +320,32 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 // buffer and nowhere else: the output transposition goes through it in four 32-channel slices (4 KB + pad per wave).
 // XS: ConvParams::xs_out — FIR 4x4 (pad 1) + ::2 of the INPUT map (the D block's skip-branch input) from the patch of each chunk as it
 // becomes visible: 8 x 16 pixels x 4 parts = one vector per thread per chunk (n tile 0 only); its store is one more op in the wait counts.
-// ST: the layer is modulated (ConvParams::sn16) — a template parameter so that the K loop is ONE straight-line body: with the test inside,
-// every sub-step is its own basic block and the waits between them fall back to lgkmcnt(0).
+// ST: the layer is modulated (ConvParams::sn16) — a template parameter so that the K loop is ONE straight-line body.
+//
+// Round 6: the K loop is a PING-PONG of the workgroup's two wave groups (waves 0-3 | 4-7: one wave of each per SIMD).  Rounds 2-5 ran
+// every wave through the same software-pipelined stage (48 MFMAs, fragment reads rolled in between them, one barrier per stage) and
+// sat at 52-62 % MFMA-busy: two in-order waves on a SIMD that both interleave LDS reads, waits and MFMAs leave the matrix pipe idle
+// whenever both wait.  Now a PHASE = one tap of one 32-channel chunk = 16 MFMAs per wave on 12 fragments, and each group alternates
+//     load interval:  this phase's 12 ds_read_b128, lgkmcnt(0)
+//     barrier
+//     MFMA interval:  16 back-to-back MFMAs from registers at s_setprio 1, the <= 2 LDS-DMA pieces of the ring issued behind the 4th
+//     barrier
+// with group 1 ONE barrier behind group 0: on every SIMD one wave streams MFMAs while its partner fetches (the guide's 8-phase GEMM
+// schedule, cdna_hip_programming.md section 5 "256^2 8-phase template").  Measured (DESIGN section 5 "Round 6"): the 512-channel layer
+// spends 1.385 M shader clocks where MFMAs + barriers alone spend 1.377 M — the loop is matrix-pipe-bound in CYCLES; what is left is
+// the clock: 1.60-1.69 GHz with fragment reads and the ring running, 2.2 GHz without them (the chip's power budget).  Ring pieces at the
+// top of the load interval (the first form) cost 12 % against rounds 2-5; inside the MFMA interval the family is 8 % faster than it was.
+// Ring rules in phase units (q = phase within a chunk, 0..8; all fragment reads of a phase are complete before that phase's first
+// barrier, so a buffer is free one barrier after its last reading phase):
+//     weights of stage s + 2 (slot (s + 2) % 3, last read in stage s - 1): one piece in each phase of stage s;
+//     patch of chunk c + 1 (buffer (c + 1) & 1, last read in chunk c - 1): one piece in each of the chunk's phases 0..4;
+//     the wave's pieces of stage s + 1 (and, before a chunk's first stage, of its patch) are waited for in stage s's LAST phase, ahead of
+//     its first barrier: every wave passes that barrier before any wave reads stage s + 1.  In-order vmcnt: the pieces issued behind
+//     the last piece of stage s + 1 at that point are 4 (q = 2) / 5 (q = 5) / 2 (q = 8) — constants, because the ring never branches:
+//     the last item of a workgroup "prefetches" itself again, into buffers nobody reads any more.
+// Epilogue operands (per-channel constants, noise, toRGB table) are LDS-DMA pieces too, requested at q = 6 of the last chunk AHEAD of
+// that phase's ring piece: the q = 8 wait covers them, the next item's stage-1 weights stay in flight through the epilogue (rounds 2-5:
+// vmcnt(0) at the top of every epilogue), and no register of the kernel is the destination of a global load while the ring runs.
 template <bool TRGB, bool XS = false, bool ST = true>
 __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NTn, int tiles_x, int tiles_y, int PT) {
     constexpr int TW = 32;
@@ -323,13 +353,15 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
     constexpr int RW = G::RW, TH = G::TH, PW = G::PW, NVA = G::NVA, NA = G::NA, A_BYTES = G::A_BYTES, OFF_B = G::OFF_B,
                   OFF_C = G::OFF_C, OFF_S = G::OFF_S;
     static_assert(RW == 2 && 8 * RW * 32 * 80 <= A_BYTES, "the sliced output image fits one patch buffer");
+    static_assert(NA == 5 && NB == 3, "ring pieces per phase: one weight piece per phase of a stage, one patch piece in phases 0..4 of a chunk");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (lane geometry is re-derived per phase from an opaque copy of the thread id: as invariants of the item loop these values and
     // every address built from them are hoisted above the K loop, where the register file is full, and spilled)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wave >> 2;                 // 0: waves 0-3 lead; 1: waves 4-7 run one barrier behind
     const int tpi = tiles_x * tiles_y;
     const int n_work = ((PT + 7) & ~7) * NTn;
-    struct Item { int b, ty0, tx0, n0; bool valid; };
+    struct Item { int b, ty0, tx0, n0, valid; };   // (no padding bytes: a struct copy with padding goes through scratch = VMEM ops in the ring)
     auto decode = [&](int id) {   // work item -> (pixel tile, n tile): the n tiles of one pixel tile sit on one XCD (id % 8)
         Item w;
         const int lo = id & 7, rest = id >> 3;
@@ -351,8 +383,8 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
     // ---- DMA sources of the item being LOADED (the current item, or the next one near the end of a tile) ----------------
     const half_t* xb = p.x;
     const half_t* wb = p.w;
-    long long a_src[NA];      // element offset into the image, or -1 = zero page
-    long long b_src[NB];      // element offset of (tap-in-row tx, n, chunk) within one tap row, without ty / c0
+    int a_src[NA];            // element offset into the image (< 2^31: launcher), or -1 = zero page
+    int b_src[NB];            // element offset of (tap-in-row tx, n, chunk) within one tap row, without ty / c0
     auto aim_a = [&](const Item& w) {
         const int t = opaque(threadIdx.x);
         xb = p.x + (long long)w.b * p.x_bstride;
@@ -363,7 +395,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             const int iy = w.ty0 - 1 + pr, ix = w.tx0 - 1 + pc;
             const int lc = (v & 3) ^ ((pix >> 2) & 3);
             const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_src[k] = ok ? ((long long)iy * p.W + ix) * p.Cin + lc * 8 : -1;
+            a_src[k] = ok ? (iy * p.W + ix) * p.Cin + lc * 8 : -1;
         }
     };
     auto aim_b = [&](const Item& w) {
@@ -374,23 +406,18 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             const int v = k * NTHR + t, row = v >> 2;          // row = tx * 128 + n
             const int tx = row >> 7, n = row & 127;
             const int lc = (v & 3) ^ ((row >> 2) & 3);
-            b_src[k] = ((long long)tx * p.Neff + w.n0 + n) * p.Cin + lc * 8;
+            b_src[k] = (tx * p.Neff + w.n0 + n) * p.Cin + lc * 8;
         }
     };
-    auto issue_a = [&](int c, int buf) {
-        char* dst = smem + buf * A_BYTES + wave * 1024;
-#pragma unroll
-        for (int k = 0; k < NA; ++k)
-            dma16(a_src[k] >= 0 ? xb + a_src[k] + c * 32 : g_zero_page + (threadIdx.x & 3) * 8, dst + k * (NTHR * 16));
+    auto issue_a1 = [&](int k, int c, int buf) {       // piece k of a patch (k is a constant wherever this is called)
+        char* dst = smem + buf * A_BYTES + wave * 1024 + k * (NTHR * 16);
+        dma16(a_src[k] >= 0 ? xb + a_src[k] + c * 32 : g_zero_page + (threadIdx.x & 3) * 8, dst);
     };
-    auto issue_b = [&](int c, int ty, int slot) {
-        char* dst = smem + OFF_B + slot * B_BYTES + wave * 1024;
-        const half_t* src = wb + (long long)ty * 3 * p.Neff * p.Cin + c * 32;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) dma16(src + b_src[k], dst + k * (NTHR * 16));
+    auto issue_b1 = [&](int k, int c, int ty, int slot) {   // piece k of a weight stage
+        char* dst = smem + OFF_B + slot * B_BYTES + wave * 1024 + k * (NTHR * 16);
+        dma16(wb + (long long)ty * 3 * p.Neff * p.Cin + c * 32 + b_src[k], dst);
     };
     const int n_chunks = p.Cin >> 5;          // even (launcher)
-    const int n_stages = n_chunks * 3;
     const half_t* Ss = (const half_t*)(smem + OFF_S);
     auto park_style = [&](int b) {            // the sample's style row (applied to the weight fragments)
         const int t = threadIdx.x;
@@ -399,18 +426,32 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
 
     aim_a(cur);
     aim_b(cur);
-    if (p.sn16) {
-        park_style(cur.b);
-        __syncthreads();
+    if (p.sn16) park_style(cur.b);
+    {   // operand arrays the layer does not have keep their neutral values for the kernel's lifetime (the epilogue reads all of them)
+        const int t = threadIdx.x;
+        float* Cc = (float*)(smem + OFF_C);
+        if (t < NT) {
+            if (!p.dscale) Cc[t] = 1.f;
+            if (!p.bias) Cc[NT + t] = 0.f;
+            if (!p.shift) Cc[2 * NT + t] = 0.f;
+        }
+        if (!p.noise) *(float*)(smem + G::OFF_N + t * 4) = 0.f;
     }
-    issue_a(0, 0);
-    issue_b(0, 0, 0);
-    issue_b(0, 1, 1);
-    for (bool first = true;; first = false) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NA; ++k) issue_a1(k, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) issue_b1(k, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) issue_b1(k, 0, 1, 1);
+    WAIT_VM(3);                                // chunk 0's patch and stage 0 landed (stage 1 travels on)
+    __builtin_amdgcn_s_barrier();
+    for (;;) {
         int nid = id + gridDim.x;
         Item nxt = decode(nid);
         while (nid < n_work && !nxt.valid) { nid += gridDim.x; nxt = decode(nid); }
         const bool has_next = nid < n_work;
+        if (!has_next) nxt = cur;              // the ring never branches: the last item re-requests itself (nobody reads those buffers)
         const int b = cur.b, ty0 = cur.ty0, tx0 = cur.tx0, n0 = cur.n0;
 
         f16x acc[RW][4];
@@ -421,151 +462,155 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-        // epilogue operands from global memory (per-channel constants, noise, toRGB table / skip taps, the next item's style row)
-        // are fetched under the LAST stage's MFMAs: at the top of the epilogue they would cost a ~2 us round trip per item
-        float c_d = 1.f, c_b = 0.f, c_s = 0.f;
-        float nzr[RW] = {0.f, 0.f};
-        float ytap[3][4];
-        h8 t6v, nsty;
+        // Epilogue operands (per-channel constants, the tile's noise values, the toRGB table) travel by LDS-DMA too, requested under the
+        // LAST stage's MFMAs ahead of that phase's ring piece: the q = 8 wait covers them, and the kernel has NO load into registers
+        // while the ring is in flight (hipcc guards every use of such a register with a wait it counts itself — vmcnt(0) here, which
+        // drained the next item's stage-1 weights at the top of every epilogue).
         auto prefetch_epilogue = [&]() {
             const int t = opaque(threadIdx.x), lr = t & 31, kh = (t >> 5) & 1;
-            const int oyb = ty0 + wave * RW, ox = tx0 + lr;
-            if (t < NT) {
-                const int o = n0 + t;
-                if (p.dscale) c_d = p.dscale[(long long)b * p.ds_stride + o];
-                if (p.bias) c_b = p.bias[o];
-                if (p.shift) c_s = p.shift[(long long)b * p.ds_stride + o];
+            if (wave < 2) {                    // channels n0 + t, t < NT = 128: [dscale | bias | shift][NT] fp32
+                char* cc = smem + OFF_C + wave * 256;
+                if (p.dscale) dma4(p.dscale + (long long)b * p.ds_stride + n0 + t, cc);
+                if (p.bias) dma4(p.bias + n0 + t, cc + NT * 4);
+                if (p.shift) dma4(p.shift + (long long)b * p.ds_stride + n0 + t, cc + 2 * NT * 4);
             }
-#pragma unroll
-            for (int i = 0; i < RW; ++i)
-                if (p.noise) nzr[i] = p.noise_strength * p.noise[((long long)(b / p.batch_size) * p.Ho + oyb + i) * p.Wo + ox];
-            if (TRGB) {
-                if (t < 6 * (NT / 8)) {
-                    const int row6 = t / (NT / 8), piece = t % (NT / 8);
-                    const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
-                    t6v = *(const h8*)(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8);
-                }
-                if (p.trgb_yprev) {
-                    const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-                    const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
-                }
+            if (p.noise) dma4(p.noise + ((long long)(b / p.batch_size) * p.Ho + ty0 + wave * RW + kh) * p.Wo + tx0 + lr, smem + G::OFF_N + wave * 256);
+            if (TRGB && t < 6 * (NT / 8)) {
+                const int row6 = t / (NT / 8), piece = t % (NT / 8);
+                const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
+                dma16(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8, smem + G::OFF_T + wave * 1024);
             }
-            if (has_next && p.sn16 && t < (p.Cin >> 3)) nsty = *(const h8*)(p.sn16 + (long long)nxt.b * p.sn_stride + t * 8);
         };
-        int c = 0, ty = 0;
-        for (int s = 0; s < n_stages; ++s) {
-            // DMA loads this wave issued after those this stage needs: B(s+1), and the next chunk's patch when it was issued after
-            // B(s) — "next" running on into the next work item.  After the first item, stage 0 finds its operands complete: the
-            // epilogue waited for everything in flight.
-            int younger = (s + 1 < n_stages || has_next) ? NB : 0;
-            if (ty != 0 && (c + 1 < n_chunks || has_next)) younger += NA;
-            if (XS && ty != 0 && n0 == 0) younger += 1;           // this chunk's blur-down store (issued in its ty == 0 iteration)
-            if (s > 0 || first) wait_vm(younger);
-            __builtin_amdgcn_s_barrier();
-            if (s + 2 < n_stages) {
-                int c2 = c, t2 = ty + 2;
-                if (t2 >= 3) { t2 -= 3; c2 = c + 1; }
-                issue_b(c2, t2, (s + 2) % 3);
-            } else if (has_next) {
-                if (s + 2 == n_stages) aim_b(nxt);
-                issue_b(0, s + 2 - n_stages, (s + 2) % 3);      // n_stages % 3 == 0: stage s' of the next item lives in slot s' % 3 too
-            }
-            if (ty == 0) {
-                if (c + 1 < n_chunks) issue_a(c + 1, (c + 1) & 1);
-                else if (has_next) { aim_a(nxt); issue_a(0, 0); }   // n_chunks even: chunk 0 of the next item lives in buffer 0 too
-            }
-            if (s == n_stages - 1) prefetch_epilogue();
-
+        if (grp) __builtin_amdgcn_s_barrier();     // group 1 falls one barrier behind: its load intervals face group 0's MFMA intervals
+        // (the last chunk is a second copy of the body: its ring pieces belong to the NEXT item, the sources are re-aimed and the epilogue
+        // operands are requested there — as run-time cases of ONE body the address arithmetic of aim_a / aim_b sat behind an
+        // s_waitcnt vmcnt(0), hipcc's guard for registers that the operand loads of "an earlier iteration" might still be writing)
+        auto chunk_body = [&](const int c, auto lastc_tag) {
+            constexpr bool lastc = decltype(lastc_tag)::value;
             const char* As = smem + (c & 1) * A_BYTES;
-            const char* Bs = smem + OFF_B + (s % 3) * B_BYTES;
-            if (XS && ty == 0 && n0 == 0) {
-                const int tq = opaque(threadIdx.x), part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
-                h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass
 #pragma unroll
-                for (int jy = 0; jy < 4; ++jy) {
-                    h8 a[4];
+            for (int ty = 0; ty < 3; ++ty) {
 #pragma unroll
-                    for (int jx = 0; jx < 4; ++jx) {
-                        const int P = (2 * ly + jy) * PW + 2 * lx + jx;
-                        a[jx] = *(const h8*)(As + P * 64 + ((part ^ ((P >> 2) & 3)) << 4));
+                for (int tx = 0; tx < 3; ++tx) {
+                    const int q = ty * 3 + tx;
+                    // ---- load interval ------------------------------------------------------------------------------------
+                    auto ring_pieces = [&]() {
+                        if (q == 6 && lastc) prefetch_epilogue();
+                        {   // weights: piece tx of stage s + 2 -> slot (ty + 2) % 3
+                            const int t2 = (ty + 2) % 3;
+                            int c2 = ty == 0 ? c : c + 1;
+                            if (ty != 0 && lastc) {            // runs on into the next item (n_stages % 3 == 0: same slots)
+                                if (q == 3) aim_b(nxt);
+                                c2 = 0;
+                            }
+                            issue_b1(tx, c2, t2, t2);
+                        }
+                        if (q < 5) {    // patch: piece q of chunk c + 1 (n_chunks even: chunk 0 of the next item lives in buffer 0 too)
+                            if (q == 0 && lastc) aim_a(nxt);
+                            issue_a1(q, lastc ? 0 : c + 1, lastc ? 0 : (c + 1) & 1);
+                        }
+                    };
+                    if (XS && q == 0 && n0 == 0) {
+                        const int tq = opaque(threadIdx.x), part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
+                        h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass
+                        h8 k125, k375;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { k125[e] = (half_t)0.125f; k375[e] = (half_t)0.375f; }
+#pragma unroll
+                        for (int jy = 0; jy < 4; ++jy) {
+                            h8 a[4];
+#pragma unroll
+                            for (int jx = 0; jx < 4; ++jx) {
+                                const int P = (2 * ly + jy) * PW + 2 * lx + jx;
+                                a[jx] = *(const h8*)(As + P * 64 + ((part ^ ((P >> 2) & 3)) << 4));
+                            }
+                            // (explicit FMA forms: left to -ffp-contract the compiler fused a different product from row to row and from build to
+                            // build — one fp16 ulp of the by-product, enough to move the D-logit regression guards)
+                            const h8 hr = __builtin_elementwise_fma(a[0] + a[3], k125, (a[1] + a[2]) * k375);
+                            if (jy == 0) s03 = hr;
+                            else if (jy == 1) s12 = hr;
+                            else if (jy == 2) s12 = s12 + hr;
+                            else s03 = s03 + hr;
+                        }
+                        const h8 o = __builtin_elementwise_fma(s12, k375, s03 * k125);
+                        *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + ly) * (p.W >> 1) + (tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
                     }
-                    const h8 hr = (a[0] + a[3]) * (half_t)0.125f + (a[1] + a[2]) * (half_t)0.375f;
-                    if (jy == 0) s03 = hr;
-                    else if (jy == 1) s12 = hr;
-                    else if (jy == 2) s12 = s12 + hr;
-                    else s03 = s03 + hr;
-                }
-                const h8 o = s03 * (half_t)0.125f + s12 * (half_t)0.375f;
-                *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + ly) * (p.W >> 1) + (tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
-            }
-            const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
-            // Six (tap, 16-channel half) sub-steps of 8 MFMAs.  Rolling fragment registers (r04): a weight fragment is dead after its two
-            // MFMAs, so the NEXT sub-step's fragment is read into its place right behind them, and the next pixel fragments (two extra
-            // registers sets of 4) at the top of the sub-step — every read of sub-step u + 1 is issued between the MFMAs of sub-step u and
-            // has 6-8 MFMAs (200-250 cycles) to land; only the first sub-step of a stage waits for a whole LDS round trip.  (hipcc still closes
-            // every sub-step with s_waitcnt lgkmcnt(0), i.e. it also waits for the two pixel fragments it has just requested: a spare weight
-            // register set to issue everything earlier was re-ordered by the scheduler into the same pattern.)  conv_gldsp layers 8.28 -> 8.02 ms.
-            {
-                h8 wf[4], xf[RW], xn[RW], sv, svn;
-                auto rdw = [&](int u, int j) {
-                    const int tx = u >> 1, lc = (u & 1) * 2 + kh, row = tx * NT + j * 32 + lr;
-                    return *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
-                };
-                auto rdx = [&](int u, int i) {
-                    const int tx = u >> 1, lc = (u & 1) * 2 + kh, pix = (wave * RW + i + ty) * PW + lr + tx;
-                    return *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
-                };
-                auto rds = [&](int u) { return *(const h8*)(Ss + c * 32 + ((u & 1) * 2 + kh) * 8); };
+                    h8 wf[2][4], xf[2][RW];
+                    {
+                        const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
+                        const char* Bs = smem + OFF_B + ty * B_BYTES;        // slot of stage s = 3 c + ty
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wf[j] = rdw(0, j);
-                if (ST) sv = rds(0);
+                        for (int kk = 0; kk < 2; ++kk) {
+                            const int lc = kk * 2 + kh;
 #pragma unroll
-                for (int i = 0; i < RW; ++i) xf[i] = rdx(0, i);
+                            for (int j = 0; j < 4; ++j) {
+                                const int row = tx * NT + j * 32 + lr;
+                                wf[kk][j] = *(const h8*)(Bs + row * 64 + ((lc ^ ((row >> 2) & 3)) << 4));
+                            }
 #pragma unroll
-                for (int u = 0; u < 6; ++u) {
-                    if (u < 5) {
+                            for (int i = 0; i < RW; ++i) {
+                                const int pix = (wave * RW + i + ty) * PW + lr + tx;
+                                xf[kk][i] = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
+                            }
+                            if (ST) {
+                                const h8 sv = *(const h8*)(Ss + c * 32 + lc * 8);
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) xn[i] = rdx(u + 1, i);
-                        if (ST) svn = rds(u + 1);
+                                for (int j = 0; j < 4; ++j) wf[kk][j] = wf[kk][j] * sv;
+                            }
+                        }
                     }
+                    // the wave's ring pieces of stage s + 1 (and of the next chunk's patch, older) have landed before ANY wave passes this
+                    // phase's first barrier; pieces issued behind them: 6 / 6 / 3 (the by-product's store is not counted: conservative)
+                    if (tx == 2) { if (ty == 2) WAIT_VM(2); else if (ty == 1) WAIT_VM(5); else WAIT_VM(4); }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    // ---- MFMA interval ------------------------------------------------------------------------------------
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const h8 w = ST ? wf[j] * sv : wf[j];
+                    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) acc[i][j] = mfma32(w, xf[i], acc[i][j]);
-                        if (u < 5) wf[j] = rdw(u + 1, j);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (u < 5) {
+                        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) xf[i] = xn[i];
-                        if (ST) sv = svn;
-                    }
+                            for (int i = 0; i < RW; ++i) acc[i][j] = mfma32(wf[kk][j], xf[kk][i], acc[i][j]);
+                            if (kk == 0 && j == 1) { __builtin_amdgcn_sched_barrier(0); ring_pieces(); __builtin_amdgcn_sched_barrier(0); }
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
                 }
             }
-            if (++ty == 3) { ty = 0; ++c; }
-        }
+        };
+        for (int c = 0; c + 1 < n_chunks; ++c) chunk_body(c, std::false_type{});
+        chunk_body(n_chunks - 1, std::true_type{});
 
         // ---- epilogue: constants via LDS, batched noise / residual loads, row-order stores through patch buffer 1 -------------
+        // Group 0 is one barrier ahead: it re-aligns here (group 1 runs its last MFMA interval meanwhile).  Every fragment read of the
+        // item was complete before the barrier both groups have passed by then, and the q = 8 wait + barrier made the operands visible.
+        if (!grp) __builtin_amdgcn_s_barrier();
         const int t = opaque(threadIdx.x), lane = t & 63, lr = lane & 31, kh = lane >> 5;
-        float* Cc = (float*)(smem + OFF_C);
+        const float* Cc = (const float*)(smem + OFF_C);
         constexpr int OP = 80;                                      // bytes per staged pixel slice (64 + 16: bank spread)
         char* Os = smem + A_BYTES + wave * (RW * 32 * OP);
         const int oyb = ty0 + wave * RW, ox = tx0 + lr;              // lane's pixel of tile row i: (oyb + i, ox)
-        WAIT_VM(0);                            // constants landed — and with them every DMA issued so far (in-order counter)
-        __builtin_amdgcn_s_barrier();          // every wave is done with patch buffer 1, weight slot 2 and the style row
-        if (t < NT) { Cc[t] = c_d; Cc[NT + t] = c_b + c_s; }
-        if (TRGB && t < 6 * (NT / 8)) *(h8*)(smem + G::OFF_T + t * 16) = t6v;
-        if (has_next && p.sn16 && t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = nsty;
-        __syncthreads();
         const int rcs = p.res_cs ? p.res_cs : p.Cout;
         const ActK ak = act_consts(p.act, p.out_scale);
+        // loads into registers start HERE (the ring has three pieces in flight and is not waited for): values used at the END of the epilogue
+        float ytap[3][4];
+        h8 nsty;
+        if (TRGB && p.trgb_yprev) {
+            const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+            const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
+        }
+        if (ST && t < (p.Cin >> 3)) nsty = *(const h8*)(p.sn16 + (long long)nxt.b * p.sn_stride + t * 8);
+        float nzr[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) nzr[i] = p.noise_strength * *(const float*)(smem + G::OFF_N + (wave * 64 + i * 32 + lr) * 4);
         f16x rgb;
 #pragma unroll
         for (int q = 0; q < 16; ++q) rgb[q] = 0.f;
@@ -597,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             for (int g = 0; g < GB; ++g) {
                 const int nl = j * 32 + 8 * (g0 + g) + 4 * kh;
                 dq[g] = *(const f4*)(Cc + nl);
-                bq[g] = *(const f4*)(Cc + NT + nl);      // bias + shift
+                bq[g] = *(const f4*)(Cc + NT + nl) + *(const f4*)(Cc + 2 * NT + nl);      // bias + shift
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -646,10 +691,14 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                 yo[cc * hw] = r;
             }
         }
+        if (ST && t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = nsty;     // (every wave left the K loop, the style row's only reader, two barriers ago)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // every wave is done with patch buffer 1 (the output slices) and the constants
         if (!has_next) break;
         id = nid;
         cur = nxt;
     }
+    WAIT_VM(0);                                // the last item's self-prefetch
 }
 
 
