@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 1) void conv_glds_kernel(ConvParams p, int NTn
 // "one chunk ahead" mean at the end of a tile.  The epilogue therefore runs while those loads are in flight, in the one patch
 // buffer and nowhere else: the output transposition goes through it in four 32-channel slices (4 KB + pad per wave).
 // XS: ConvParams::xs_out — FIR 4x4 (pad 1) + ::2 of the INPUT map (the D block's skip-branch input) from the patch of each chunk as it
-// becomes visible: 8 x 16 pixels x 4 parts = one vector per thread per chunk (n tile 0 only); its store is one more op in the wait counts.
+// becomes visible: 8 x 16 pixels x 4 parts = one vector per thread per chunk (chunk c by the pixel tile's n tile c % NTn); its store is one more op in the queue.
 // ST: the layer is modulated (ConvParams::sn16) — a template parameter so that the K loop is ONE straight-line body.
 //
 // Round 6: the K loop is a PING-PONG of the workgroup's two wave groups (waves 0-3 | 4-7: one wave of each per SIMD).  Rounds 2-5 ran
@@ -510,7 +510,9 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                             issue_a1(q, lastc ? 0 : c + 1, lastc ? 0 : (c + 1) & 1);
                         }
                     };
-                    if (XS && q == 0 && n0 == 0) {
+                    // (the by-product of chunk c is written by the pixel tile's n tile c % NTn: with every chunk on n tile 0 the workgroups that
+                    // walk n tile 0 — a workgroup keeps its n tile from item to item — carried all of it and the others waited for them)
+                    if (XS && q == 0 && c % NTn == (n0 >> 7)) {
                         const int tq = opaque(threadIdx.x), part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = pix & 15;
                         h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass
                         h8 k125, k375;

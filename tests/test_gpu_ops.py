@@ -301,7 +301,7 @@ def test_conv_glds_persistent_matches_tiled():
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     sn = rng.uniform(-1.0, 1.0, (B, Cin)).astype(np.float32)
     check("persistent conv_glds (style on weights) vs direct", ops.conv(x, w, impl=5, sn=sn, **kw), ops.conv(x, w, impl=1, sn=sn, **kw), 4e-3)
-    # blur-down of the input as a by-product of the staged patches (two n tiles per pixel tile: only the first one writes it)
+    # blur-down of the input as a by-product of the staged patches (two n tiles per pixel tile: chunk c is written by n tile c % 2)
     xs = np.full((B, H // 2, W // 2, Cin), np.nan, dtype=np.float32)
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
     y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
