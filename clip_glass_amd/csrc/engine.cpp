@@ -163,7 +163,13 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
     // (default; GLASS_NO_CLIP_OVERLAP=1 / glass_engine_set_overlap(e, 0) put everything on one stream)
     e->clip_overlap = glass_knob("GLASS_NO_CLIP_OVERLAP") == nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->stream_d, hipStreamNonBlocking);
+    if (err == hipSuccess) {
+        // the second stream carries CLIP's ~75 short dependent launches beside the discriminator's chip-filling kernels: at the highest
+        // priority its workgroups are placed first whenever a CU has room (the main stream's persistent kernels never yield one)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        err = hipStreamCreateWithPriority(&e->stream_d, hipStreamNonBlocking, prio_hi);
+    }
     e->cur = e->stream;
     if (err == hipSuccess) err = hipEventCreate(&e->ev0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev1);
@@ -756,9 +762,22 @@ extern "C" int glass_engine_set_target(glass_engine* e, const float* feat, int32
 void collect_profile(glass_engine* e) {
     std::map<std::string, glass_prof_row> rows;
     std::vector<std::string> order;
+#ifdef GLASS_AB_KNOBS
+    // developer build: GLASS_TIMELINE=<file> appends "start end name" (ms from the pass's first event) of every instrumented launch —
+    // where the second stream's launches sit beside the main stream's (tools/layer_ab.py --mode 2)
+    FILE* tl = getenv("GLASS_TIMELINE") ? fopen(getenv("GLASS_TIMELINE"), "a") : nullptr;
+    if (tl) fprintf(tl, "# pass\n");
+#endif
     for (auto& pe : e->prof_events) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, pe.e0, pe.e1);
+#ifdef GLASS_AB_KNOBS
+        if (tl) {
+            float t0 = 0.f;
+            hipEventElapsedTime(&t0, e->ev0, pe.e0);
+            fprintf(tl, "%9.3f %9.3f %s\n", t0, t0 + ms, pe.name.c_str());
+        }
+#endif
         auto it = rows.find(pe.name);
         if (it == rows.end()) {
             glass_prof_row r;
@@ -772,6 +791,9 @@ void collect_profile(glass_engine* e) {
         it->second.flops += pe.flops;
         it->second.bytes += pe.bytes;
     }
+#ifdef GLASS_AB_KNOBS
+    if (tl) fclose(tl);
+#endif
     e->prof_rows.clear();
     for (auto& n : order) e->prof_rows.push_back(rows[n]);
     e->prof_events.clear();

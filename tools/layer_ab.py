@@ -12,6 +12,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--rows", default=".")
     ap.add_argument("--pop", type=int, default=64)
+    ap.add_argument("--mode", type=int, default=0, help="stream mode of the instrumented passes (0 one stream; 2 CLIP beside D: use ONE library per process)")
+    ap.add_argument("--timed", type=int, default=0, help="also: N un-instrumented passes per library and round in the engine's default two-stream mode, wall ms per pass")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     from clip_glass_amd import synth, engine as E
@@ -36,6 +38,7 @@ def main():
     data = {n: {} for n, _ in engs}
     for r in range(a.rounds):
         for n, eng in engs:
+            eng.set_overlap(a.mode)
             eng.set_profiling(True)
             eng.evaluate(synth.latents(1000 + r, a.pop, lat), generation=r)
             tot = 0.0
@@ -45,7 +48,25 @@ def main():
                 data[n].setdefault(row["name"], []).append(us)
             data[n].setdefault("~pass", []).append(tot)
             eng.set_profiling(False)
+            eng.set_overlap(0)
     names = [n for n, _ in engs]
+    if a.timed:
+        import time
+        wall = {n: {0: [], 2: []} for n in names}
+        pops = [synth.latents(2000 + i, a.pop, lat) for i in range(a.timed)]
+        for r in range(a.rounds):
+            for mode in (2, 0):
+                for n, eng in engs:
+                    eng.set_overlap(mode)
+                    eng.evaluate(pops[0], generation=50)
+                    t0 = time.perf_counter()
+                    for i in range(a.timed):
+                        eng.evaluate(pops[i], generation=100 + i)
+                    wall[n][mode].append((time.perf_counter() - t0) / a.timed * 1e3)
+                    eng.set_overlap(0)
+        for mode in (2, 0):
+            print("%-60s" % ("wall ms per pass, stream mode %d (median / min of %d x %d)" % (mode, a.rounds, a.timed)) +
+                  "".join("%10s" % ("%.2f/%.2f" % (float(np.median(wall[n][mode])), min(wall[n][mode]))) for n in names))
     rows = [k for k in data[names[0]] if pat.search(k) and k != "~pass"]
     print("%-60s" % ("median us per launch, %d interleaved rounds" % a.rounds) + "".join("%10s" % n[:9] for n in names))
     sums = {n: 0.0 for n in names}
