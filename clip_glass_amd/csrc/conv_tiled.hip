@@ -251,18 +251,23 @@ __global__ __launch_bounds__(256, (DEEP && NT == 64 && S == 1) ? 3 : 2) void con
                 asm volatile("" : "+v"(tq));                      // (geometry derived here, not hoisted above the MFMA blocks as loop invariants)
                 const int part = tq & 3, pix = tq >> 2, ly = pix >> 4, lx = tl_col(pix & 15);
                 h8 s03, s12;                                     // rows 0 + 3, rows 1 + 2 of the horizontal pass (one row live at a time)
+                h8 k125, k375;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { k125[e] = (half_t)0.125f; k375[e] = (half_t)0.375f; }
 #pragma unroll
                 for (int jy = 0; jy < 4; ++jy) {
                     const char* rp = As + ((2 * ly + jy) * PW + 2 * lx) * ROWB + part * 16;
                     const h8 a0 = *(const h8*)rp, a1 = *(const h8*)(rp + ROWB), a2 = *(const h8*)(rp + 2 * ROWB), a3 = *(const h8*)(rp + 3 * ROWB);
-                    const h8 hr = (a0 + a3) * (half_t)0.125f + (a1 + a2) * (half_t)0.375f;
+                    // (explicit FMA forms — the ones -ffp-contract chose in rounds 2-5: left to the compiler the fused product changes from
+                    // build to build, one fp16 ulp of the by-product, enough to move the D-logit regression guards)
+                    const h8 hr = __builtin_elementwise_fma(a1 + a2, k375, (a0 + a3) * k125);
                     if (jy == 0) s03 = hr;
                     else if (jy == 1) s12 = hr;
                     else if (jy == 2) s12 = s12 + hr;
                     else s03 = s03 + hr;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                const h8 o = s03 * (half_t)0.125f + s12 * (half_t)0.375f;
+                const h8 o = __builtin_elementwise_fma(s12, k375, s03 * k125);
                 *(h8*)(p.xs_out + (((long long)cur.b * (p.H >> 1) + (cur.ty0 >> 1) + ly) * (p.W >> 1) + (cur.tx0 >> 1) + lx) * p.Cin + c * 32 + part * 8) = o;
             }
             int nc = c, nty = ty + 1;

@@ -327,6 +327,49 @@ def test_conv_glds_persistent_matches_tiled():
     check("persistent conv_glds fused toRGB", got, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 128, 256), (1, 256, 128), (5, 128, 128), (2, 512, 512)])
+def test_conv_wres_matches_tiled(B, H, W):
+    """conv_wres.hip (64 -> 64 channels: weights resident in LDS, patches on an LDS-DMA double buffer, ping-pong K loop, contiguous tile
+    ranges per workgroup): the tiled kernel's numbers with the full epilogue, image borders through the zero page, ranges that cross
+    candidates and end unevenly; the blur-down by-product; the fused toRGB with and without the skip image."""
+    rng = np.random.default_rng(41)
+    C = 64
+    x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / math.sqrt(9 * C)).astype(np.float32)
+    ds = rng.uniform(0.5, 2.0, (B, C)).astype(np.float32)
+    noise = rng.standard_normal((B, H, W)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32) * 0.2
+    res = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
+    kw = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, res=res, out_scale=0.7)
+    got = ops.conv(x, w, impl=5, **kw)
+    ref_t = ops.conv(x, w, impl=2, **kw)
+    diag("[wres] B%d %dx%d max|wres-tiled| %.3e" % (B, H, W, np.abs(got - ref_t).max()))
+    assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
+    check("conv_wres vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
+    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, **kw))          # the ring is deterministic
+    # blur-down of the input as a by-product of the staged patches
+    xs = np.full((B, H // 2, W // 2, C), np.nan, dtype=np.float32)
+    kw2 = dict(bias=bias, act=True, out_scale=0.7)
+    y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
+    np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, **kw2))
+    f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    check("conv_wres blur-down by-product", xs, sum(f[a] * f[b2] * xp[:, a:a + H:2, b2:b2 + W:2] for a in range(4) for b2 in range(4)), 2e-3)
+    xs_t = np.full_like(xs, np.nan)
+    ops.conv(x, w, impl=2, xs_out=xs_t, **kw2)
+    np.testing.assert_array_equal(xs, xs_t)                                   # the same packed-fp16 FIR as conv_tiled<xs>
+    # fused toRGB
+    kw3 = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True)
+    wrgb = (rng.standard_normal((3, C)) / math.sqrt(C)).astype(np.float32)
+    brgb = (rng.standard_normal(3) * 0.1).astype(np.float32)
+    srgb = rng.uniform(0.2, 1.0, (B, C)).astype(np.float32)
+    smax = rng.uniform(0.5, 3.0, B).astype(np.float32)
+    feat = ops.conv(x, w, impl=5, **kw3)
+    for yprev in (rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32), None):
+        got_rgb = ops.conv(x, w, impl=5, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw3)
+        check("conv_wres fused toRGB", got_rgb, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
+
+
 @pytest.mark.parametrize("impl", [1, 2])
 def test_conv_modulated_demod_noise(impl):
     got, ref = _modconv_case(False, impl)
