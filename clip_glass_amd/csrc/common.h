@@ -114,13 +114,16 @@ inline bool glass_lds_fits(int bytes) {
     const GlassDevProps dp = glass_dev_props();
     if (bytes <= dp.lds_optin) return true;
     static std::mutex mu;
-    static int seen[16], n_seen = 0;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < n_seen; ++i)
-        if (seen[i] == bytes) return false;
-    if (n_seen < 16) seen[n_seen++] = bytes;
+    static int seen_dev[16], seen_bytes[16], n_seen = 0;
     int d = 0;
     (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n_seen; ++i)
+        if (seen_dev[i] == d && seen_bytes[i] == bytes) return false;
+    if (n_seen == 16) return false;            // table full: the last line printed said so
+    seen_dev[n_seen] = d;
+    seen_bytes[n_seen++] = bytes;
+    if (n_seen == 16) fprintf(stderr, "libglass: further LDS refusals are not reported\n");
     fprintf(stderr, "libglass: device %d offers %d B of opt-in LDS per workgroup; a kernel family that needs %d B is refused and its "
                     "layers fall back to a slower kernel (expected on gfx950: 163840 B)\n", d, dp.lds_optin, bytes);
     return false;

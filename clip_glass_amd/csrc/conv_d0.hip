@@ -84,11 +84,13 @@ struct D0Params {
     const float* b1;      // [64]
     half_t* y;            // [B][R/2][R/2][64]
     int B, R;
-    unsigned long long* trace;   // dev build (make TRACE=1, GLASS_D0_TRACE): phase timestamps of workgroup 0
-    int skew;             // start delay (units of ~1000 clocks) of the second half of the grid: de-synchronises the two workgroups of a CU
-    int ablate;           // developer build only (make AB=1, GLASS_D0_ABLATE): timing experiments that switch phases off — 1 image loads,
-                          // 2 P1 (fromRGB MFMA + lrelu + patch writes), 4 P2 (skip-input FIR), 8 conv0 MFMAs, 16 conv0 epilogue + horizontal FIR,
-                          // 32 P4 (vertical FIR), 64 conv1 + skip MFMAs, 128 output stores.  WRONG RESULTS.
+#if defined(GLASS_AB_KNOBS) || defined(GLASS_DEV_TRACE)      // developer builds only (make AB=1 / TRACE=1): the release struct carries none of these
+    unsigned long long* trace;   // GLASS_D0_TRACE: phase timestamps of workgroup 0
+    int skew;             // GLASS_D0_SKEW: start delay (units of ~1000 clocks) of the second half of the grid
+    int ablate;           // GLASS_D0_ABLATE: timing experiments that switch phases off — 1 image loads, 2 P1 (fromRGB MFMA + lrelu + patch writes),
+                          // 4 P2 (skip-input FIR), 8 conv0 MFMAs, 16 conv0 epilogue + horizontal FIR, 32 P4 (vertical FIR), 64 conv1 + skip MFMAs,
+                          // 128 output stores.  WRONG RESULTS.
+#endif
 };
 #ifdef GLASS_AB_KNOBS
 #define D0_ABL(bit) (p.ablate & (bit))
@@ -97,9 +99,13 @@ struct D0Params {
 #endif
 // phases: 0 top, 1 after B0, 2 patch written, 3 after B1, 4 P2 done, 5 conv0 MFMAs done, 6 ring written, 7 after B2, 8 P4 done, 9 after B3,
 // 10 conv1 MFMAs done, 11 stores issued
+#ifdef GLASS_DEV_TRACE
 #define D0TRACE(ph)                                                                                          \
     if (TR && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && n_item < 96)                                      \
         p.trace[(n_item * 16 + (ph)) * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime()
+#else
+#define D0TRACE(ph) (void)n_item
+#endif
 
 template <bool TR>
 __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_x, int tiles_y, int n_steps, int per_block) {
@@ -463,12 +469,14 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     };
 
     __syncthreads();           // constants staged
+#ifdef GLASS_AB_KNOBS
     if (p.skew > 0 && blockIdx.x >= (gridDim.x >> 1)) {
         // the two workgroups of a CU start together and run identical phases: in lock-step their MFMA phases meet on the same matrix pipe
         // and their VALU phases on the same issue port; the second half of the grid (the second workgroup of every CU under round-robin
         // placement) starts half a step late
         for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(16);     // 16 x 64 clocks
     }
+#endif
     Item cur = next_item();
     load_image(cur);
     for (;;) {
@@ -491,11 +499,13 @@ const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* 
     if (!dblock0_supported(R, Cin, Cout)) return nullptr;
     D0Params p;
     p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
+#if defined(GLASS_AB_KNOBS) || defined(GLASS_DEV_TRACE)
     p.trace = nullptr;
     static const int ablate = glass_knob("GLASS_D0_ABLATE") ? atoi(glass_knob("GLASS_D0_ABLATE")) : 0;
     p.ablate = ablate;
     static const int skew = glass_knob("GLASS_D0_SKEW") ? atoi(glass_knob("GLASS_D0_SKEW")) : 0;
     p.skew = skew;
+#endif
     const int Ro = R / 2, tiles_x = (Ro + TW - 1) / TW, tiles_y = R / 4;
     const long long n_steps = (long long)B * tiles_x * tiles_y;
     if (n_steps >= (1LL << 30)) return nullptr;

@@ -155,12 +155,12 @@ extern "C" int glass_engine_create(const glass_config* cfg, glass_engine** out) 
         return GLASS_ERR_ARG;
     }
     e->chunk = chunk;
-    // two-stream overlap is worth +3 % throughput but stretches every co-running kernel ~2x, which makes
-    // per-kernel profiles (rocprof, roofline) meaningless: opt-in (GLASS_OVERLAP=1 / glass_engine_set_overlap)
+    // Stream mode: glass_engine_set_overlap() is the only control in the release library (glass_knob() reads nothing there; the two
+    // variables below exist in the developer build, and bench.py translates them into set_overlap() calls for the measure_* scripts).
+    // Chunk pipelining (mode 1) stretches every co-running kernel ~2x, which makes per-kernel profiles meaningless: opt-in.
     e->overlap = glass_knob("GLASS_OVERLAP") != nullptr;
-    // CLIP's image tower (short, latency-bound launches: 2.2 ms of a mostly idle GPU) on the second stream next to the
-    // discriminator, which only shares the finished image with it
-    // (default; GLASS_NO_CLIP_OVERLAP=1 / glass_engine_set_overlap(e, 0) put everything on one stream)
+    // default (mode 2): CLIP's image tower (short, latency-bound launches) on the second stream next to the discriminator, which only
+    // shares the finished image with it
     e->clip_overlap = glass_knob("GLASS_NO_CLIP_OVERLAP") == nullptr;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (err == hipSuccess) {

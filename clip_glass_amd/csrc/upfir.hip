@@ -287,10 +287,12 @@ struct UpGeo {
     unsigned invPX, invPY;     // ceil(2^32 / (W + 1)), ceil(2^32 / (H + 1)): exact n / pitch for the ranges used here
     unsigned inv2PX, inv2PY;   // same for the output pitches 2 (W + 1), 2 (H + 1)
     int prefetch;              // GRID = false: fetch the next step's stage-0 operands under this step's FIR (A/B knob)
+#ifdef GLASS_AB_KNOBS
     int ablate;                // developer build only (make AB=1, GLASS_UPFIR_ABLATE): timing experiments that switch phases of the single-image
                                // instance off — 1 MFMAs, 2 T write + FIR + stores, 4 global stores, 8 FIR arithmetic, 16 operand loads, 32 weight loads after a
                                // segment's first step, 64 patch loads, 128 weight LDS writes after the first step (WRONG RESULTS); 256: no request of the next step's stage 0
                                // behind the FIR (correct results: the r04 order, addresses derived and loads issued after the step barrier).
+#endif
 };
 #ifdef GLASS_AB_KNOBS
 #define U_ABL(bit) (!GRID && (g.ablate & (bit)))
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
     // vmcnt(0), i.e. for the previous step's 16 row stores, at the FIRST barrier of the next step; the counted waits hipcc places in front
     // of each operand's first use are all the K loop needs from global memory
     auto kbar = [&]() {
-        if (BS) {
+        if constexpr (BS) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         } else {
@@ -780,10 +782,12 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                 }
                 const long long rowpitch = (long long)p.Wo * p.Cout;
                 half_t* yp = p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)
-                // buffer form: descriptor over this image's output map (uniform), 32-bit byte offset per lane
+#ifdef GLASS_AB_KNOBS
+                // (r05 experiment, developer build: the BS instance) buffer form: descriptor over this image's output map (uniform), 32-bit byte offset per lane
                 const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + (long long)img0 * p.Ho * p.Wo * p.Cout), 0,
                                                                                       (int)((long long)p.Ho * p.Wo * p.Cout * 2), 0x00020000);
                 unsigned yoff = (unsigned)((((long long)ovy0 * p.Wo + ox) * p.Cout + n0 + cg * 8) * 2);   // (wraps for the rows of step 0 that are not written)
+#endif
                 // (software-pipelined like the grid instance's loop above: row r + 1's T vectors and noise value are requested before row r
                 // is filtered, only the store is predicated — the plain loop had TWO exposed LDS round trips per row)
                 h8 cv[4];
@@ -805,14 +809,17 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                     h8 v = (hs[(r - 3) & 3] + hs[r & 3]) * fq4 + ((hs[(r - 2) & 3] + hs[(r - 1) & 3]) * ft4 + bn);
                     v = __builtin_elementwise_max(v, v * slope) * kps;
                     if (U_ABL(8)) v = cv[0];
-                    if (BS) {
+#ifdef GLASS_AB_KNOBS
+                    if constexpr (BS) {
                         // UNCONDITIONAL buffer store, rows that must not be written get an out-of-range offset (the hardware drops them): the
                         // number of memory operations in flight is then static, so the wait in front of the next step's prefetched operands is a
                         // counted vmcnt(16) that lets the row stores keep draining (a store under a branch forces vmcnt(0))
                         const unsigned off = ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) ? yoff : 0xFFFFFFF0u;
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), yrsrc, off, 0, 0);
                         yoff += (unsigned)rowpitch * 2u;
-                    } else if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
+                    } else
+#endif
+                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);
                     if (r + 1 < TR) {
@@ -902,9 +909,9 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
     // layers — a wash, as round 2's persistent-prefetch experiment was (round 5: 2127 vs 2016 us).  Off.
     static const bool prefetch = glass_knob("GLASS_UPFIR_PREFETCH") != nullptr;
     g.prefetch = prefetch ? 1 : 0;
+#ifdef GLASS_AB_KNOBS
     static const int ablate = glass_knob("GLASS_UPFIR_ABLATE") ? atoi(glass_knob("GLASS_UPFIR_ABLATE")) : 0;
     g.ablate = ablate;
-#ifdef GLASS_AB_KNOBS
     // (r05 experiment, developer build) bit 0: unconditional buffer stores + LDS-only barriers (template instance BS), bit 1: operand prefetch
     static const int bstore = glass_knob("GLASS_UPFIR_BSTORE") ? atoi(glass_knob("GLASS_UPFIR_BSTORE")) : 0;
     if (lean && (bstore & 2)) g.prefetch = 1;

@@ -157,10 +157,10 @@ int glass_engine_set_profiling(glass_engine* e, int32_t on);
 int glass_engine_set_profile_filter(glass_engine* e, const char* kernel_substr);
 int glass_engine_get_profile(glass_engine* e, glass_prof_row* rows, int32_t max_rows, int32_t* n_rows);
 
-/* Stream mode of evaluate().  2 (default; GLASS_NO_CLIP_OVERLAP=1 at creation selects 0): generator and discriminator on one stream,
- * CLIP's image tower (short latency-bound launches) on a second stream next to the discriminator, +2 % throughput.
- * 1 (GLASS_OVERLAP=1 at creation): synthesis of chunk k+1 || resize + D + CLIP of chunk k.  0: one stream — the mode for clean
- * per-kernel profiles (co-running kernels stretch each other).  Results are identical in every mode. */
+/* Stream mode of evaluate() — this call is the ONLY control (the library reads no environment variable).  2 (default): generator and
+ * discriminator on one stream, CLIP's image tower (short latency-bound launches) on a second, highest-priority stream next to the
+ * discriminator.  1: synthesis of chunk k+1 || resize + D + CLIP of chunk k.  0: one stream — the mode for clean per-kernel profiles
+ * (co-running kernels stretch each other).  Results are identical in every mode. */
 int glass_engine_set_overlap(glass_engine* e, int32_t on);
 /* BigGAN-deep diagnostic: record the activation after GenBlock `block` (-1: after the self-attention block, -2: off) of the first
  * chunk of the next evaluate / generate; get_biggan_tap returns it as NHWC float32 [dims[0]][dims[1]][dims[2]][dims[3]] (out may

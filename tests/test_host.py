@@ -495,10 +495,14 @@ def test_release_library_has_no_environment_knobs():
     """VERDICT r4 / release hygiene: the product library reads NO environment variable — the GLASS_* A/B knobs, the phase-ablation and
     experiment switches exist in the developer build only (`make -C clip_glass_amd/csrc AB=1` -> tools/lib/libglass_ab.so).  The release
     binary therefore contains no knob name and does not import getenv."""
+    import glob
     import subprocess
+    if not os.path.exists(engine.LIB_PATH):
+        pytest.skip("libglass.so is not built here (python -c 'import __graft_entry__ as g; g.build()')")
     blob = open(engine.LIB_PATH, "rb").read()
     assert b"GLASS_" not in blob, "a GLASS_* knob name is compiled into the release library"
     syms = subprocess.run(["nm", "-D", "--undefined-only", engine.LIB_PATH], capture_output=True, text=True).stdout
     assert "getenv" not in syms
-    assert not os.path.exists(os.path.join(os.path.dirname(engine.LIB_PATH), "libglass_a.so"))          # developer libraries live under
-    assert not os.path.exists(os.path.join(os.path.dirname(engine.LIB_PATH), "libglass_trace.so"))      # tools/lib/, never in the package
+    # developer libraries (libglass_ab.so, libglass_trace.so, A/B copies) live under tools/lib/, never next to the product
+    others = [f for f in glob.glob(os.path.join(os.path.dirname(engine.LIB_PATH), "libglass*.so")) if os.path.basename(f) != "libglass.so"]
+    assert not others, others

@@ -12,6 +12,7 @@ OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
 # single stream, no event instrumentation, and EVERY pass at the full population (the set-up pass included): a kernel's
 # dispatches are then its P = 64 launches only
+# (GLASS_NO_CLIP_OVERLAP is read by bench.py, which calls glass_engine_set_overlap(0): the release library itself reads no environment)
 export GLASS_NO_CLIP_OVERLAP=1 GLASS_BENCH_NOPROF=1 GLASS_BENCH_UNIFORM_POP=1
 ARGS="--config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-legs"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- python bench.py $ARGS > /dev/null 2> $OUT/fetch.err
