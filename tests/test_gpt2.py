@@ -234,6 +234,65 @@ def test_img2txt_generation_problem_end_to_end(assets, tmp_path):
 
 
 @pytest.mark.gpu
+def test_img2txt_full_size_generation_problem_matches_oracle(tmp_path):
+    """Config C5 END TO END at the real geometry, with a checker: GPT-2-small (12 x 768, vocab 50257) token-latent
+    decode -> parse_out -> clip.tokenize on generated BPE tables of the reference's sizes and file formats (synth.write_bpe_assets;
+    50257 / 49408 ids) -> CLIP text tower (512 x 12 x 8 heads, context 77) -> cosine against the image feature, through
+    `GenerationProblem._evaluate` at P = 64 — the chain `bench.py --config gpt2` times (/root/reference/generator.py:52-59,
+    models.py:45-62, problem.py:14-29).  Oracle: gpt2_ref.sample_sequence -> gpt2_ref.parse_out -> the same tokenizer ->
+    clip_ref.encode_text -> cosine; F within 1e-3 relative (north_star's bar), texts identical, tokens identical."""
+    import types
+    from clip_glass_amd import config as gconfig
+    from clip_glass_amd.problem import GenerationProblem
+    from oracle import clip_ref
+    P = 64
+    clipg = (768, 12, 12, 32, 224, 512)
+    enc, voc, bpe = synth.write_bpe_assets(str(tmp_path))
+    tf = synth.normal(3, "imgfeat", (512,))
+    cfg = types.SimpleNamespace(config="GPT2", device="cuda:0", target="unused")
+    vars(cfg).update(gconfig.get_config("GPT2"))
+    vars(cfg).update(weights="synthetic:5", clip_weights="synthetic:0", clip_geometry=clipg, clip_text_geometry=dict(width=512, layers=12),
+                     encoder=enc, vocab=voc, bpe_path=bpe, target_features=tf, pop_size=P, max_pop=P)
+    prob = GenerationProblem(cfg)
+    gen = prob.generator
+    assert len(gen.model.init_tokens) == 3
+    x = np.random.RandomState(11).randint(0, 50257, size=(P, cfg.dim_z))
+    # ---- oracle chain ------------------------------------------------------------------------------------------------------------
+    sdg = synth.make_state(synth.gpt2_spec(), 5)
+    ctx = np.concatenate([x, np.tile(gen.model.init_tokens, (P, 1))], axis=1)
+    dd = {}
+    ora = gpt2_ref.sample_sequence(_t(sdg), torch.tensor(ctx), cfg.max_tokens_len, detail=dd).numpy()
+    ref_texts = gpt2_ref.parse_out(ora, cfg.dim_z, gen.model.enc.eot, gen.model.enc.decode, cfg.max_text_len)
+    sdt = synth.make_state(synth.clip_text_spec(width=512, layers=12, vocab=49408, out_dim=512), 0)
+    tok = gen.tokenizer.tokenize(ref_texts)                 # (a failure here would zero the population, generator.py:53-56: the synthetic
+    tfeat = clip_ref.encode_text(_t(sdt), torch.tensor(tok))  # vocabulary is built so that 50-character texts fit 77 tokens)
+    # the target image feature: a direction the population's text features correlate with (a random one is orthogonal to all of them —
+    # similarities ~0, where a relative bar means nothing): their normalised mean plus an equal-norm random part
+    fn = torch.nn.functional.normalize(tfeat, dim=1).mean(0)
+    tgt = (fn / fn.norm() + torch.nn.functional.normalize(torch.tensor(tf), dim=0)).numpy().astype(np.float32)
+    gen.image_features = tgt[None]
+    sim = torch.cosine_similarity(tfeat, torch.tensor(tgt)[None]).numpy()
+    # ---- the product path ----------------------------------------------------------------------------------------------------------
+    out = {}
+    prob._evaluate(x, out)
+    texts = list(gen.last_texts)
+    assert out["F"].shape == (P,) and len(texts) == P
+    got_tok = gen.engine.gpt2_decode(ctx, cfg.max_tokens_len)
+    mg = dd["margins"].numpy() if hasattr(dd["margins"], "numpy") else dd["margins"]
+    excepted = _assert_token_parity("C5 full size", got_tok, ora, mg, ctx.shape[1])
+    assert all(a == b for i, (a, b) in enumerate(zip(texts, ref_texts)) if i not in excepted)
+    F = np.asarray(out["F"])
+    rel = np.abs(F + sim) / np.abs(sim)
+    ok = np.ones(P, bool)
+    ok[list(excepted)] = False
+    diag("[gpt2] C5 full size: P=%d, max rel err of F vs oracle %.2e (sim %.3f..%.3f), %d near-tie row(s) excepted; sample %r"
+         % (P, rel[ok].max(), sim.min(), sim.max(), len(excepted), texts[:2]))
+    assert np.abs(sim).min() > 0.05                          # (the relative bar below means something)
+    assert rel[ok].max() <= 1e-3
+    gen.engine.close()
+
+
+@pytest.mark.gpu
 def test_gpt2_small_full_size_decode_and_timing():
     """GPT-2 small at true size (12 x 768, vocab 50257): P=64 x 23-token context, 30 greedy steps (config C5 shape);
     token parity of ALL 64 rows against the oracle + wall time of the device decode."""
