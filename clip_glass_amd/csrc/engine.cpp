@@ -1848,6 +1848,13 @@ extern "C" int glass_engine_last_details(glass_engine* e, int32_t P, float* feat
     return GLASS_OK;
 }
 
+extern "C" int glass_engine_last_F_device(glass_engine* e, int32_t P, void** dev_ptr) {
+    REQUIRE(e && dev_ptr, GLASS_ERR_ARG, "null argument");
+    REQUIRE(P > 0 && P == e->last_P && e->d_F, GLASS_ERR_STATE, "no evaluate() of this population size has run");
+    *dev_ptr = e->d_F;
+    return GLASS_OK;
+}
+
 extern "C" int glass_engine_last_gpu_ms(glass_engine* e, float* ms) {
     REQUIRE(e && ms, GLASS_ERR_ARG, "null argument");
     *ms = e->last_ms;

@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.glass_engine_generate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
     lib.glass_engine_last_gpu_ms.argtypes = [C.c_void_p, fp]
+    lib.glass_engine_last_F_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
     lib.glass_engine_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_overlap.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_biggan_tap.argtypes = [C.c_void_p, C.c_int32]
@@ -233,6 +234,17 @@ class Engine:
         sim = np.empty((P,), dtype=np.float32)
         _check(self.lib, self.lib.glass_engine_last_details(self._h, P, _fp(feat), _fp(dis), _fp(sim)))
         return dict(features=feat, dis=dis, sim=sim)
+
+    def last_F_device(self, P):
+        """The last evaluate()'s fitness rows as a torch CUDA tensor VIEW [P, n_obj] of the engine's own buffer (no copy; valid until the
+        engine's next call) — what the RCCL all-gather of a generation sends (parallel.py)."""
+        import torch
+        ptr = C.c_void_p()
+        _check(self.lib, self.lib.glass_engine_last_F_device(self._h, P, C.byref(ptr)))
+
+        class _View:      # CUDA array interface (v2): torch.as_tensor wraps device memory it does not own
+            __cuda_array_interface__ = dict(shape=(P, int(self.cfg.n_obj)), typestr="<f4", data=(int(ptr.value), False), version=2)
+        return torch.as_tensor(_View(), device=torch.device("cuda", int(self.cfg.device)))
 
     def last_gpu_ms(self):
         ms = C.c_float()

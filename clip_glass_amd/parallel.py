@@ -27,11 +27,14 @@ def shard_bounds(P, world, batch_size):
 
 
 class ShardedEvaluator:
-    def __init__(self, engine, dist, rank, world, batch_size, device=None):
+    def __init__(self, engine, dist, rank, world, batch_size, device=None, force_collective=False):
         """device: the GPU this rank's engine runs on (default: the engine's own).  The RCCL gather tensors are staged THERE — not on
         torch's current device, which is cuda:0 on every rank unless the launcher called torch.cuda.set_device (a duplicate-GPU
-        error or a hang in the collective otherwise)."""
+        error or a hang in the collective otherwise).  force_collective: run the all-gather at world size 1 too (tests/rccl_worker.py
+        on a 1-GPU box: the `nccl` call itself is then exercised)."""
         self.engine, self.dist, self.rank, self.world, self.batch_size = engine, dist, rank, world, batch_size
+        self.force_collective = bool(force_collective)
+        self.last_gather_source = None          # "device" / "host": where the last all-gather read this rank's rows from
         if device is None:
             device = getattr(getattr(engine, "cfg", None), "device", 0)
         self.device = int(device)
@@ -56,22 +59,36 @@ class ShardedEvaluator:
             F = self.engine.evaluate(x[lo:hi], generation=generation, first_minibatch=lo // self.batch_size)
         return self.all_gather(F, sizes=[b - a for a, b in shard_bounds(x.shape[0], self.world, self.batch_size)])
 
+    def _local_rows(self, F, dev):
+        """This rank's rows as a tensor on the gather device.  Under `nccl` they are taken where evaluate() left them — the engine's own
+        device buffer (glass_engine_last_F_device), no D2H -> H2D bounce; `F` (the host copy evaluate() returned) is the gloo / fallback
+        source and must hold the same rows."""
+        import torch
+        if dev.type == "cuda" and F.shape[0] > 0 and hasattr(self.engine, "last_F_device"):
+            try:
+                t = self.engine.last_F_device(F.shape[0])
+                self.last_gather_source = "device"
+                return t
+            except Exception:
+                pass
+        self.last_gather_source = "host"
+        return torch.from_numpy(np.ascontiguousarray(F)).to(dev)
+
     def all_gather(self, F, sizes=None):
-        if self.dist is None or self.world == 1:
+        if self.dist is None or (self.world == 1 and not self.force_collective):
             return F
         import torch
         dev = self.gather_device()
         n_obj = F.shape[1]
+        t = self._local_rows(F, dev)
         if sizes is None or len(set(sizes)) == 1:
-            t = torch.from_numpy(np.ascontiguousarray(F)).to(dev)
             out = torch.empty((self.world * t.shape[0], n_obj), dtype=t.dtype, device=dev)
-            self.dist.all_gather_into_tensor(out, t)
+            self.dist.all_gather_into_tensor(out, t.contiguous())
             return out.cpu().numpy()
-        m = max(sizes)  # ragged shards: pad to the largest, gather, trim
-        pad = np.zeros((m, n_obj), np.float32)
-        pad[:F.shape[0]] = F
-        t = torch.from_numpy(pad).to(dev)
-        out = torch.empty((self.world * m, n_obj), dtype=t.dtype, device=dev)
-        self.dist.all_gather_into_tensor(out, t)
+        m = max(sizes)  # ragged shards: pad to the largest (on the gather device), gather, trim
+        pad = torch.zeros((m, n_obj), dtype=torch.float32, device=dev)
+        pad[:F.shape[0]] = t
+        out = torch.empty((self.world * m, n_obj), dtype=pad.dtype, device=dev)
+        self.dist.all_gather_into_tensor(out, pad)
         out = out.cpu().numpy().reshape(self.world, m, n_obj)
         return np.concatenate([out[r, :sizes[r]] for r in range(self.world)])

@@ -139,6 +139,10 @@ int glass_engine_generate(glass_engine* e, const float* latents, int32_t P, int3
 
 /* GPU time of the last evaluate() in ms, from hipEvents on the engine's stream. */
 int glass_engine_last_gpu_ms(glass_engine* e, float* ms);
+/* Device address of the fitness rows [P][n_obj] float32 of the last evaluate() (the buffer evaluate() copied `out_F` from; valid until the
+ * engine's next call).  The multi-GPU host code hands it to the one RCCL all-gather of a generation (clip_glass_amd/parallel.py) without
+ * bouncing the rows through host memory. */
+int glass_engine_last_F_device(glass_engine* e, int32_t P, void** dev_ptr);
 
 /* Per-kernel profile (hipEvent pairs around every launch while enabled).
  * After evaluate(): n rows of {name, launches, total_ms, flops, bytes} — algorithmic
