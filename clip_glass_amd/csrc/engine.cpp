@@ -1257,18 +1257,30 @@ static void run_d_head(glass_engine* e, int P, const half_t* X, half_t* scratch)
     }
 }
 
-void run_clip(glass_engine* e, int P) {
+void run_clip(glass_engine* e, int P, int l0, int l1);
+// layers [l0, end) + the head WITHOUT the patch embedding (it ran with layers [0, l0) on another stream)
+static void run_clip_rest(glass_engine* e, int P, int l0) {
+    if (l0 == 0) {          // run_clip's l0 == 0 means "with the embedding": walk layer 0 through the general path's layer loop instead
+        run_clip(e, P, -1, 1 << 20);
+        return;
+    }
+    run_clip(e, P, l0, 1 << 20);
+}
+// layers [l0, l1) of the image tower; l0 == 0 also runs the patch embedding (l0 < 0: layers from 0 WITHOUT it), l1 >= the layer count also
+// the head (ln_post, projection, cosine)
+void run_clip(glass_engine* e, int P, int l0, int l1) {
     const glass_config& c = e->cfg;
     const int W = c.clip_width, ps = c.clip_patch, G = c.clip_res / ps, T = G * G + 1, M = P * T;
     GemmParams g;
-    memset(&g, 0, sizeof g);
-    g.a = e->d_patches; g.w = e->c_patch_w; g.M = P * G * G; g.N = W; g.K = 3 * ps * ps; g.mode = 3; g.out32 = e->d_pe; g.ldo = W; g.cand_rows = G * G;
-    run_gemm(e, g, "clip.patch_embed");
-    {
+    if (l0 == 0) {
+        memset(&g, 0, sizeof g);
+        g.a = e->d_patches; g.w = e->c_patch_w; g.M = P * G * G; g.N = W; g.K = 3 * ps * ps; g.mode = 3; g.out32 = e->d_pe; g.ldo = W; g.cand_rows = G * G;
+        run_gemm(e, g, "clip.patch_embed");
         Prof pr(e, "clip.embed_lnpre", 0, 8.0 * M * W);
         launch_embed_lnpre(e->d_pe, e->c_cls, e->c_pos, e->c_lnpre_g, e->c_lnpre_b, P, T, W, e->d_x, e->cur);
     }
-    for (auto& b : e->cblk) {
+    for (int li = l0 < 0 ? 0 : l0; li < l1 && li < (int)e->cblk.size(); ++li) {
+        auto& b = e->cblk[li];
         {
             Prof pr(e, "clip.layernorm", 0, 6.0 * M * W);
             launch_layernorm(e->d_x, W, M, W, b.ln1_g, b.ln1_b, e->d_ln16, nullptr, e->cur);
@@ -1294,7 +1306,7 @@ void run_clip(glass_engine* e, int P) {
         g.a = e->d_hid; g.w = b.w_proj; g.M = M; g.N = W; g.K = 4 * W; g.bias = b.b_proj; g.mode = 2; g.out32 = e->d_x; g.ldo = W; g.cand_rows = T;
         run_gemm(e, g, "clip.mlp_proj");
     }
-    {
+    if (l1 >= (int)e->cblk.size()) {
         Prof pr(e, "clip.head", 2.0 * P * W * c.clip_embed, 4.0 * W * c.clip_embed);
         launch_layernorm(e->d_x, (long long)T * W, P, W, e->c_lnpost_g, e->c_lnpost_b, nullptr, e->d_cls, e->cur);
         launch_dense(e->d_cls, W, P, W, e->c_proj, c.clip_embed, nullptr, e->d_feat, c.clip_embed, 0, 0, nullptr, 0,
@@ -1342,7 +1354,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
             }
         }
         if (out_F) {
-            run_clip(e, P);
+            run_clip(e, P, 0, 1 << 20);
             launch_assemble_F(e->d_sim, e->d_dis, P, c.n_obj, e->d_F, e->cur);
             GLASS_HIP(hipMemcpyAsync(e->h_pinned, e->d_F, (size_t)P * c.n_obj * sizeof(float), hipMemcpyDeviceToHost, e->cur));
         }
@@ -1435,11 +1447,15 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
                 launch_resize_patches(y, B, e->R, c.clip_res, ps, e->d_patches + (size_t)c0 * G * G * 3 * ps * ps,
                                       e->cur);
             }
-            if (clip_ov && !clip_late && c0 + e->chunk >= P) {   // last chunk's patches are in place: CLIP starts now on the second stream
+            if (clip_ov && !clip_late && c0 + e->chunk >= P) {   // last chunk's patches are in place: CLIP starts now
+                // its first layers on the MAIN stream (alone on the chip), the rest on the second stream beside the discriminator
+                static const int serial_layers = glass_knob("GLASS_CLIP_SERIAL") ? atoi(glass_knob("GLASS_CLIP_SERIAL")) : GLASS_CLIP_SERIAL_LAYERS;
+                if (serial_layers >= 0) run_clip(e, P, 0, serial_layers);      // (0: the patch embedding alone; -1: nothing)
                 GLASS_HIP(hipEventRecord(e->ev_g[0], e->stream));
                 GLASS_HIP(hipStreamWaitEvent(e->stream_d, e->ev_g[0], 0));
                 e->cur = e->stream_d;
-                run_clip(e, P);
+                if (serial_layers >= 0) run_clip_rest(e, P, serial_layers);
+                else run_clip(e, P, 0, 1 << 20);
                 GLASS_HIP(hipEventRecord(e->ev_d[0], e->stream_d));
                 e->cur = e->stream;
             }
@@ -1460,7 +1476,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
         GLASS_HIP(hipEventRecord(e->ev_g[0], e->stream));          // next to its chip-filling high-resolution kernels
         GLASS_HIP(hipStreamWaitEvent(e->stream_d, e->ev_g[0], 0));
         e->cur = e->stream_d;
-        run_clip(e, P);
+        run_clip(e, P, 0, 1 << 20);
         GLASS_HIP(hipEventRecord(e->ev_d[0], e->stream_d));
         e->cur = e->stream;
     }
@@ -1477,7 +1493,7 @@ static int run_pass(glass_engine* e, const float* latents, int P, int generation
         }
         e->cur = e->stream;
         if (clip_ov) GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_d[0], 0));   // join: CLIP finished on the second stream
-        else run_clip(e, P);
+        else run_clip(e, P, 0, 1 << 20);
         if (overlap) {   // join: D head finished
             GLASS_HIP(hipEventRecord(e->ev_g[0], sd));
             GLASS_HIP(hipStreamWaitEvent(e->stream, e->ev_g[0], 0));
@@ -1595,7 +1611,7 @@ extern "C" int glass_engine_encode_image(glass_engine* e, const float* images, i
     hipError_t err = hipMemcpyAsync(d_img, images, elems * sizeof(float), hipMemcpyHostToDevice, e->stream);
     e->cur = e->stream;
     launch_image_patches(d_img, n, c.clip_res, c.clip_patch, e->d_patches, e->stream);
-    run_clip(e, n);
+    run_clip(e, n, 0, 1 << 20);
     if (err == hipSuccess)
         err = hipMemcpyAsync(out_feat, e->d_feat, (size_t)n * c.clip_embed * sizeof(float), hipMemcpyDeviceToHost, e->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

@@ -282,7 +282,13 @@ void collect_profile(glass_engine* e);
 void run_conv(glass_engine* e, const ConvParams& p, const char* tag, double flops, double bytes);
 void run_gemm(glass_engine* e, const GemmParams& p, const char* tag);
 ConvParams conv_defaults();
-void run_clip(glass_engine* e, int P);
+void run_clip(glass_engine* e, int P, int l0, int l1);
+// Stream mode 2: the patch embedding and this many layers of CLIP's image tower run on the MAIN stream, alone on the chip, before the
+// discriminator starts; the rest of the tower runs on the second stream beside it.  Forked right behind the resize (rounds 2-5), the tower's
+// first launch raced the discriminator's first kernel — a persistent kernel that fills every CU for 3.9 ms — and lost about every other
+// process: 31.0-31.5 ms per pass against 29.6 with the embedding and ONE layer in front (sweep 0 / 1 / 2 / 3 / 4 / 6 / 8 / 10 / 12 layers:
+// 29.66 / 29.59 / 29.60 / 29.74 / 29.79 / 29.91 / 29.96 / 30.13 / 30.53 ms, three runs each within 0.1 ms; DESIGN section 5 "Round 6").
+#define GLASS_CLIP_SERIAL_LAYERS 1
 std::vector<_Float16> to_half(const float* p, size_t n, float scale = 1.f);
 std::vector<float> scaled(const float* p, size_t n, float scale);
 std::vector<float> transposed(const float* W, int N, int K, float coef);

@@ -70,7 +70,8 @@ def load_library(path=None):
     lib.glass_engine_generate.argtypes = [C.c_void_p, fp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(GlassNoise), fp]
     lib.glass_engine_last_details.argtypes = [C.c_void_p, C.c_int32, fp, fp, fp]
     lib.glass_engine_last_gpu_ms.argtypes = [C.c_void_p, fp]
-    lib.glass_engine_last_F_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    if hasattr(lib, "glass_engine_last_F_device"):      # (absent from older A/B builds loaded through GLASS_LIB)
+        lib.glass_engine_last_F_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
     lib.glass_engine_set_profiling.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_overlap.argtypes = [C.c_void_p, C.c_int32]
     lib.glass_engine_set_biggan_tap.argtypes = [C.c_void_p, C.c_int32]
