@@ -201,6 +201,8 @@ struct ConvParams {
     float* trgb_yout;       // [B][3][Ho][Wo]
     float* rgb_tanh_out;    // conv_tiled (3x3, one 32-wide n tile, fast path): [B][3][Ho][Wo] = tanh of output channels 0..2 taken from the fp32
                             // accumulators (BigGAN's conv_to_rgb[:, :3] + tanh, oracle/biggan_ref.py generator()); p.y is NOT written
+    float* trgb_part;       // conv_glds persistent form, layers with SEVERAL 128-wide n tiles: [NTn][B][3][Ho][Wo] fp32 — every n tile writes the toRGB
+                            // partial sum of its 128 channels (no bias, no skip image); launch_trgb_finish adds them in n-tile order
     const half_t* trgb_tab; // conv_tiled / conv_glds (their output map IS stored too): [B][2][16][Neff] fp16 weight tables from
                             // launch_trgb_tables (the MFMA A operand of the 1x1 conv in accumulator-lane channel order)
     // conv_tiled<3,1,8,N> only: FIR 4x4 (pad 1) + ::2 of the INPUT map [B][H/2][W/2][Cin] as a by-product of the staged patch — the D

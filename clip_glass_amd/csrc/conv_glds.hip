@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
             if (TRGB && t < 6 * (NT / 8)) {
                 const int row6 = t / (NT / 8), piece = t % (NT / 8);
                 const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
-                dma16(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8, smem + G::OFF_T + wave * 1024);
+                dma16(p.trgb_tab + ((long long)b * 32 + n) * p.Neff + n0 + piece * 8, smem + G::OFF_T + wave * 1024);     // (rows of Neff entries: this n tile's 128)
             }
         };
         if (grp) __builtin_amdgcn_s_barrier();     // group 1 falls one barrier behind: its load intervals face group 0's MFMA intervals
@@ -685,12 +685,18 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
         }
         if (TRGB) {
             const long long hw = (long long)p.Ho * p.Wo;
-            float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
+            if (p.trgb_part) {       // several n tiles per pixel: this tile's partial sum over its 128 channels (launch_trgb_finish adds them up)
+                float* yo = p.trgb_part + ((long long)(n0 >> 7) * p.B + b) * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
 #pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                float r = p.trgb_b[cc] + (rgb[cc] + rgb[4 + cc] * (1.f / 2048.f));
-                if (p.trgb_yprev) r += trgb_skip(ytap[cc], oyb + kh, ox);
-                yo[cc * hw] = r;
+                for (int cc = 0; cc < 3; ++cc) yo[cc * hw] = rgb[cc] + rgb[4 + cc] * (1.f / 2048.f);
+            } else {
+                float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    float r = p.trgb_b[cc] + (rgb[cc] + rgb[4 + cc] * (1.f / 2048.f));
+                    if (p.trgb_yprev) r += trgb_skip(ytap[cc], oyb + kh, ox);
+                    yo[cc * hw] = r;
+                }
             }
         }
         if (ST && t < (p.Cin >> 3)) *(h8*)(smem + OFF_S + t * 16) = nsty;     // (every wave left the K loop, the style row's only reader, two barriers ago)
@@ -741,7 +747,7 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
 #undef GLDSP_LAUNCH
         return pname;
     }
-    if (p.xs_out) return nullptr;            // (the blur-down by-product exists in the persistent form only)
+    if (p.xs_out || p.trgb_part) return nullptr;   // (the blur-down by-product and the toRGB partial sums exist in the persistent form only)
     if (p.dry_run) return name;
     hipLaunchKernelGGL((conv_glds_kernel<TW, TRGB>), dim3(PT8 * NTn), dim3(NTHR), G::LDS_BYTES, st, p, NTn, tiles_x, tiles_y, PT);
     return name;
@@ -756,6 +762,11 @@ const char* launch_conv_glds(const ConvParams& p0, hipStream_t st, bool force) {
     if ((p.sn && !p.sn16) || p.pre_shift || p.in_up || p.Cin > 1024 || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cin < 128 || p.Neff % NT != 0 || (p.Cout & 7) || p.Hc % 16 != 0) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
+    if (p.trgb_part) {   // toRGB partial sums per 128-wide n tile (persistent form only: the caller falls back to the separate pass otherwise)
+        if (!p.trgb_tab || p.trgb_yout || p.trgb_yprev || p.xs_out || p.Neff != p.Cout || p.Neff % NT != 0 || p.Wc % 32 != 0) return nullptr;
+        const char* k = launch_glds_inst<32, true>(p, st, nullptr);
+        return k;
+    }
     if (p.trgb_yout) {   // fused toRGB: only where one workgroup holds every output channel of its pixels
         if (!p.trgb_tab || !p.trgb_b || p.Neff != NT || p.Cout != NT || p.Wc % 32 != 0) return nullptr;
         return launch_glds_inst<32, true>(p, st, "conv_glds_kernel<32,true>");

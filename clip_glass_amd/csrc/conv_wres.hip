@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
 const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
     static const bool off = glass_knob("GLASS_NO_WRES") != nullptr;       // A/B knob (developer build): conv_tiled<3,1,8,64> instead
     if (off || p.Cin != 64 || p.Neff != NT || p.Cout != NT || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
-    if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16) return nullptr;
+    if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16 || p.trgb_part) return nullptr;
     if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
     if (p.xs_out && p.trgb_yout) return nullptr;

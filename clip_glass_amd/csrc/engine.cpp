@@ -558,7 +558,14 @@ static int alloc_buffers(glass_engine* e) {
     if ((rc = dev_alloc(e, &e->d_s, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_s16, (size_t)P * e->S_total))) return rc;
     if ((rc = dev_alloc(e, &e->d_smax, (size_t)P * e->n_style))) return rc;
-    if ((rc = dev_alloc(e, &e->d_trgb_tab, (size_t)P * 32 * 128))) return rc;
+    if ((rc = dev_alloc(e, &e->d_trgb_tab, (size_t)P * 32 * 512))) return rc;
+    {   // toRGB partial sums of the blocks wider than 128 channels: [C / 128][chunk][3][res][res] fp32, the largest block's
+        size_t part = 0;
+        for (int b = 0; b < c.n_blocks; ++b)
+            if (c.channels[b] > 128 && c.channels[b] % 128 == 0 && c.channels[b] <= 512)
+                part = std::max(part, (size_t)(c.channels[b] / 128) * (size_t)P * 3 * ((size_t)4 << b) * ((size_t)4 << b));   // (P: the blocks up to 32 x 32 run the whole population)
+        if (part && (rc = dev_alloc(e, &e->d_trgb_part, part))) return rc;
+    }
     if (e->cfg.generator != GLASS_GEN_BIGGAN_DEEP && e->cfg.n_blocks > 0) {
         // StyleGAN2's low-resolution layers as im2col + GEMM (conv_gemm.hip): conv grids up to 16 x 16 per candidate, widest
         // channel count (151 + 134 MB at P = 64).  The capacities are per candidate: whether a layer takes this path must not
@@ -1043,6 +1050,36 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
                                            e->d_trgb_tab + (size_t)c0 * 32 * 128, e->cur);
                         k = launch_conv_glds(q, e->cur);
                         if (!k) k = launch_conv_tiled(q, e->cur);
+                        if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
+                        if (e->profiling) e->tag_kernel[tag] = k;
+                        rgb_done = true;
+                        x = out;
+                        xbs = (long long)g.res_out * g.res_out * g.cout;
+                    }
+                }
+            }
+            if (l == nl - 1 && !g.up && !no_trgb_fuse && !rgb_done && !no_trgb_mid && e->d_trgb_part) {
+                // blocks wider than 128 channels (several 128-wide n tiles per pixel): every n tile's conv epilogue writes the toRGB partial sum of
+                // its channels, a 3-value-per-pixel pass adds them (+ bias + the upsampled previous image) — the separate toRGB pass read the
+                // whole feature map again (0.19 + 0.09 + 0.03 ms at r128 / r64 / r32)
+                const GRgb& r = e->grgb[b];
+                if (r.cin > 128 && r.cin % 128 == 0 && r.cin <= 512) {
+                    ConvParams q = p;
+                    q.trgb_w = r.w; q.trgb_b = r.bias;
+                    q.trgb_sn = e->d_s + (size_t)c0 * e->S_total + r.style_off; q.trgb_sn_stride = e->S_total;
+                    q.trgb_smax = e->d_smax + (size_t)c0 * e->n_style + r.style_idx; q.trgb_smax_stride = e->n_style;
+                    q.trgb_tab = e->d_trgb_tab + (size_t)c0 * 32 * 512;
+                    q.trgb_part = e->d_trgb_part;
+                    q.dry_run = 1;
+                    if (launch_conv_glds(q, e->cur)) {
+                        q.dry_run = 0;
+                        const double tflops = flops + 2.0 * B * (double)r.res * r.res * 3 * r.cin;
+                        const double ybytes = B * (double)r.res * r.res * (12.0 * (1 + 2 * (r.cin / 128)) + (b ? 3.0 : 0.0));
+                        Prof pr(e, tag, tflops, bytes + ybytes);
+                        launch_trgb_tables(q.trgb_w, q.trgb_sn, q.trgb_sn_stride, q.trgb_smax, q.trgb_smax_stride, B, r.cin,
+                                           e->d_trgb_tab + (size_t)c0 * 32 * 512, e->cur);
+                        const char* k = launch_conv_glds(q, e->cur);
+                        launch_trgb_finish(e->d_trgb_part, r.cin / 128, B, r.res, r.bias, yprev, yb[yi], e->cur);
                         if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
                         if (e->profiling) e->tag_kernel[tag] = k;
                         rgb_done = true;

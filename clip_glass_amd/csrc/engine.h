@@ -165,7 +165,8 @@ struct glass_engine {
     half_t* ws_a2 = nullptr;  // second scratch set: launches on the second stream never share a buffer with the main stream's
     float* ws_c2 = nullptr;
     long long cap_a = 0, cap_c = 0;
-    half_t* d_trgb_tab = nullptr;   // [P][2][16][128] fp16: toRGB weight tables of the fused conv epilogues
+    half_t* d_trgb_tab = nullptr;   // [P][2][16][<= 512] fp16: toRGB weight tables of the fused conv epilogues
+    float* d_trgb_part = nullptr;   // [C / 128][chunk][3][res][res]: toRGB partial sums of the blocks wider than 128 channels
     float *d_z = nullptr, *d_w0 = nullptr, *d_w1 = nullptr, *d_s = nullptr, *d_smax = nullptr, *d_epsrow = nullptr,
           *d_dscale = nullptr;
     std::vector<float*> d_noise;  // per noise layer: [n_mb_max][res*res]

@@ -67,6 +67,8 @@ void launch_noise(float* out, int n_mb, int hw, uint32_t layer, uint32_t mb0, ui
 // y[b][c][p] = bias[c] + smax[b]*sum_i wrgb[c][i]*sn[b][i]*x[b][p][i] + upfir(yprev)
 void launch_trgb_tables(const float* wrgb, const float* sn, int sn_stride, const float* smax, int smax_stride, int B, int NT,
                         half_t* tab, hipStream_t st);   // [B][2][16][NT] fp16: A operand of the toRGB fused into a conv epilogue
+// skip image from the per-n-tile toRGB partial sums of a conv epilogue (ConvParams::trgb_part [ntn][B][3][R][R])
+void launch_trgb_finish(const float* part, int ntn, int B, int R, const float* bias, const float* yprev, float* yout, hipStream_t st);
 // false: channel width not instantiated (16 ... 512 in powers of two) — nothing launched
 bool launch_torgb(const half_t* x, int B, int H, int W, int C, const float* wrgb, const float* bias,
                   const float* sn, int sn_stride, const float* smax, int smax_stride,

@@ -545,6 +545,32 @@ void launch_trgb_tables(const float* wrgb, const float* sn, int sn_stride, const
     hipLaunchKernelGGL(trgb_tables_kernel, dim3(B), dim3(256), 0, st, wrgb, sn, sn_stride, smax, smax_stride, NT, tab);
 }
 
+// toRGB partial sums -> skip image (stylegan2/models.py:852-870, modules.py:580-602): y = bias + sum over the layer's 128-wide n tiles (in
+// n-tile order: deterministic) of the conv epilogues' partial sums + the FIR-upsampled previous image.  3 floats per pixel in and out per
+// tile instead of the separate toRGB pass's read of the whole feature map.
+__global__ __launch_bounds__(256) void trgb_finish_kernel(const float* part, int ntn, int B, int R, const float* bias, const float* yprev, float* yout) {
+    const long long hw = (long long)R * R, n = (long long)B * 3 * hw;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int px = (int)(i % R), py = (int)((i / R) % R), c = (int)((i / hw) % 3);
+    const long long b = i / (3 * hw);
+    float r = bias[c];
+    for (int t = 0; t < ntn; ++t) r += part[(long long)t * n + i];
+    if (yprev) {
+        const int h2 = R >> 1, my = py >> 1, mx = px >> 1;
+        const float* yp = yprev + (b * 3 + c) * (long long)h2 * h2;
+        float tap[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tap[q] = yp[(long long)max(my - 1 + (q >> 1), 0) * h2 + max(mx - 1 + (q & 1), 0)];
+        r += trgb_skip(tap, py, px);
+    }
+    yout[i] = r;
+}
+void launch_trgb_finish(const float* part, int ntn, int B, int R, const float* bias, const float* yprev, float* yout, hipStream_t st) {
+    const long long n = (long long)B * 3 * R * R;
+    hipLaunchKernelGGL(trgb_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, ntn, B, R, bias, yprev, yout);
+}
+
 // ---- biggan_norm: utils.py:14-17 ---------------------------------------------------
 __global__ void finalize_image_kernel(const float* y, float* img, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
