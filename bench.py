@@ -35,8 +35,7 @@ POP, BATCH = 64, 4
 _FLAG_ARGS = {"conv_stream_kernel": (0, ["fromrgb", "torgb", "trace"]),
               "conv_tiled_kernel": (4, ["persist", "torgb", "skip", "xs", "spl", "b2", "deep", "tr"])}
 # launches the engine tags by LAYER only (no "@kernel" part): the kernel symbol they run on
-_TAG_KERNELS = (("D.blurdown.", "blur_kernel<1,2,8>"), ("D.blur.", "blur_kernel<2,1,16>"), ("G.torgb.r128", "torgb_kernel<32>"),
-                ("G.torgb.", "torgb_kernel<64>"), ("noise", "noise_kernel"), ("clip.layernorm", "layernorm_kernel"),
+_TAG_KERNELS = (("D.blurdown.", "blur_kernel<1,2,8>"), ("D.blur.", "blur_kernel<2,1,16>"), ("G.torgb.", "torgb_kernel<64>"), ("noise", "noise_kernel"), ("clip.layernorm", "layernorm_kernel"),
                 ("clip.attention", "attention_mfma_kernel<2>"), ("clip.resize", "resize_patches_kernel"),
                 ("clip.embed_lnpre", "embed_lnpre_kernel"), ("mapping", "mapping_fused_kernel<2>"), ("D.mbstd", "mbstd_vec_kernel"),
                 ("styles", "dense_kernel"), ("demod", "dense_kernel"), ("premod_weights", "modulate_weights_kernel"))

@@ -86,12 +86,15 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
             const int iy = w.ty0 - 1 + pr, ix = w.tx0 - 1 + pc;
             const int lc = (v & 3) ^ ((pix >> 2) & 3);
             const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_src[k] = ok ? (iy * p.W + ix) * p.Cin + lc * 8 : -1;
+            a_src[k] = ok ? (iy * p.W + ix) * (p.x_planar32 ? 32 : p.Cin) + lc * 8 : -1;
         }
     };
+    // the second chunk of a pixel: 32 channels on in the pixel-major layout, a plane on in the chunk-planar one (common.h: there a 128-byte
+    // line holds ONE chunk of two pixels — pixel-major, its two halves were fetched a half tile apart and crossed the fabric twice)
+    const int c_step = p.x_planar32 ? p.H * p.W * 32 : 32;
     auto issue_a1 = [&](int k, int c) {        // piece k of chunk c -> patch buffer c (k is a constant wherever this is called)
         char* dst = smem + c * A_BYTES + wave * 1024 + k * (NTHR * 16);
-        dma16(a_src[k] >= 0 ? xb + a_src[k] + c * 32 : g_wres_zero_page + (threadIdx.x & 3) * 8, dst);
+        dma16(a_src[k] >= 0 ? xb + a_src[k] + c * c_step : g_wres_zero_page + (threadIdx.x & 3) * 8, dst);
     };
     auto issue_w = [&](int b) {                // the weight image of candidate b (shared weights: w_bstride = 0)
         const half_t* wb = p.w + (long long)b * p.w_bstride;
@@ -387,21 +390,27 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
     WR_WAIT_VM0();                             // the last tile's self-prefetch
 }
 
-// nullptr: the layer does not qualify (the caller goes on to conv_tiled)
-const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
+// would a plain 3x3 layer of this geometry run here?  (the producers of its input ask before they write the chunk-planar layout)
+bool conv_wres_supported(int Cin, int Cout, int H, int W) {
     static const bool off = glass_knob("GLASS_NO_WRES") != nullptr;       // A/B knob (developer build): conv_tiled<3,1,8,64> instead
-    if (off || p.Cin != 64 || p.Neff != NT || p.Cout != NT || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
-    if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16 || p.trgb_part) return nullptr;
-    if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
-    if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;
-    if (p.xs_out && p.trgb_yout) return nullptr;
-    if (p.trgb_yout && (!p.trgb_tab || !p.trgb_b)) return nullptr;
-    if (!glass_lds_fits(LDS_BYTES)) return nullptr;
-    const int tiles_x = p.Wc / TW, tiles_y = p.Hc / TH;
+    if (off || Cin != 64 || Cout != NT || H % TH != 0 || W % TW != 0 || (long long)H * W * Cin >= (1LL << 31)) return false;
+    if (!glass_lds_fits(LDS_BYTES)) return false;
     // worth a persistent workgroup per CU only with several tiles each — judged at the nominal population (common.h), so that a layer runs on
     // the same kernel whatever the size of this launch
+    return (long long)GLASS_NOMINAL_POP * (W / TW) * (H / TH) >= 8LL * glass_cu_count();
+}
+
+// nullptr: the layer does not qualify (the caller goes on to conv_tiled)
+const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
+    if (!conv_wres_supported(p.Cin, p.Cout, p.Hc, p.Wc)) return nullptr;
+    if (p.Cin != 64 || p.Neff != NT || p.Cout != NT || p.up || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;
+    if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16 || p.trgb_part) return nullptr;
+    if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
+    if (p.xs_out && p.trgb_yout) return nullptr;
+    if (p.y_planar32) return nullptr;              // (reads the chunk-planar layout, writes pixel-major)
+    if (p.trgb_yout && (!p.trgb_tab || !p.trgb_b)) return nullptr;
+    const int tiles_x = p.Wc / TW, tiles_y = p.Hc / TH;
     const int n_cu = glass_cu_count();
-    if ((long long)GLASS_NOMINAL_POP * tiles_x * tiles_y < 8LL * n_cu) return nullptr;
     const int PT = p.B * tiles_x * tiles_y;
     const char* name = p.trgb_yout ? "conv_wres_kernel<true,false>" : p.xs_out ? "conv_wres_kernel<false,true>" : "conv_wres_kernel<false,false>";
     if (p.dry_run) return name;

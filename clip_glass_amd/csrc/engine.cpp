@@ -942,6 +942,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     static const bool no_trgb_fuse = glass_knob("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
     static const bool no_trgb_mid = glass_knob("GLASS_NO_TRGB_MID") != nullptr;
     static const bool no_pre_style = glass_knob("GLASS_NO_PRE_STYLE") != nullptr;
+    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wres's input stays pixel-major
     // A block's SEPARATE toRGB pass (blocks wider than 128 channels) is a bandwidth-bound read of the map the next block's
     // up-conv reads too; in the two-stream mode it runs on the second stream next to that (issue-bound) up-conv.  The main
     // stream joins before the next block's last conv: that launch overwrites the map toRGB reads and consumes its skip image.
@@ -952,7 +953,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     bool rgb_pending = false;
     for (int b = b_lo; b < b_hi; ++b) {
         const int nl = b == 0 ? 1 : 2;
-        bool rgb_done = false, pre_styled = false;
+        bool rgb_done = false, pre_styled = false, x_planar = false;
         for (int l = 0; l < nl; ++l, ++gi) {
             if (rgb_pending && l == nl - 1) {
                 hipStreamWaitEvent(e->stream, e->ev_rgb, 0);
@@ -997,6 +998,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             // upconv -> conv link: the up-conv's only consumer is the block's second conv, so (where the fused up-conv kernel
             // runs and that conv modulates on the activation side) its style is applied once, to the up-conv's output
             if (pre_styled) { p.sn = nullptr; p.sn16 = nullptr; pre_styled = false; }
+            if (x_planar) { p.x_planar32 = 1; x_planar = false; }     // (a launcher that does not read the layout refuses the layer: run_conv reports it)
             if (g.up && l == 0 && nl == 2 && !no_pre_style && !e->gconv[gi + 1].premod && !e->gconv[gi + 1].up) {
                 ConvParams dq = p;
                 dq.dry_run = 1;
@@ -1010,6 +1012,15 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             }
             half_t* out = pp[(x == pp[0]) ? 1 : 0];
             p.y = out;
+            // upconv -> conv_wres link: that kernel reads its input one 32-channel chunk at a time, so the up-conv writes the map
+            // chunk-planar for it (common.h x_planar32) — where the up-conv instance that can runs and the conv has no activation-side style
+            if (g.up && l == 0 && nl == 2 && !no_planar && !e->gconv[gi + 1].up && (pre_styled || e->gconv[gi + 1].premod) &&
+                conv_wres_supported(e->gconv[gi + 1].cin, e->gconv[gi + 1].cout, g.res_out, g.res_out)) {
+                ConvParams dq = p;
+                dq.dry_run = 1;
+                dq.y_planar32 = 1;
+                if (launch_upconv_fused(dq, e->cur)) { p.y_planar32 = 1; x_planar = true; }
+            }
             const double flops = 2.0 * B * (double)g.res_in * g.res_in * 9.0 * g.cin * g.cout;  // reference count
             const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
                                  2.0 * 9 * g.cin * p.Neff;
@@ -1135,6 +1146,8 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
                             const float* rgb_y = nullptr) {
     char tag[64];
     half_t *Hb = bufs[0], *HB = bufs[1], *XS = bufs[2], *S = bufs[3], *O = bufs[4];
+    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wres's input stays pixel-major
+    bool x_planar = false;       // X is chunk-planar (common.h x_planar32): written so by the fused first block for conv_wres
     for (int i = i_lo; i < i_hi; ++i) {
         const DBlock& d = e->dblk[i];
         const int r = d.res, r2 = r / 2;
@@ -1142,13 +1155,19 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         p.x = X; p.x_bstride = (long long)r * r * d.cin; p.B = B; p.H = p.W = r; p.Cin = d.cin;
         p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
         p.bias = d.b0; p.act = 1; p.y = Hb;
+        const bool x_was_planar = x_planar;
+        if (x_planar) { p.x_planar32 = 1; x_planar = false; }
         bool fused_rgb = false, have_xs = false;
         if (i == 0 && rgb_y) {       // the whole block from the skip image in one kernel (conv_d0.hip): neither x nor h reaches HBM
             snprintf(tag, sizeof tag, "D.block0.r%d.%dx%dx%d", r, d.cin, d.cin, d.cout);
             const double px = (double)B * r * r, px2 = (double)B * r2 * r2;
             Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin) + 2.0 * px2 * 10.0 * d.cin * d.cout, px * 12.0 + px2 * 2.0 * d.cout);
-            const char* k = launch_dblock0(rgb_y, e->d_frgb_w, e->d_frgb_b, d.w0, d.b0, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur);
+            // the next block's first conv on conv_wres (with the blur-down by-product: nothing else reads this map): chunk-planar output
+            static const bool no_xs_fuse = glass_knob("GLASS_NO_XS_FUSE") != nullptr;
+            const bool planar = !no_planar && !no_xs_fuse && i + 1 < i_hi && e->dblk[i + 1].cin == d.cout && conv_wres_supported(d.cout, d.cout, r2, r2);
+            const char* k = launch_dblock0(rgb_y, e->d_frgb_w, e->d_frgb_b, d.w0, d.b0, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur, planar);
             if (k) {
+                x_planar = planar;
                 if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
                 if (e->profiling) e->tag_kernel[tag] = k;
                 std::swap(X, O);
@@ -1189,6 +1208,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
             }
             run_conv(e, p, tag, 2.0 * B * (double)r * r * 9 * d.cin * d.cin, 4.0 * B * (double)r * r * d.cin + (have_xs ? 0.5 * B * (double)r * r * d.cin : 0.0));
         }
+        if (!have_xs && x_was_planar && e->launch_error.empty()) e->launch_error = std::string("chunk-planar block input without the fused blur-down: ") + tag;
         if (!have_xs) {
             snprintf(tag, sizeof tag, "D.blurdown.r%d", r);
             Prof pr(e, tag, 2.0 * B * (double)r2 * r2 * d.cin * 16, 2.5 * B * (double)r * r * d.cin);

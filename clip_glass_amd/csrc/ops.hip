@@ -138,6 +138,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
             p.trgb_tab = tab;
         }
     }
+    p.x_planar32 = d->x_planar32;
     if (d->impl == 1) { if (!launch_conv_direct(p, 0)) { glass_set_error("direct conv: unsupported launch"); return GLASS_ERR_ARG; } }
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
@@ -278,8 +279,8 @@ extern "C" int glass_op_dblock0(int32_t device, int32_t B, int32_t R, int32_t im
     float* db0 = dv.up32(b0, Cin); float* db1 = dv.up32(b1, Cout);
     half_t* dout = dv.alloc<half_t>((size_t)B * Ro * Ro * Cout);
     OPREQ(dy && dw0 && dw1 && dws && dout, "device allocation failed");
-    if (impl == 0) {          // conv_d0.hip: the whole block in one kernel
-        OPREQ(launch_dblock0(dy, dfw, dfb, dw0, db0, dw1, dws, db1, dout, B, R, Cin, Cout, 0) != nullptr, "dblock0: unsupported shape");
+    if (impl == 0 || impl == 2) {          // conv_d0.hip: the whole block in one kernel (2: chunk-planar output)
+        OPREQ(launch_dblock0(dy, dfw, dfb, dw0, db0, dw1, dws, db1, dout, B, R, Cin, Cout, 0, impl == 2) != nullptr, "dblock0: unsupported shape");
     } else {                  // the two-kernel form it replaces: conv_stream<fromrgb> (h + the skip input to HBM) + conv_down
         half_t* dh = dv.alloc<half_t>((size_t)B * R * R * Cin);
         half_t* dxs = dv.alloc<half_t>((size_t)B * Ro * Ro * Cin);

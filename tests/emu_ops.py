@@ -26,8 +26,8 @@ def mfma_probe(a, b):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None, skip=None, xs_out=None):
-    x = np.asarray(x, np.float32)
+         torgb=None, skip=None, xs_out=None, planar_x=False):
+    x = np.asarray(x, np.float32)       # (planar_x: a device-side layout of the real op; the values are the same)
     Bx, H, W, Cin = x.shape
     B = B or Bx
     Cout, _, KS, _ = w.shape
@@ -556,9 +556,10 @@ def _d0_swz(row, chunk):
     return (row << 6) + ((chunk ^ ((row >> 2) & 3)) << 4)
 
 
-def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
+def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
     """y [B,3,R,R] skip image; frgb_w [32,3] scaled; w0 [32,32,3,3], w1 [64,32,3,3], wskip [64,32,1,1] reference layouts.
-    Returns [B,R/2,R/2,64] float32.  n_wg: number of emulated workgroups (contiguous step ranges -> priming mid-column)."""
+    Returns [B,R/2,R/2,64] float32.  n_wg: number of emulated workgroups (contiguous step ranges -> priming mid-column).
+    impl 2: the kernel's chunk-planar output addresses ([B][2][R/2][R/2][32]), un-permuted at the end."""
     f16, f32 = np.float16, np.float32
     y = np.asarray(y, f32)
     B, _, R, _ = y.shape
@@ -571,7 +572,8 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
     Cf = np.concatenate([(np.asarray(frgb_w, f32)[:, c] * f32(math.sqrt(2))).astype(f16) for c in range(3)] +
                         [(np.asarray(frgb_b, f32) * f32(math.sqrt(2))).astype(f16)]).reshape(4, 32)
     b0 = np.asarray(b0, f32); b1 = np.asarray(b1, f32)
-    out = np.full((B, Ro, Ro, 64), np.nan, f32)
+    out = np.full(B * Ro * Ro * 64, np.nan, f32)                # flat device buffer: the kernel's element addresses
+    planar = impl == 2
     lds = np.zeros(_D0_LDS // 2, f16)
     lane = np.arange(64); lr, kh = lane & 31, lane >> 5
 
@@ -703,8 +705,9 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
                 ox = 30 * tx + pix
                 for i in range(64):
                     if pix[i] < 30 and ox[i] < Ro and o_row < Ro:
-                        assert np.isnan(out[b, o_row, ox[i], nh * 32 + chv[i] * 8]), "output written twice"
-                        out[b, o_row, ox[i], nh * 32 + chv[i] * 8:nh * 32 + chv[i] * 8 + 8] = data[i]
+                        a = ((((b * 2 + nh) * Ro + o_row) * Ro + ox[i]) * 32 if planar else ((b * Ro + o_row) * Ro + ox[i]) * 64 + nh * 32) + chv[i] * 8
+                        assert np.isnan(out[a]), "output written twice"
+                        out[a:a + 8] = data[i]
 
     for wg in range(n_wg):
         first, last = wg * per_block, min((wg + 1) * per_block, n_steps)
@@ -718,4 +721,6 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0):
             need_prime = False
             run_item(b, tx, k, False)
     assert not np.isnan(out).any(), "some outputs were never written"
-    return out
+    if planar:
+        return np.ascontiguousarray(out.reshape(B, 2, Ro, Ro, 32).transpose(0, 2, 3, 1, 4)).reshape(B, Ro, Ro, 64)
+    return out.reshape(B, Ro, Ro, 64)

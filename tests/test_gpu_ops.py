@@ -306,6 +306,9 @@ def test_conv_glds_persistent_matches_tiled():
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
     y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
     np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, **kw2))
+    xs_p = np.full_like(xs, np.nan)
+    np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, xs_out=xs_p, planar_x=True, **kw2))
+    np.testing.assert_array_equal(xs, xs_p)
     f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
     xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
     check("persistent conv_glds blur-down by-product", xs,
@@ -347,6 +350,7 @@ def test_conv_wres_matches_tiled(B, H, W):
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     check("conv_wres vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
     np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, **kw))          # the ring is deterministic
+    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, planar_x=True, **kw))      # chunk-planar input (common.h x_planar32): same values
     # blur-down of the input as a by-product of the staged patches
     xs = np.full((B, H // 2, W // 2, C), np.nan, dtype=np.float32)
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
@@ -475,6 +479,7 @@ def test_dblock0_fused(B, R):
     args, ref = _dblock0_case(B, R)
     got = ops.dblock0(*args)
     check("D block0 fused B%d R%d" % (B, R), nchw(got), ref, 6e-3)
+    np.testing.assert_array_equal(got, ops.dblock0(*args, impl=2))     # the chunk-planar output (for conv_wres): same values, other addresses
     for name, sl in (("top", np.s_[:, :, :2, :]), ("bottom", np.s_[:, :, -2:, :]), ("left", np.s_[:, :, :, :2]), ("right", np.s_[:, :, :, -2:])):
         check("D block0 fused border " + name, nchw(got)[sl], ref[sl], 8e-3)
     if R >= 192 and R % 64 == 0 and ops is not None and hasattr(ops, "load_library"):

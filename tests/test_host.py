@@ -478,9 +478,9 @@ def test_bench_kernel_labels_resolve_to_pmc_rows():
     assert bench._canon_label("conv_tiled_kernel<3,1,8,64,xs,deep>")[1] == "3,1,8,64,false,false,false,true,false,false,true,false".split(",")
     assert bench._canon_label("conv_stream_kernel<torgb>")[1] == ["false", "true", "false"]
     labels = ["conv_gldsp_kernel<false,true,false>", "dblock0_kernel", "upfir2_kernel<false>", "upfir2_kernel<true>", "conv_s2_kernel",
-              "conv_gldsp_kernel<false,false,false>", "conv_stream_kernel<torgb>", "conv_tiled_kernel<3,1,8,64,torgb,deep>",
-              "conv_tiled_kernel<3,1,8,64,xs,deep>", "conv_gldsp_kernel<true,false,false>", "gemm_tiled_kernel<64>", "gemm_tiled_kernel<128>",
-              "D.blur.r512", "D.blur.r64", "G.torgb.r128", "G.torgb.r64", "clip.layernorm", "clip.attention", "noise", "mapping",
+              "conv_wres_kernel<true,false>", "conv_wres_kernel<false,true>", "conv_stream_kernel<torgb>",
+              "conv_gldsp_kernel<true,false,false>", "trgb_finish_kernel", "gemm_tiled_kernel<64>", "gemm_tiled_kernel<128>",
+              "D.blur.r512", "D.blur.r64", "G.torgb.r16", "G.torgb.r8", "clip.layernorm", "clip.attention", "noise", "mapping",
               "conv_glds_kernel<16>"]
     for name in labels:
         row = bench.match_kernel(name, table)
