@@ -1,57 +1,118 @@
 // conv_wres.hip — 3x3 stride-1 convolution 64 -> 64 channels at 512^2 (G's last-but-one conv with its toRGB, D's second block's first conv
 // with the blur-down by-product; stylegan2/modules.py:920-967, models.py:852-870, modules.py:1238-1254) with the WHOLE weight tensor
-// resident in LDS and the input patches on an LDS-DMA double buffer — the ping-pong schedule of conv_glds.hip's persistent kernel.
+// resident in LDS and the input patches on a four-deep LDS-DMA ring — the ping-pong schedule of conv_glds.hip's persistent kernel.
 //
 // Why its own kernel (round 6).  Rounds 1-5 ran these two layers on conv_tiled<3,1,8,64>: register-staged, three 256-thread workgroups per
 // CU, 1.84 + 1.56 ms where the HBM roof (2.1 GB in + 2.1 GB out per layer at 6.3 TB/s) is 0.7 ms.  A tile of that kernel moves 43 KB of
 // patch AND the layer's whole 74 KB of weights through registers into LDS; loads, MFMAs (40 % busy) and stores run back to back per
 // tile.  Here the 9 x 64 x 64 weights (73 728 B) are loaded ONCE per workgroup (per candidate for pre-modulated per-sample weights: a
-// workgroup walks a contiguous range of tiles), a tile is 16 rows x 32 px x 64 channels on eight waves (wave = 2 rows x 2 n blocks), its two
-// 32-channel patch chunks ARE the double buffer (chunk 0 of tile t + 1 lands while chunk 1 of tile t is read), and the K loop is six
-// phases of 24 MFMAs on 24 fragments (one tap row of one chunk) played as a ping-pong of the two wave groups:
-//     load interval: 24 ds_read_b128, [vmcnt wait], lgkmcnt(0) | barrier | MFMA interval: 24 MFMAs at s_setprio 1, <= 3 ring pieces | barrier
-// with waves 4-7 one barrier behind waves 0-3 (one wave of each group per SIMD).  Per tile and wave: 10 patch pieces of 1 KB
-//     phase 0: chunk 1 of THIS tile (its buffer held the output slices of the previous tile's epilogue until then) — waited for in phase 2
-//     phase 3: chunk 0 of the NEXT tile (buffer 0 is free after phase 2)                                             — waited for in phase 5
-// (the epilogue operands — per-channel constants, noise values, toRGB table — are LDS-DMA pieces of phase 1)
-// (vmcnt(0) both times: everything else in the queue — the epilogue's stores, the by-product's — is at least a phase older).
-// Epilogue = conv_glds.hip's: operands by LDS-DMA, constants through LDS, output slices transposed through patch buffer 1, 16-byte
-// row-order stores; toRGB (TRGB) and the blur-down by-product (XS) as there.  Same MFMA order per accumulator as conv_tiled.
+// workgroup walks a contiguous range of tiles), a tile is 16 rows x 32 px x 64 channels on eight waves (wave = 2 rows x 2 n blocks).
+//
+// Second form (this one).  The first form kept the patch as two 32-channel chunks = two 40 KB buffers: one chunk in flight while the other
+// was read, requested two phases (~4000 clocks) ahead of its wait.  Ablations (developer build, GLASS_WRES_ABLATE; DESIGN "Round 6"): without
+// MFMAs, fragment reads and epilogue the kernel still took 1.1 of its 1.7 ms — one 40 KB request per CU and a wait per half tile is a
+// latency chain (10.5 MB per CU at 4.8 B/clock); the epilogue was another 22 %.  Now
+//   * the patch is FOUR 16-channel chunks (18 x 34 px x 32 B = 19 584 B each) = four buffers: chunk c of tile t + 1 is requested in phase
+//     c + 1 of tile t, right behind the last read of chunk c of tile t — three chunks (59 KB) are in flight all the time and every chunk has
+//     three phases + the epilogue (> 7000 clocks) to land;
+//   * a phase is one chunk: 36 MFMAs per wave on 12 patch fragments (4 rows x 3 columns, each feeding up to three tap rows) + 18 weight
+//     fragments — 0.83 fragment reads per MFMA where the tap-row phases of the first form read 1.0 (the kernel sits at the LDS read rate);
+//   * the epilogue needs no LDS: a lane pair (px, kh = 0 / 1) exchanges quads with v_permlane32_swap and each lane stores 16 contiguous
+//     bytes; the tile's addresses are scalar bases + lane constants (the first form spent ~250 of its ~1000 epilogue instructions on
+//     64-bit address arithmetic) — so no patch buffer is borrowed for the output and the ring never stops;
+//   * counted waits: every wave issues exactly three patch pieces per phase (2 x 512 vectors + a 25-lane tail per wave), so "chunk c has
+//     landed" is vmcnt(<= the number of pieces requested since) — stores and operand pieces in between only make the wait earlier.
+// Ping-pong: waves 4-7 run one barrier behind waves 0-3 (one wave of each group per SIMD):
+//     load interval: 12 ds_read_b128, counted vmcnt, lgkmcnt(0) | barrier | MFMA interval: 36 MFMAs at s_setprio 1, the next tap row's six
+//     weight fragments behind each tap row, the ring's three pieces behind the first four MFMAs | barrier
+// Input layout: pixel-major [B][H][W][64], or chunk-planar [B][4][H][W][16] (common.h x_planar16) written by upfir2<false> / dblock0 for
+// this kernel — pixel-major, the four 32-byte quarters of every 128-byte line cross the fabric at four different times.
+// toRGB (TRGB) and the blur-down by-product (XS) as in conv_glds.hip.  K order per accumulator: chunk, tap row, tap column.
 #include "common.h"
 #include "kernels.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
 constexpr int NT = 64, NTHR = 512, TW = 32, TH = 16, RW = 2;
 constexpr int PH = TH + 2, PW = TW + 2;
-constexpr int NVA = PH * PW * 4;                         // 16-byte vectors of a patch chunk (2448)
-constexpr int NA = (NVA + NTHR - 1) / NTHR;              // 5 pieces per thread per chunk
-constexpr int A_BYTES = NA * NTHR * 16;                  // 40960
-constexpr int NVW = 2 * 9 * NT * 4;                      // 4608 vectors of the weight image [chunk][tap][n][32 ch]
+constexpr int NCH = 4;                                   // 16-channel chunks = ring buffers
+constexpr int NVA = PH * PW * 2;                         // 16-byte vectors of a patch chunk (1224): 2 x 512 + 8 waves x 25
+constexpr int NTAIL = (NVA - 2 * NTHR) / 8;              // 25 lanes of every wave carry the third piece
+constexpr int A_BYTES = (NVA * 16 + 511) / 512 * 512;    // 19968
+constexpr int NVW = NCH * 9 * NT * 2;                    // 4608 vectors of the weight image [chunk][tap][n][16 ch]
 constexpr int NWP = NVW / NTHR;                          // 9 pieces per thread
-constexpr int OFF_W = 2 * A_BYTES;                       // 81920
-constexpr int OFF_C = OFF_W + NVW * 16;                  // 155648: [dscale | bias | shift][NT] fp32
+constexpr int OFF_W = NCH * A_BYTES;                     // 79872
+constexpr int OFF_C = OFF_W + NVW * 16;                  // 153600: [dscale | bias | shift][NT] fp32
 constexpr int OFF_T = OFF_C + 3 * NT * 4;                // TRGB: toRGB weight rows [hi r,g,b | lo r,g,b][NT] fp16
 constexpr int OFF_N = OFF_T + 6 * NT * 2;                // the tile's noise values [8 waves][2 rows][32 px] fp32
-constexpr int LDS_BYTES = OFF_N + 8 * 64 * 4;            // 159232
-static_assert(LDS_BYTES <= 163840 && NVW % NTHR == 0 && 8 * RW * 32 * 80 <= A_BYTES, "one workgroup per CU; the output slices fit a patch buffer");
+constexpr int OFF_Y = OFF_N + 8 * 64 * 4;                // TRGB: the previous skip image's taps of the tile [8 waves][3 ch][2 rows][17 cols] fp32 (128 slots per wave)
+constexpr int LDS_BYTES = OFF_Y + 8 * 128 * 4;           // 161280
+static_assert(LDS_BYTES <= 163840 && NVW % NTHR == 0 && 2 * NTHR + 8 * NTAIL == NVA && NTAIL <= 64, "one workgroup per CU; three pieces per wave and chunk");
 
-__device__ __attribute__((aligned(64))) half_t g_wres_zero_page[32];   // zero-initialised: source of the zero padding
+__device__ __attribute__((aligned(256))) float g_wres_zero_page[64];   // zero-initialised: source of the zero padding and of absent operands
+__device__ __attribute__((aligned(256))) float g_wres_ones_page[64] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                                                       1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
-__device__ __forceinline__ void dma16(const half_t* src, char* lds_wave_base) {    // LDS destination = wave-uniform base + lane * 16
+__device__ __forceinline__ void dma16(const void* src, char* lds_wave_base) {      // LDS destination = wave-uniform base + lane * 16
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ void dma4(const float* src, char* lds_wave_base) {      // LDS destination = wave-uniform base + lane * 4
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)lds_wave_base, 4, 0, 0);
 }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-#define WR_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// v_permlane32_swap, register by register: the upper 32 lanes of `a` trade places with the lower 32 lanes of `b`
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void swap32(h4& a, h4& b) {
+    u2v x = __builtin_bit_cast(u2v, a), y = __builtin_bit_cast(u2v, b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x[e], y[e], false, false);
+        x[e] = r[0];
+        y[e] = r[1];
+    }
+    a = __builtin_bit_cast(h4, x);
+    b = __builtin_bit_cast(h4, y);
+}
+__device__ __forceinline__ void swap32(h8& a, h8& b) {
+    u4w x = __builtin_bit_cast(u4w, a), y = __builtin_bit_cast(u4w, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x[e], y[e], false, false);
+        x[e] = r[0];
+        y[e] = r[1];
+    }
+    a = __builtin_bit_cast(h8, x);
+    b = __builtin_bit_cast(h8, y);
+}
+#define WR_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Fragment reads of the K loop as inline assembly: hipcc puts lgkmcnt(0) in front of the first MFMA that uses ANY outstanding ds_read, i.e. it
+// also waits for the reads requested a moment ago for the NEXT tap row (stamps: 2400-3800 clocks per interval of 36 MFMAs).  A read it cannot see
+// needs no wait in its eyes; the waits are the explicit ones below, tied to the registers they release by "+v" operands.
+#define WR_LDS_RD(dst, vaddr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(vaddr), "n"(imm))
+#define WR_WAIT_LGKM6(a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)::"memory")
+#define WR_WAIT_LGKM4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
+// developer build only (make AB=1, GLASS_WRES_ABLATE): timing experiments that switch parts of a tile off — 1 the whole epilogue, 2 its global
+// stores, 4 the K loop's MFMAs, 8 the patch fragment reads of the load interval, 16 the weight fragment reads, 32 the ring's requests (WRONG RESULTS)
+#ifdef GLASS_AB_KNOBS
+#define WR_ABL_ARG , int abl
+#define WR_ABL(bit) (abl & (bit))
+// bit 64: shader-clock stamps of the sixth tile of one workgroup in the middle of the grid, printed by the launcher (which synchronises)
+__device__ unsigned long long* g_wres_trace = nullptr;
+#define WRT(ph) \
+    if (WR_ABL(64) && blockIdx.x == 77 && (threadIdx.x & 63) == 0 && id - first == 5) g_wres_trace[(ph) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime()
+#else
+#define WR_ABL_ARG
+#define WR_ABL(bit) false
+#define WRT(ph)
+#endif
 }  // namespace
 
 template <bool TRGB, bool XS>
-__global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int tiles_x, int tiles_y, int PT, int per_wg) {
+__global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int tiles_x, int tiles_y, int PT, int per_wg WR_ABL_ARG) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2;                 // 0: waves 0-3 lead; 1: waves 4-7 run one barrier behind
@@ -72,73 +133,102 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
     Item cur = decode(id);
 
     // ---- DMA sources --------------------------------------------------------------------------------------------------------------
-    // vector v = k * 512 + t of an LDS image sits at byte v * 16: row = v >> 2, physical chunk v & 3 holding the row's LOGICAL 8-channel
-    // chunk (v & 3) ^ ((row >> 2) & 3) (swizzle on the source side: LDS-DMA writes lane-linear)
+    // vector v of a patch chunk sits at byte v * 16: pixel v >> 1, physical half v & 1 holding the pixel's LOGICAL 8-channel half
+    // (v & 1) ^ ((pixel >> 3) & 1) (swizzle on the source side — LDS-DMA writes lane-linear: any 16 consecutive pixels of a fragment read then
+    // cover the 64 banks once).  Thread t carries vectors t, 512 + t and (lanes < 25) 1024 + 25 wave + lane.
+    const int pixs = p.x_planar16 ? 16 : p.Cin;                   // elements between pixels / between the 16-channel chunks of a pixel
+    const int c_step = p.x_planar16 ? p.H * p.W * 16 : 16;
+    int a_geo[3];             // lane constants: patch row | patch column << 8 | logical half << 16 | vector exists << 17
+    {
+        const int t = opaque(threadIdx.x), lane = t & 63;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int v = k < 2 ? k * NTHR + t : 2 * NTHR + wave * NTAIL + lane;
+            const int pix = v >> 1, pr = pix / PW, pc = pix - pr * PW;
+            a_geo[k] = opaque(pr | (pc << 8) | ((((v & 1) ^ ((pix >> 3) & 1))) << 16) | ((k < 2 || lane < NTAIL) ? 1 << 17 : 0));
+        }
+    }
     const half_t* xb = p.x;
-    int a_src[NA];            // element offset into the image (< 2^31: launcher), or -1 = zero page
+    int a_src[3];             // element offset into the image (< 2^31: launcher), or -1 = zero page
     auto aim_a = [&](const Item& w) {
-        const int t = opaque(threadIdx.x);
         xb = p.x + (long long)w.b * p.x_bstride;
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            const int v = k * NTHR + t, pix = v >> 2;
-            const int pr = pix / PW, pc = pix - pr * PW;
-            const int iy = w.ty0 - 1 + pr, ix = w.tx0 - 1 + pc;
-            const int lc = (v & 3) ^ ((pix >> 2) & 3);
-            const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_src[k] = ok ? (iy * p.W + ix) * (p.x_planar32 ? 32 : p.Cin) + lc * 8 : -1;
+        for (int k = 0; k < 3; ++k) {
+            const int iy = w.ty0 - 1 + (a_geo[k] & 255), ix = w.tx0 - 1 + ((a_geo[k] >> 8) & 255);
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            a_src[k] = ok ? (iy * p.W + ix) * pixs + ((a_geo[k] >> 16) & 1) * 8 : -1;
         }
     };
-    // the second chunk of a pixel: 32 channels on in the pixel-major layout, a plane on in the chunk-planar one (common.h: there a 128-byte
-    // line holds ONE chunk of two pixels — pixel-major, its two halves were fetched a half tile apart and crossed the fabric twice)
-    const int c_step = p.x_planar32 ? p.H * p.W * 32 : 32;
-    auto issue_a1 = [&](int k, int c) {        // piece k of chunk c -> patch buffer c (k is a constant wherever this is called)
-        char* dst = smem + c * A_BYTES + wave * 1024 + k * (NTHR * 16);
-        dma16(a_src[k] >= 0 ? xb + a_src[k] + c * c_step : g_wres_zero_page + (threadIdx.x & 3) * 8, dst);
+    // (the page's address is taken ONCE: inside the tile loop it was a GOT load + lgkmcnt(0) in the middle of every MFMA interval)
+    const half_t* zp;
+    const float* ones_page;
+    {
+        unsigned long long za = (unsigned long long)g_wres_zero_page, oa = (unsigned long long)g_wres_ones_page;
+        asm volatile("" : "+s"(za), "+s"(oa));
+        zp = (const half_t*)za;
+        ones_page = (const float*)oa;
+    }
+    auto issue_chunk = [&](int c) {            // the three pieces of chunk c -> ring buffer c (c is a constant wherever this is called)
+        char* buf = smem + c * A_BYTES;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) dma16(a_src[k] >= 0 ? xb + a_src[k] + c * c_step : zp, buf + (k * NTHR + wave * 64) * 16);
+        if ((a_geo[2] >> 17) & 1) dma16(a_src[2] >= 0 ? xb + a_src[2] + c * c_step : zp, buf + (2 * NTHR + wave * NTAIL) * 16);
     };
     auto issue_w = [&](int b) {                // the weight image of candidate b (shared weights: w_bstride = 0)
         const half_t* wb = p.w + (long long)b * p.w_bstride;
         const int t = opaque(threadIdx.x);
 #pragma unroll
         for (int k = 0; k < NWP; ++k) {
-            const int v = k * NTHR + t, row = v >> 2;              // row = (c * 9 + tap) * 64 + n
+            const int v = k * NTHR + t, row = v >> 1;              // row = (c * 9 + tap) * 64 + n: 32 bytes, halves swizzled by (n >> 3) & 1
             const int n = row & 63, ct = row >> 6, c = ct / 9, tap = ct - 9 * c;
-            const int lc = (v & 3) ^ ((row >> 2) & 3);
-            dma16(wb + ((long long)tap * p.Neff + n) * p.Cin + c * 32 + lc * 8, smem + OFF_W + wave * 1024 + k * (NTHR * 16));
+            const int lh = (v & 1) ^ ((n >> 3) & 1);
+            dma16(wb + ((long long)tap * p.Neff + n) * p.Cin + c * 16 + lh * 8, smem + OFF_W + wave * 1024 + k * (NTHR * 16));
         }
     };
 
-    {   // operand arrays the layer does not have keep their neutral values for the kernel's lifetime (the epilogue reads all of them)
-        const int t = threadIdx.x;
-        float* Cc = (float*)(smem + OFF_C);
-        if (t < NT) {
-            if (!p.dscale) Cc[t] = 1.f;
-            if (!p.bias) Cc[NT + t] = 0.f;
-            if (!p.shift) Cc[2 * NT + t] = 0.f;
-        }
-        if (!p.noise) *(float*)(smem + OFF_N + t * 4) = 0.f;
+    if (!p.noise) *(float*)(smem + OFF_N + threadIdx.x * 4) = 0.f;     // (absent per-channel operands are DMA'd from the ones / zero pages)
+    float tb[3] = {0.f, 0.f, 0.f};             // toRGB bias: read ONCE (a register load inside the tile loop waits for the whole ring)
+    if (TRGB) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)         // (readfirstlane: the value is CONSUMED here, so hipcc's wait for it sits here and not in the loop)
+            tb[cc] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.trgb_b[cc])));
     }
     __syncthreads();
     aim_a(cur);
     issue_w(cur.b);
-#pragma unroll
-    for (int k = 0; k < NA; ++k) issue_a1(k, 0);
-    WR_WAIT_VM0();
+    issue_chunk(0);
+    issue_chunk(1);
+    issue_chunk(2);
+    WR_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
-    h8 wf[2][3][2][2];                         // weight fragments of the current / the next phase: [phase parity][tx][kk][j]
-    int wbase[2][2];                           // lane-constant LDS offsets of the weight image's fragment rows [chunk][kk], computed once and kept
-                                               // opaque: rebuilt per read they were ~100 VALU instructions inside every MFMA interval
+
+    // lane-constant LDS offsets of the fragments, computed once and kept opaque (rebuilt per read they were ~100 VALU instructions inside
+    // every MFMA interval)
+    int xoff[4][3];                            // patch fragment of row wave * 2 + rr, column lr + tx: pixel * 32 + swizzled half
+    int wbase[2];                              // weight fragment rows of chunks 0-1 / 2-3 (the immediate offset of a ds_read reaches 64 KB)
+    int yoff;                                  // output: byte offset of the lane's 16 bytes inside its wave's row pair
+    int lds_base;
     {
         const int t = threadIdx.x, lr = t & 31, kh = (t >> 5) & 1;
+        const int lds0 = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of smem (the asm reads address LDS directly)
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
+        for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) wbase[cc][kk] = opaque(OFF_W + cc * 9 * NT * 64 + lr * 64 + (((kk * 2 + kh) ^ ((lr >> 2) & 3)) << 4));
+            for (int tx = 0; tx < 3; ++tx) {
+                const int pix = (wave * RW + rr) * PW + lr + tx;
+                xoff[rr][tx] = opaque(lds0 + pix * 32 + ((kh ^ ((pix >> 3) & 1)) << 4));
+            }
+        const int wl = lds0 + OFF_W + lr * 32 + ((kh ^ ((lr >> 3) & 1)) << 4);
+        wbase[0] = opaque(wl);
+        wbase[1] = opaque(wl + 2 * 9 * NT * 32);
+        yoff = opaque((lr * p.Cout + 8 * kh) * 2);
+        lds_base = lds0;
     }
-    bool have_w = false;                       // (uniform) phase 0's fragments were requested in the previous tile's last phase
+    h8 wf[2][3][2];                            // weight fragments of the current / the next tap row: [parity][tx][j]
+    bool have_w = false;                       // (uniform) chunk 0's first tap row was requested in the previous tile's last phase
     for (;;) {
         const bool has_next = id + 1 < last;
-        const Item nxt = has_next ? decode(id + 1) : cur;     // the ring never branches: the last tile re-requests itself (nobody reads that buffer)
+        const Item nxt = has_next ? decode(id + 1) : cur;     // the ring never branches: the last tile re-requests itself (nobody reads those buffers)
         const int b = cur.b, ty0 = cur.ty0, tx0 = cur.tx0;
 
         f16x acc[RW][2];
@@ -149,158 +239,168 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-        // epilogue operands (per-channel constants, the tile's noise values, the toRGB table) by LDS-DMA, ahead of phase 3's patch pieces
+        // epilogue operands (per-channel constants, the tile's noise values, the toRGB table) by LDS-DMA: the same number of pieces from every
+        // wave whatever the layer has (absent arrays come from the ones / zero pages; waves 3-7 repeat an array: same bytes, same place)
         auto prefetch_epilogue = [&]() {
-            const int t = opaque(threadIdx.x), lr = t & 31, kh = (t >> 5) & 1;
-            if (wave == 0) {                   // channels t < NT = 64: [dscale | bias | shift][NT] fp32
-                char* cc = smem + OFF_C;
-                if (p.dscale) dma4(p.dscale + (long long)b * p.ds_stride + t, cc);
-                if (p.bias) dma4(p.bias + t, cc + NT * 4);
-                if (p.shift) dma4(p.shift + (long long)b * p.ds_stride + t, cc + 2 * NT * 4);
-            }
+            const int t = opaque(threadIdx.x), lane = t & 63, lr = t & 31, kh = (t >> 5) & 1;
+            const int arr = wave % 3;          // 0 dscale, 1 bias, 2 shift
+            const float* src = arr == 0 ? (p.dscale ? p.dscale + (long long)b * p.ds_stride : ones_page)
+                             : arr == 1 ? (p.bias ? p.bias : (const float*)zp)
+                                        : (p.shift ? p.shift + (long long)b * p.ds_stride : (const float*)zp);
+            dma4(src + lane, smem + OFF_C + arr * NT * 4);
             if (p.noise) dma4(p.noise + ((long long)(b / p.batch_size) * p.Ho + ty0 + wave * RW + kh) * p.Wo + tx0 + lr, smem + OFF_N + wave * 256);
-            if (TRGB && t < 6 * (NT / 8)) {
-                const int row6 = t / (NT / 8), piece = t % (NT / 8);
+            if (TRGB && lane < 6 * (NT / 8)) {
+                const int row6 = lane / (NT / 8), piece = lane % (NT / 8);
                 const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
-                dma16(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8, smem + OFF_T + wave * 1024);
+                dma16(p.trgb_tab + ((long long)b * 32 + n) * NT + piece * 8, smem + OFF_T);
+            }
+            if (TRGB && p.trgb_yprev) {
+                // the wave's two output rows share the previous image's rows my - 1, my and columns mx0 - 1 .. mx0 + 15 (clamped loads, zero weight
+                // outside: trgb_skip): 3 x 2 x 17 values as two pieces (a load into REGISTERS here made hipcc wait vmcnt(0) — for the whole ring)
+                const int my = (ty0 + wave * RW) >> 1, mx0 = tx0 >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
+                const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int e = min(lane + 64 * u, 101), cc = e / 34, rem = e - cc * 34, dy = rem / 17, dx = rem - dy * 17;
+                    dma4(yp + (cc * h2 + max(my - 1 + dy, 0)) * w2 + max(mx0 - 1 + dx, 0), smem + OFF_Y + wave * 512 + u * 256);
+                }
             }
         };
+        WRT(0);
         if (grp) __builtin_amdgcn_s_barrier();     // group 1 falls one barrier behind: its load intervals face group 0's MFMA intervals
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int c = q / 3, ty = q - 3 * c;
+        for (int c = 0; c < NCH; ++c) {
             const char* As = smem + c * A_BYTES;
-            // weight fragments of a phase: [tx][kk][j]; the weights are resident, so the NEXT phase's twelve are requested in this phase's
-            // MFMA interval (two per group of four MFMAs) into the other register set — 24 reads in the load interval took longer than the
-            // partner's 24 MFMAs (~45 clocks per read and wave with four waves reading), the matrix pipe idled a third of every interval
-            auto rd_w = [&](int qq, int tx, int kk, int j) {      // one instruction: lane-constant base + immediate offset
-                const int cc = qq / 3, tyy = qq - 3 * cc;
-                return *(const h8*)(smem + wbase[cc][kk] + ((tyy * 3 + tx) * NT + j * 32) * 64);
-            };
+            // weight fragment (tap row s % 3 of chunk (s / 3) % 4, column tx, n block j) -> dst: one instruction, lane-constant base + immediate offset
+#define WR_RD_W(dst, s_, tx_, j_)                                                                                                              \
+    do {                                                                                                                                       \
+        const int cc_ = ((s_) / 3) % NCH, tyy_ = (s_) % 3;                                                                                     \
+        if (WR_ABL(16)) dst = h8{0, 0, 0, 0, 0, 0, 0, 0};                                                                                      \
+        else WR_LDS_RD(dst, wbase[cc_ >> 1], (((cc_ & 1) * 9 + tyy_ * 3 + (tx_)) * NT + (j_) * 32) * 32);                                       \
+    } while (0)
             // ---- load interval ---------------------------------------------------------------------------------------------------
-            h8 xf[3][2][RW];                   // [tx][kk][i]
-            {
-                const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
-                if (q == 0 && !have_w) {       // first tile of the range / behind a weight reload: nobody prefetched phase 0's fragments
-#pragma unroll
-                    for (int tx = 0; tx < 3; ++tx)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) wf[0][tx][kk][j] = rd_w(0, tx, kk, j);
-                }
+            h8 xf[4][3];                       // [patch row rr = i + ty][tx]
+            // chunk c of this tile has landed: it was requested three phases ago, and at least 3 x (phases since) pieces behind it (8 output
+            // stores of the previous tile on top of that for chunks 0-2; chunk 3's epilogue operands were requested AHEAD of phase 1's pieces)
+            if (c == 3) WR_WAIT_VM(6); else WR_WAIT_VM(14);
+            WRT(1 + 5 * c);
+            if (c == 0 && !have_w) {           // first tile of the range / behind a weight reload: nobody prefetched the first tap row
 #pragma unroll
                 for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-                        const int lc = kk * 2 + kh;
-#pragma unroll
-                        for (int i = 0; i < RW; ++i) {
-                            const int pix = (wave * RW + i + ty) * PW + lr + tx;
-                            xf[tx][kk][i] = *(const h8*)(As + pix * 64 + ((lc ^ ((pix >> 2) & 3)) << 4));
-                        }
-                    }
+                    for (int j = 0; j < 2; ++j) WR_RD_W(wf[0][tx][j], 0, tx, j);
+                WR_WAIT_LGKM6(wf[0][0][0], wf[0][0][1], wf[0][1][0], wf[0][1][1], wf[0][2][0], wf[0][2][1]);
             }
-            if (q == 3) aim_a(nxt);            // (~150 address instructions with divisions: in the short load interval, not between MFMAs; this tile's
-                                               // pieces were all issued in phase 0)
-            if (q == 2 || q == 5) WR_WAIT_VM0();   // this tile's chunk 1 / the next tile's chunk 0 (and the epilogue operands) have landed
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
+                    if (!WR_ABL(8)) WR_LDS_RD(xf[rr][tx], xoff[rr][tx], c * A_BYTES);
+                    else xf[rr][tx] = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+            if (c == 1) aim_a(nxt);            // (the pieces of THIS tile's chunk 3 went out in phase 0; from here on the ring requests the next tile)
+            WR_WAIT_LGKM6(xf[0][0], xf[0][1], xf[0][2], xf[1][0], xf[1][1], xf[1][2]);
+            WR_WAIT_LGKM6(xf[2][0], xf[2][1], xf[2][2], xf[3][0], xf[3][1], xf[3][2]);
+            WRT(2 + 5 * c);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            WRT(3 + 5 * c);
             // ---- MFMA interval ---------------------------------------------------------------------------------------------------
             auto ring_pieces = [&]() {
-                if (q == 0) {
-#pragma unroll
-                    for (int k = 0; k < NA; ++k) issue_a1(k, 1);
-                } else if (q == 1) {
-                    prefetch_epilogue();
-                } else if (q == 3) {
-#pragma unroll
-                    for (int k = 0; k < NA; ++k) issue_a1(k, 0);
+                if (WR_ABL(32)) return;
+                if (c == 0) {
+                    issue_chunk(3);            // of THIS tile: buffer 3 was read last in the previous tile's phase 3
+                } else {
+                    if (c == 1) prefetch_epilogue();
+                    issue_chunk(c - 1);        // of the NEXT tile: both groups are past their last read of that buffer
                 }
             };
-            // XS by-product (a chunk's first phase): FIR 4x4 (pad 1) + ::2 of this chunk of the INPUT map, 8 x 16 pixels x 4 parts = one vector
-            // per thread, from the patch: one patch row of four vectors per MFMA group, folded a group later — in the MFMA stream's shadow
-            // (explicit FMA forms: conv_glds.hip)
-            const bool xs_on = XS && ty == 0;
-            h8 xa[4], s03, s12, k125, k375;
-            int xs_part = 0, xs_ly = 0, xs_lx = 0;
-            if (xs_on) {
+            // XS by-product: FIR 4x4 (pad 1) + ::2 of this chunk of the INPUT map, 8 x 16 pixels x 2 halves = 256 vectors: a lane pair (l, l + 32)
+            // shares one — lanes < 32 filter tap rows 0-1, lanes >= 32 rows 2-3, v_permlane32_swap brings the four rows together in the lower
+            // lane, which folds them in conv_tiled<xs>'s order (explicit FMA forms: conv_glds.hip) and stores 16 bytes
+            h8 xa[4], hr[2], k125, k375;
+            int xs_half = 0, xs_ly = 0, xs_lx = 0, xs_jy = 0;
+            if (XS) {
                 const int tq = opaque(threadIdx.x);
-                xs_part = tq & 3; xs_ly = tq >> 6; xs_lx = (tq >> 2) & 15;
+                xs_half = tq & 1; xs_lx = (tq >> 1) & 15; xs_jy = (tq >> 5) & 1; xs_ly = wave;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { k125[e] = (half_t)0.125f; k375[e] = (half_t)0.375f; }
             }
-            auto xs_read = [&](int jy) {
+            auto xs_read = [&](int r2) {       // tap row 2 * xs_jy + r2
 #pragma unroll
                 for (int jx = 0; jx < 4; ++jx) {
-                    const int P = (2 * xs_ly + jy) * PW + 2 * xs_lx + jx;
-                    xa[jx] = *(const h8*)(As + P * 64 + ((xs_part ^ ((P >> 2) & 3)) << 4));
+                    const int P = (2 * xs_ly + 2 * xs_jy + r2) * PW + 2 * xs_lx + jx;
+                    const int va = lds_base + P * 32 + ((xs_half ^ ((P >> 3) & 1)) << 4);
+                    WR_LDS_RD(xa[jx], va, c * A_BYTES);
                 }
             };
-            auto xs_fold = [&](int jy) {
-                const h8 hr = __builtin_elementwise_fma(xa[1] + xa[2], k375, (xa[0] + xa[3]) * k125);     // (conv_tiled<xs>'s contraction, made explicit there too)
-                if (jy == 0) s03 = hr;
-                else if (jy == 1) s12 = hr;
-                else if (jy == 2) s12 = s12 + hr;
-                else s03 = s03 + hr;
+            auto xs_fold = [&](int r2) {
+                hr[r2] = __builtin_elementwise_fma(xa[1] + xa[2], k375, (xa[0] + xa[3]) * k125);     // (conv_tiled<xs>'s contraction, made explicit there too)
             };
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx)
+            for (int ty = 0; ty < 3; ++ty) {
+                const int s = c * 3 + ty;
+                // the NEXT tap row's six weight fragments (the next tile's first row behind the last one: the weights do not change) are requested at
+                // the TOP of this row: hipcc waits lgkmcnt(0) in front of a row's first MFMA whatever the order — requested between the MFMA groups,
+                // the last pair was 4 MFMAs old at that wait and every tap row began with an exposed LDS round trip (stamps: 2400-3800 clocks per
+                // interval of 36 MFMAs); at the top they have the row's 12 MFMAs to land
+                __builtin_amdgcn_sched_barrier(0);
+                // this row's fragments (requested at the top of the previous row — the previous phase's last row for ty = 0) have landed: nothing
+                // newer is outstanding at this point, so the wait is for reads that had 12 MFMAs to come back
+                WR_WAIT_LGKM6(wf[s & 1][0][0], wf[s & 1][0][1], wf[s & 1][1][0], wf[s & 1][1][1], wf[s & 1][2][0], wf[s & 1][2][1]);
+                if (XS && ty > 0) WR_WAIT_LGKM4(xa[0], xa[1], xa[2], xa[3]);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
+                for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) WR_RD_W(wf[(s + 1) & 1][tx][j], s + 1, tx, j);
+                if (XS) {                      // two tap rows per lane: requested beside the weight fragments, folded a tap row later
+                    if (ty == 1) xs_fold(0);
+                    if (ty == 2) xs_fold(1);
+                    if (ty < 2) xs_read(ty);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int i = 0; i < RW; ++i) acc[i][j] = mfma32(wf[q & 1][tx][kk][j], xf[tx][kk][i], acc[i][j]);
-                    const int m = tx * 2 + kk;
-                    if (m == 0) { __builtin_amdgcn_sched_barrier(0); ring_pieces(); __builtin_amdgcn_sched_barrier(0); }
-                    {   // the next phase's weight fragments (phase 0 of the next tile behind phase 5)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) wf[(q + 1) & 1][tx][kk][j] = rd_w((q + 1) % 6, tx, kk, j);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (xs_on && m >= 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (m >= 2) xs_fold(m - 2);
-                        if (m <= 4) xs_read(m - 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                        for (int i = 0; i < RW; ++i)
+                            if (!WR_ABL(4)) acc[i][j] = mfma32(wf[s & 1][tx][j], xf[i + ty][tx], acc[i][j]);
+                    if (ty == 0 && tx == 0) { __builtin_amdgcn_sched_barrier(0); ring_pieces(); __builtin_amdgcn_sched_barrier(0); }
                 }
-            if (xs_on) {
+            }
+            if (XS) {
+                // lanes < 32 hold rows 0, 1; lanes >= 32 rows 2, 3: the swap hands the upper lanes' registers to the lower lanes
+                h8 r2v = hr[0], r3v = hr[1], d0 = hr[0], d1 = hr[1];     // (upper lanes: hr[0] = row 2, hr[1] = row 3)
+                swap32(r2v, d0);               // lower lanes of d0 / d1 = the upper lanes' rows 2 / 3
+                swap32(r3v, d1);
+                const h8 s03 = hr[0] + d1, s12 = hr[1] + d0;
                 const h8 o = __builtin_elementwise_fma(s12, k375, s03 * k125);
-                *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + xs_ly) * (p.W >> 1) + (tx0 >> 1) + xs_lx) * p.Cin + c * 32 + xs_part * 8) = o;
+                if (xs_jy == 0)
+                    *(h8*)(p.xs_out + (((long long)b * (p.H >> 1) + (ty0 >> 1) + xs_ly) * (p.W >> 1) + (tx0 >> 1) + xs_lx) * p.Cin + c * 16 + xs_half * 8) = o;
             }
             __builtin_amdgcn_s_setprio(0);
+            WRT(4 + 5 * c);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            WRT(5 + 5 * c);
         }
 
-        // ---- epilogue (conv_glds.hip's): group 0 re-aligns first; every fragment read of the tile was complete before the barrier both groups
-        // have passed by then, and the phase-5 wait + barrier made the operands visible.  A candidate switch of per-sample weights reloads
-        // the weight image here (every wave is out of the K loop) and is waited for behind the epilogue. ---------------------------------
+        // ---- epilogue: group 0 re-aligns first (a weight reload must not overtake group 1's last reads; the operands of phase 1 were waited
+        // for in phase 3 and two barriers lie in between).  No LDS but the operand tables: the ring keeps running underneath. ---------------
         if (!grp) __builtin_amdgcn_s_barrier();
+        WRT(21);
         const bool reload = has_next && p.w_bstride != 0 && nxt.b != b;      // uniform
         if (reload) issue_w(nxt.b);
         const int t = opaque(threadIdx.x), lane = t & 63, lr = lane & 31, kh = lane >> 5;
         const float* Cc = (const float*)(smem + OFF_C);
-        constexpr int OP = 80;                                      // bytes per staged pixel slice (64 + 16: bank spread)
-        char* Os = smem + A_BYTES + wave * (RW * 32 * OP);
         const int oyb = ty0 + wave * RW, ox = tx0 + lr;              // lane's pixel of tile row i: (oyb + i, ox)
         const int rcs = p.res_cs ? p.res_cs : p.Cout;
         const ActK ak = act_consts(p.act, p.out_scale);
-        float ytap[3][4];                      // (a load into registers: used at the END of the epilogue)
-        if (TRGB && p.trgb_yprev) {
-            const int my = (oyb + kh) >> 1, mx = ox >> 1, h2 = p.Ho >> 1, w2 = p.Wo >> 1;
-            const float* yp = p.trgb_yprev + (long long)b * 3 * h2 * w2;
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    ytap[cc][q] = yp[(cc * h2 + max(my - 1 + (q >> 1), 0)) * w2 + max(mx - 1 + (q & 1), 0)];
-        }
+        // the wave's two output rows: scalar base (tile, wave) + lane constant
+        char* yrow = (char*)(p.y + (((long long)b * p.Ho + oyb) * p.Wo + tx0) * p.Cout);
+        const long long yrow_pitch = (long long)p.Wo * p.Cout * 2;
         float nzr[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) nzr[i] = p.noise_strength * *(const float*)(smem + OFF_N + (wave * 64 + i * 32 + lr) * 4);
@@ -313,6 +413,7 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
         const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            if (WR_ABL(1)) { if (acc[0][j][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
             h4 va[RW][4];
             h4 rq[4][RW];
             if (p.res) {
@@ -343,8 +444,7 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
                     h4 out;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) out[q] = (half_t)v[q];
-                    *(h4*)(Os + (i * 32 + lr) * OP + (8 * g + 4 * kh) * 2) = out;
-                    if (TRGB) va[i][g] = out;
+                    va[i][g] = out;
                 }
             }
             if (TRGB) {
@@ -358,36 +458,45 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();        // LDS is in-order per wave: only pin the compiler's order
+            // lane (px, kh) holds channels 8 g + 4 kh .. + 3 of every g: the pair (px, 0) / (px, 1) trades quads so that the lower lane owns the
+            // eight channels of g = 2 gp and the upper lane those of g = 2 gp + 1 — 16 contiguous bytes each, 32 per pixel and instruction
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {           // 2 rows x 32 px x four 16-byte pieces of this 32-channel slice
-                const int v = lane + 64 * k, i = v >> 7, pix = (v >> 2) & 31, piece = v & 3;
-                half_t* dst = p.y + (((long long)b * p.Ho + oyb + i) * p.Wo + tx0 + pix) * p.Cout + j * 32 + piece * 8;
-                *(h8*)dst = *(const h8*)(Os + (i * 32 + pix) * OP + piece * 16);
-            }
-            __builtin_amdgcn_wave_barrier();
+            for (int i = 0; i < RW; ++i)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    h4 lo = va[i][2 * gp], hi = va[i][2 * gp + 1];
+                    swap32(lo, hi);
+                    // after the swap: lower lanes lo = own quad of g0, hi = the partner's quad of g0; upper lanes lo = the partner's quad of g1, hi = own quad of g1
+                    const h8 ov = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    if (!WR_ABL(2) || ov[0] == (half_t)123.f) *(h8*)(yrow + i * yrow_pitch + (j * 32 + 16 * gp) * 2 + yoff) = ov;
+                }
         }
         if (TRGB) {
             const long long hw = (long long)p.Ho * p.Wo;
             float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
-                float r = p.trgb_b[cc] + (rgb[cc] + rgb[4 + cc] * (1.f / 2048.f));
-                if (p.trgb_yprev) r += trgb_skip(ytap[cc], oyb + kh, ox);
+                float r = tb[cc] + (rgb[cc] + rgb[4 + cc] * (1.f / 2048.f));
+                if (p.trgb_yprev) {
+                    float ytap[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ytap[q] = *(const float*)(smem + OFF_Y + wave * 512 + (cc * 34 + (q >> 1) * 17 + (lr >> 1) + (q & 1)) * 4);
+                    r += trgb_skip(ytap, oyb + kh, ox);
+                }
                 yo[cc * hw] = r;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the staged slices are read: patch buffer 1 may be refilled once every wave is past its epilogue
+        WRT(22);
         if (reload) {                          // the next candidate's weights: every wave's pieces landed before anybody reads them
-            WR_WAIT_VM0();
+            WR_WAIT_VM(0);
             __builtin_amdgcn_s_barrier();
         }
-        have_w = !reload;                      // (the fragments requested in phase 5 were the OLD candidate's)
+        have_w = !reload;                      // (the fragments requested in the last phase were the OLD candidate's)
         if (!has_next) break;
         ++id;
         cur = nxt;
     }
-    WR_WAIT_VM0();                             // the last tile's self-prefetch
+    WR_WAIT_VM(0);                             // the last tile's self-prefetch
 }
 
 // would a plain 3x3 layer of this geometry run here?  (the producers of its input ask before they write the chunk-planar layout)
@@ -407,7 +516,7 @@ const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
     if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16 || p.trgb_part) return nullptr;
     if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.xs_out && p.trgb_yout) return nullptr;
-    if (p.y_planar32) return nullptr;              // (reads the chunk-planar layout, writes pixel-major)
+    if (p.y_planar16) return nullptr;              // (reads the chunk-planar layout, writes pixel-major)
     if (p.trgb_yout && (!p.trgb_tab || !p.trgb_b)) return nullptr;
     const int tiles_x = p.Wc / TW, tiles_y = p.Hc / TH;
     const int n_cu = glass_cu_count();
@@ -423,8 +532,42 @@ const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
     // contiguous tile ranges: the tiles of a candidate split over whole workgroups where they can (per-sample weights load once per range)
     const int per_wg = (PT + n_cu - 1) / n_cu;
     const int grid = (PT + per_wg - 1) / per_wg;
-    if (p.trgb_yout) hipLaunchKernelGGL((conv_wres_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg);
-    else if (p.xs_out) hipLaunchKernelGGL((conv_wres_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg);
-    else hipLaunchKernelGGL((conv_wres_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg);
+#ifdef GLASS_AB_KNOBS
+    static const int abl = glass_knob("GLASS_WRES_ABLATE") ? atoi(glass_knob("GLASS_WRES_ABLATE")) : 0;
+    struct TraceDump {         // bit 64: print the stamps of this launch when the scope ends (synchronises)
+        unsigned long long* d = nullptr;
+        hipStream_t st;
+        const char* name;
+        ~TraceDump() {
+            if (!d) return;
+            unsigned long long hb[23 * 8];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hb, d, sizeof hb, hipMemcpyDeviceToHost);
+            (void)hipFree(d);
+            for (int w = 0; w < 8; w += 4) {
+                fprintf(stderr, "[wres %s w%d] per chunk: vm-wait reads barrierA mfma barrierB |", name, w);
+                for (int c = 0; c < 4; ++c) {
+                    fprintf(stderr, " %llu", hb[(1 + 5 * c) * 8 + w] - hb[(c ? 5 * c : 0) * 8 + w]);
+                    for (int ph = 2; ph <= 5; ++ph) fprintf(stderr, " %llu", hb[(ph + 5 * c) * 8 + w] - hb[(ph - 1 + 5 * c) * 8 + w]);
+                    fprintf(stderr, " |");
+                }
+                fprintf(stderr, " realign %llu epilogue %llu total %llu\n", hb[21 * 8 + w] - hb[20 * 8 + w], hb[22 * 8 + w] - hb[21 * 8 + w], hb[22 * 8 + w] - hb[w]);
+            }
+        }
+    } dump;
+    if (abl & 64) {
+        (void)hipMalloc(&dump.d, 23 * 8 * sizeof(unsigned long long));
+        (void)hipMemset(dump.d, 0, 23 * 8 * sizeof(unsigned long long));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wres_trace), &dump.d, sizeof dump.d);
+        dump.st = st;
+        dump.name = name;
+    }
+#define WR_ABL_PASS , abl
+#else
+#define WR_ABL_PASS
+#endif
+    if (p.trgb_yout) hipLaunchKernelGGL((conv_wres_kernel<true, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg WR_ABL_PASS);
+    else if (p.xs_out) hipLaunchKernelGGL((conv_wres_kernel<false, true>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg WR_ABL_PASS);
+    else hipLaunchKernelGGL((conv_wres_kernel<false, false>), dim3(grid), dim3(NTHR), LDS_BYTES, st, p, tiles_x, tiles_y, PT, per_wg WR_ABL_PASS);
     return name;
 }

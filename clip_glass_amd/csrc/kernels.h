@@ -31,7 +31,7 @@ bool conv_down_supported(int R, int Cin, int Cout);
 // conv3x3 stride 2 32 -> 64, + the 1x1 skip branch of FIR (pad 1)[::2] of the fromRGB map, merged; x and h never leave the CU.
 // nullptr when the block does not qualify (caller: conv_stream<fromrgb> + conv_down)
 const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* rgb_b, const half_t* w0, const float* b0, const half_t* w1,
-                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar32 = 0);
+                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar16 = 0);
 bool dblock0_supported(int R, int Cin, int Cout);
 // fused transposed-conv + FIR + epilogue (upfir.hip); nullptr when unsupported
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);

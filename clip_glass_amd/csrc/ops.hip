@@ -138,7 +138,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
             p.trgb_tab = tab;
         }
     }
-    p.x_planar32 = d->x_planar32;
+    p.x_planar16 = d->x_planar16;
     if (d->impl == 1) { if (!launch_conv_direct(p, 0)) { glass_set_error("direct conv: unsupported launch"); return GLASS_ERR_ARG; } }
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }

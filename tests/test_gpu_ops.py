@@ -350,7 +350,7 @@ def test_conv_wres_matches_tiled(B, H, W):
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     check("conv_wres vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
     np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, **kw))          # the ring is deterministic
-    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, planar_x=True, **kw))      # chunk-planar input (common.h x_planar32): same values
+    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, planar_x=True, **kw))      # chunk-planar input (common.h x_planar16): same values
     # blur-down of the input as a by-product of the staged patches
     xs = np.full((B, H // 2, W // 2, C), np.nan, dtype=np.float32)
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
