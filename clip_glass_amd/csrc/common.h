@@ -218,13 +218,13 @@ struct ConvParams {
     const half_t* skip_x;   // [B][Ho][Wo][Cin] (nullable)
     const half_t* skip_w;   // [Neff][Cin]
     int dry_run;            // conv_tiled / conv_glds launchers: report the kernel that would run, launch nothing
-    // chunk-planar activation maps [B][C / 16][H][W][16] (round 6): conv_wres stages the 16-channel chunks of its input at different times,
-    // and in the pixel-major layout the pieces of every 128-byte line crossed the fabric once per chunk (two 32-channel chunks: 4.6 GB
-    // fetched per launch for 2.15 GB of input, PMC).  With each chunk a plane of its own a line belongs to ONE chunk.  Only the producer /
-    // consumer pairs that implement the layout accept the flags (upfir2<false> / dblock0 write it, conv_wres reads it); every other launcher
-    // refuses them.
-    int x_planar16;         // the input map is chunk-planar
-    int y_planar16;         // the output map is written chunk-planar
+    // chunk-planar activation maps [B][C / 8][H][W][8] (round 6): conv_wreg stages the 16-channel chunks of its input at different times,
+    // and in the pixel-major layout the pieces of every 128-byte line crossed the fabric once per chunk (conv_wres's first form, two
+    // 32-channel chunks: 4.6 GB fetched per launch for 2.15 GB of input, PMC).  With 8-channel planes a line belongs to ONE chunk and a
+    // 64-lane LDS-DMA piece (16 B per lane) is 1 KB of contiguous memory.  Only the producer / consumer pairs that implement the layout
+    // accept the flags (upfir2<false> / dblock0 write it, conv_wreg reads it); every other launcher refuses them.
+    int x_planar8;         // the input map is chunk-planar
+    int y_planar8;         // the output map is written chunk-planar
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)
     int row_walk;           // conv_stream A/B knob: row-major walk of the persistent workgroups (round 2) instead of down the columns
     half_t* y;              // output [B][Ho][Wo][Cout] fp16 (or)

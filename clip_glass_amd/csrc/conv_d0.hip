@@ -82,9 +82,9 @@ struct D0Params {
     const half_t* w1;     // [9][64][32]
     const half_t* ws;     // [64][32]
     const float* b1;      // [64]
-    half_t* y;            // [B][R/2][R/2][64], or chunk-planar [B][4][R/2][R/2][16] (common.h x_planar16: the consumer is conv_wres)
+    half_t* y;            // [B][R/2][R/2][64], or chunk-planar [B][8][R/2][R/2][8] (common.h x_planar8: the consumer is conv_wreg)
     int B, R;
-    int y_planar16;
+    int y_planar8;
 #if defined(GLASS_AB_KNOBS) || defined(GLASS_DEV_TRACE)      // developer builds only (make AB=1 / TRACE=1): the release struct carries none of these
     unsigned long long* trace;   // GLASS_D0_TRACE: phase timestamps of workgroup 0
     int skew;             // GLASS_D0_SKEW: start delay (units of ~1000 clocks) of the second half of the grid
@@ -456,16 +456,16 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             }
             __builtin_amdgcn_wave_barrier();
             const int orow = 2 * k + r;
-            // this half's 32 channels of a row: pixel-major, or two planes of 16 channels
-            const int ypix = p.y_planar16 ? 16 : 64;
-            const long long yplane = p.y_planar16 ? (long long)Ro * Ro * 16 - 16 : 0;      // (vector chv: plane chv >> 1, half chv & 1)
-            half_t* yrow = p.y_planar16 ? p.y + ((((long long)b * 4 + nh * 2) * Ro + orow) * Ro + 30 * tx) * 16
-                                        : p.y + (((long long)b * Ro + orow) * Ro + 30 * tx) * 64 + nh * 32;
+            // this half's 32 channels of a row: pixel-major, or four planes of 8 channels (vector chv = plane chv)
+            const int ypix = p.y_planar8 ? 8 : 64;
+            const long long yplane = p.y_planar8 ? (long long)Ro * Ro * 8 - 8 : 0;
+            half_t* yrow = p.y_planar8 ? p.y + ((((long long)b * 8 + nh * 4) * Ro + orow) * Ro + 30 * tx) * 8
+                                       : p.y + (((long long)b * Ro + orow) * Ro + 30 * tx) * 64 + nh * 32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
                 const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
-                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && !D0_ABL(128)) *(h8*)(yrow + pix * ypix + chv * 8 + (chv >> 1) * yplane) = d;
+                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && !D0_ABL(128)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
             }
             __builtin_amdgcn_wave_barrier();
             D0TRACE(11);
@@ -500,11 +500,11 @@ bool dblock0_supported(int R, int Cin, int Cout) {
 
 // Returns the kernel symbol, or nullptr when the block does not qualify (caller runs the two-kernel form).
 const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* rgb_b, const half_t* w0, const float* b0, const half_t* w1,
-                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar16) {
+                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar8) {
     if (!dblock0_supported(R, Cin, Cout)) return nullptr;
     D0Params p;
     p.rgb_y = rgb_y; p.rgb_w = rgb_w; p.rgb_b = rgb_b; p.w0 = w0; p.b0 = b0; p.w1 = w1; p.ws = ws; p.b1 = b1; p.y = y; p.B = B; p.R = R;
-    p.y_planar16 = y_planar16;
+    p.y_planar8 = y_planar8;
 #if defined(GLASS_AB_KNOBS) || defined(GLASS_DEV_TRACE)
     p.trace = nullptr;
     static const int ablate = glass_knob("GLASS_D0_ABLATE") ? atoi(glass_knob("GLASS_D0_ABLATE")) : 0;

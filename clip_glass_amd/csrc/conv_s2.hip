@@ -378,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
 
 const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force) {
     static const bool off = glass_knob("GLASS_NO_S2DMA") != nullptr;      // A/B knob: the register-staged conv_tiled<3,2,4,128,skip> instead
-    if (p.x_planar16 || p.y_planar16) return nullptr;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8) return nullptr;   // chunk-planar maps (common.h): not implemented here
     if ((off && !force) || !p.skip_x || !p.skip_w || p.KS != 3 || p.stride != 2 || p.pad != 0 || p.up || p.y32 || !p.y) return nullptr;
     if (p.res || p.dscale || p.noise || p.shift || p.sn || p.pre_shift || p.in_up || p.xs_out || p.trgb_yout || p.post_scale16 || p.rgb_y) return nullptr;
     if (p.Neff != p.Cout || p.Neff % NT != 0 || p.Neff > MAX_N || p.Cin % 32 != 0 || p.Hc % TH != 0 || p.Wc % 32 != 0) return nullptr;

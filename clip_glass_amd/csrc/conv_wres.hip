@@ -25,7 +25,7 @@
 // Ping-pong: waves 4-7 run one barrier behind waves 0-3 (one wave of each group per SIMD):
 //     load interval: 12 ds_read_b128, counted vmcnt, lgkmcnt(0) | barrier | MFMA interval: 36 MFMAs at s_setprio 1, the next tap row's six
 //     weight fragments behind each tap row, the ring's three pieces behind the first four MFMAs | barrier
-// Input layout: pixel-major [B][H][W][64], or chunk-planar [B][4][H][W][16] (common.h x_planar16) written by upfir2<false> / dblock0 for
+// Input layout: pixel-major [B][H][W][64], or chunk-planar [B][4][H][W][16] (common.h x_planar8) written by upfir2<false> / dblock0 for
 // this kernel — pixel-major, the four 32-byte quarters of every 128-byte line cross the fabric at four different times.
 // toRGB (TRGB) and the blur-down by-product (XS) as in conv_glds.hip.  K order per accumulator: chunk, tap row, tap column.
 #include "common.h"
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(512, 1) void conv_wres_kernel(ConvParams p, int til
     // vector v of a patch chunk sits at byte v * 16: pixel v >> 1, physical half v & 1 holding the pixel's LOGICAL 8-channel half
     // (v & 1) ^ ((pixel >> 3) & 1) (swizzle on the source side — LDS-DMA writes lane-linear: any 16 consecutive pixels of a fragment read then
     // cover the 64 banks once).  Thread t carries vectors t, 512 + t and (lanes < 25) 1024 + 25 wave + lane.
-    const int pixs = p.x_planar16 ? 16 : p.Cin;                   // elements between pixels / between the 16-channel chunks of a pixel
-    const int c_step = p.x_planar16 ? p.H * p.W * 16 : 16;
+    const int pixs = p.Cin;                    // elements between pixels / between the 16-channel chunks of a pixel (pixel-major input only)
+    const int c_step = 16;
     int a_geo[3];             // lane constants: patch row | patch column << 8 | logical half << 16 | vector exists << 17
     {
         const int t = opaque(threadIdx.x), lane = t & 63;
@@ -516,7 +516,7 @@ const char* launch_conv_wres(const ConvParams& p, hipStream_t st) {
     if (p.sn || p.sn16 || p.pre_shift || p.in_up || p.rgb_y || p.rgb_tanh_out || p.skip_x || p.post_scale16 || p.trgb_part) return nullptr;
     if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.xs_out && p.trgb_yout) return nullptr;
-    if (p.y_planar16) return nullptr;              // (reads the chunk-planar layout, writes pixel-major)
+    if (p.x_planar8 || p.y_planar8) return nullptr;   // (pixel-major maps only: the chunk-planar layout is conv_wreg's)
     if (p.trgb_yout && (!p.trgb_tab || !p.trgb_b)) return nullptr;
     const int tiles_x = p.Wc / TW, tiles_y = p.Hc / TH;
     const int n_cu = glass_cu_count();

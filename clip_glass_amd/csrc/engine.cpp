@@ -998,7 +998,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             // upconv -> conv link: the up-conv's only consumer is the block's second conv, so (where the fused up-conv kernel
             // runs and that conv modulates on the activation side) its style is applied once, to the up-conv's output
             if (pre_styled) { p.sn = nullptr; p.sn16 = nullptr; pre_styled = false; }
-            if (x_planar) { p.x_planar16 = 1; x_planar = false; }     // (a launcher that does not read the layout refuses the layer: run_conv reports it)
+            if (x_planar) { p.x_planar8 = 1; x_planar = false; }     // (a launcher that does not read the layout refuses the layer: run_conv reports it)
             if (g.up && l == 0 && nl == 2 && !no_pre_style && !e->gconv[gi + 1].premod && !e->gconv[gi + 1].up) {
                 ConvParams dq = p;
                 dq.dry_run = 1;
@@ -1012,14 +1012,14 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
             }
             half_t* out = pp[(x == pp[0]) ? 1 : 0];
             p.y = out;
-            // upconv -> conv_wres link: that kernel reads its input one 32-channel chunk at a time, so the up-conv writes the map
-            // chunk-planar for it (common.h x_planar16) — where the up-conv instance that can runs and the conv has no activation-side style
+            // upconv -> conv_wreg link: that kernel reads its input one 32-channel chunk at a time, so the up-conv writes the map
+            // chunk-planar for it (common.h x_planar8) — where the up-conv instance that can runs and the conv has no activation-side style
             if (g.up && l == 0 && nl == 2 && !no_planar && !e->gconv[gi + 1].up && (pre_styled || e->gconv[gi + 1].premod) &&
-                conv_wres_supported(e->gconv[gi + 1].cin, e->gconv[gi + 1].cout, g.res_out, g.res_out)) {
+                conv_wreg_supported(e->gconv[gi + 1].cin, e->gconv[gi + 1].cout, g.res_out, g.res_out)) {
                 ConvParams dq = p;
                 dq.dry_run = 1;
-                dq.y_planar16 = 1;
-                if (launch_upconv_fused(dq, e->cur)) { p.y_planar16 = 1; x_planar = true; }
+                dq.y_planar8 = 1;
+                if (launch_upconv_fused(dq, e->cur)) { p.y_planar8 = 1; x_planar = true; }
             }
             const double flops = 2.0 * B * (double)g.res_in * g.res_in * 9.0 * g.cin * g.cout;  // reference count
             const double bytes = 2.0 * B * ((double)g.res_in * g.res_in * g.cin + (double)g.res_out * g.res_out * g.cout) +
@@ -1147,7 +1147,7 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
     char tag[64];
     half_t *Hb = bufs[0], *HB = bufs[1], *XS = bufs[2], *S = bufs[3], *O = bufs[4];
     static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wres's input stays pixel-major
-    bool x_planar = false;       // X is chunk-planar (common.h x_planar16): written so by the fused first block for conv_wres
+    bool x_planar = false;       // X is chunk-planar (common.h x_planar8): written so by the fused first block for conv_wres
     for (int i = i_lo; i < i_hi; ++i) {
         const DBlock& d = e->dblk[i];
         const int r = d.res, r2 = r / 2;
@@ -1156,15 +1156,15 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
         p.Hc = p.Wc = r; p.KS = 3; p.pad = 1; p.w = d.w0; p.Cout = p.Neff = d.cin; p.Ho = p.Wo = r;
         p.bias = d.b0; p.act = 1; p.y = Hb;
         const bool x_was_planar = x_planar;
-        if (x_planar) { p.x_planar16 = 1; x_planar = false; }
+        if (x_planar) { p.x_planar8 = 1; x_planar = false; }
         bool fused_rgb = false, have_xs = false;
         if (i == 0 && rgb_y) {       // the whole block from the skip image in one kernel (conv_d0.hip): neither x nor h reaches HBM
             snprintf(tag, sizeof tag, "D.block0.r%d.%dx%dx%d", r, d.cin, d.cin, d.cout);
             const double px = (double)B * r * r, px2 = (double)B * r2 * r2;
             Prof pr(e, tag, 2.0 * px * (9.0 * d.cin * d.cin + 3.0 * d.cin) + 2.0 * px2 * 10.0 * d.cin * d.cout, px * 12.0 + px2 * 2.0 * d.cout);
-            // the next block's first conv on conv_wres (with the blur-down by-product: nothing else reads this map): chunk-planar output
+            // the next block's first conv on conv_wreg (with the blur-down by-product: nothing else reads this map): chunk-planar output
             static const bool no_xs_fuse = glass_knob("GLASS_NO_XS_FUSE") != nullptr;
-            const bool planar = !no_planar && !no_xs_fuse && i + 1 < i_hi && e->dblk[i + 1].cin == d.cout && conv_wres_supported(d.cout, d.cout, r2, r2);
+            const bool planar = !no_planar && !no_xs_fuse && i + 1 < i_hi && e->dblk[i + 1].cin == d.cout && conv_wreg_supported(d.cout, d.cout, r2, r2);
             const char* k = launch_dblock0(rgb_y, e->d_frgb_w, e->d_frgb_b, d.w0, d.b0, d.w1, d.wskip, d.b1, O, B, r, d.cin, d.cout, e->cur, planar);
             if (k) {
                 x_planar = planar;

@@ -19,6 +19,9 @@ const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force = f
 // first by launch_conv_glds); nullptr: the layer does not qualify
 const char* launch_conv_wres(const ConvParams& p, hipStream_t st);
 bool conv_wres_supported(int Cin, int Cout, int H, int W);
+// the same layers with the weights in REGISTERS, one wave per SIMD (conv_wreg.hip; tried first); reads pixel-major or chunk-planar input
+const char* launch_conv_wreg(const ConvParams& p, hipStream_t st);
+bool conv_wreg_supported(int Cin, int Cout, int H, int W);
 // conv_s2.hip: the D blocks' stride-2 3x3 conv + fused 1x1 skip branch on an LDS-DMA ring (nullptr: not applicable -> conv_tiled)
 const char* launch_conv_s2(const ConvParams& p, hipStream_t st, bool force = false);
 // second half of the full-resolution discriminator block in one kernel (conv_down.hip):
@@ -31,7 +34,7 @@ bool conv_down_supported(int R, int Cin, int Cout);
 // conv3x3 stride 2 32 -> 64, + the 1x1 skip branch of FIR (pad 1)[::2] of the fromRGB map, merged; x and h never leave the CU.
 // nullptr when the block does not qualify (caller: conv_stream<fromrgb> + conv_down)
 const char* launch_dblock0(const float* rgb_y, const float* rgb_w, const float* rgb_b, const half_t* w0, const float* b0, const half_t* w1,
-                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar16 = 0);
+                           const half_t* ws, const float* b1, half_t* y, int B, int R, int Cin, int Cout, hipStream_t st, int y_planar8 = 0);
 bool dblock0_supported(int R, int Cin, int Cout);
 // fused transposed-conv + FIR + epilogue (upfir.hip); nullptr when unsupported
 const char* launch_upconv_fused(const ConvParams& p, hipStream_t st);

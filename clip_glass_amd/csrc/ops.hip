@@ -138,7 +138,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
             p.trgb_tab = tab;
         }
     }
-    p.x_planar16 = d->x_planar16;
+    p.x_planar8 = d->x_planar8;
     if (d->impl == 1) { if (!launch_conv_direct(p, 0)) { glass_set_error("direct conv: unsupported launch"); return GLASS_ERR_ARG; } }
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
@@ -163,7 +163,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
     if (rc) return rc;
     if (yrgb) {
         GLASS_HIP(hipMemcpy(d->trgb_yout, yrgb, nrgb * sizeof(float), hipMemcpyDeviceToHost));
-        return GLASS_OK;
+        return p.y ? down16(d->y, y, nout) : GLASS_OK;      // (the forms that also store the feature map hand it back too)
     }
     if (xs_dev && (rc = down16(d->xs_out, xs_dev, nxs))) return rc;
     return down16(d->y, y, nout);

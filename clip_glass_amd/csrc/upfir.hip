@@ -780,9 +780,9 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                     const int ltx = oxl + 1 + jx;
                     tr[jx] = (const char*)T + u_tpos(ltx) * 64 + ((cg ^ ((ltx >> 2) & 3)) * 16);
                 }
-                // pixel-major [B][Ho][Wo][Cout], or chunk-planar [B][Cout / 16][Ho][Wo][16] for conv_wres (common.h): this n tile is two chunks
-                const long long rowpitch = (long long)p.Wo * (p.y_planar16 ? 16 : p.Cout);
-                half_t* yp = p.y_planar16 ? p.y + ((((long long)img0 * 2 * g.NTn + (n0 >> 4) + (cg >> 1)) * p.Ho + ovy0) * p.Wo + ox) * 16 + (cg & 1) * 8
+                // pixel-major [B][Ho][Wo][Cout], or chunk-planar [B][Cout / 8][Ho][Wo][8] for conv_wreg (common.h): the lane's eight channels are a plane
+                const long long rowpitch = (long long)p.Wo * (p.y_planar8 ? 8 : p.Cout);
+                half_t* yp = p.y_planar8 ? p.y + ((((long long)img0 * 4 * g.NTn + (n0 >> 3) + cg) * p.Ho + ovy0) * p.Wo + ox) * 8
                                           : p.y + (((long long)img0 * p.Ho + ovy0) * p.Wo + ox) * p.Cout + n0 + cg * 8;   // (row ovy0 + r is only touched when it exists)
 #ifdef GLASS_AB_KNOBS
                 // (r05 experiment, developer build: the BS instance) buffer form: descriptor over this image's output map (uniform), 32-bit byte offset per lane
@@ -955,7 +955,7 @@ static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
     // per-sample weights carry style and demodulation: the lean single-image instance; anything else goes through the tables
     const bool lean = p.w_bstride && !p.sn16 && !p.dscale;
     (void)no_grid;
-    if (p.y_planar16 && !lean) return nullptr;    // the chunk-planar output (common.h) is the single-image instance's
+    if (p.y_planar8 && !lean) return nullptr;    // the chunk-planar output (common.h) is the single-image instance's
 #ifdef GLASS_AB_KNOBS
     // half-height steps (4 m rows, 51 KB of LDS, 156 VGPRs: THREE workgroups per CU) for the single-image instance — developer build only.
     // Measured (r05, same box, parity-green on the op tests and the goldens): r1024 1997 -> 2193 us, r512 1393 -> 1575 us: a third workgroup
@@ -970,13 +970,13 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     if (!p.up || !p.w_up || p.y32 || !p.y || p.res || (p.sn && !p.sn16)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.KS != 3) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;
-    if (p.x_planar16) return nullptr;              // chunk-planar input (common.h): not implemented here
+    if (p.x_planar8) return nullptr;              // chunk-planar input (common.h): not implemented here
     static const bool v1 = glass_knob("GLASS_UPFIR_V1") != nullptr;      // A/B knob: round 2's one-tile-per-workgroup kernel
     if (!v1) {
         const char* k = launch_upfir2(p, st);
         if (k) return k;
     }
-    if (p.y_planar16) return nullptr;
+    if (p.y_planar8) return nullptr;
     if (p.W < 16) return nullptr;
 
     if ((long long)p.H * p.W * p.Cin >= (1LL << 31)) return nullptr;

@@ -24,17 +24,17 @@ class ConvDesc(C.Structure):
                 ("trgb_smax", C.POINTER(C.c_float)), ("trgb_yprev", C.POINTER(C.c_float)),
                 ("trgb_yout", C.POINTER(C.c_float)),
                 ("skip_x", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float)), ("xs_out", C.POINTER(C.c_float)),
-                ("x_planar16", C.c_int32)]
+                ("x_planar8", C.c_int32)]
 
 
-def to_planar16(a):
-    """[B,H,W,C] -> the chunk-planar layout [B,C/16,H,W,16] conv_wres's producers write (csrc/common.h x_planar16)."""
+def to_planar8(a):
+    """[B,H,W,C] -> the chunk-planar layout [B,C/8,H,W,8] conv_wreg's producers write (csrc/common.h x_planar8)."""
     B, H, W, Cc = a.shape
-    return np.ascontiguousarray(a.reshape(B, H, W, Cc // 16, 16).transpose(0, 3, 1, 2, 4))
+    return np.ascontiguousarray(a.reshape(B, H, W, Cc // 8, 8).transpose(0, 3, 1, 2, 4))
 
 
-def from_planar16(a, B, H, W, Cc):
-    return np.ascontiguousarray(a.reshape(B, Cc // 16, H, W, 16).transpose(0, 2, 3, 1, 4)).reshape(B, H, W, Cc)
+def from_planar8(a, B, H, W, Cc):
+    return np.ascontiguousarray(a.reshape(B, Cc // 8, H, W, 8).transpose(0, 2, 3, 1, 4)).reshape(B, H, W, Cc)
 
 
 def _opt(a):
@@ -46,7 +46,7 @@ def _opt(a):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None, skip=None, xs_out=None, planar_x=False):
+         torgb=None, skip=None, xs_out=None, planar_x=False, both=False):
     """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout].
     torgb = dict(w [3,Cout], b [3], sn [B,Cout], smax [B], yprev [B,3,Ho/2,Wo/2] or None) with impl=4: the fused conv + toRGB
     form of the streaming kernel — returns the skip image [B,3,Ho,Wo] instead of y.
@@ -55,7 +55,7 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
     x = _f32(x); w = _f32(w)
     Bx, H, W, Cin = x.shape
     if planar_x:
-        x = to_planar16(x)
+        x = to_planar8(x)
     B = B if B is not None else Bx
     Cout, _, KS, _ = w.shape
     pad = (KS // 2) if pad is None else pad
@@ -69,7 +69,7 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
     d.KS, d.stride, d.pad, d.up, d.Ho, d.Wo = KS, stride, pad, int(up), Ho, Wo
     d.broadcast_x, d.act, d.batch_size, d.impl = int(broadcast_x), int(act), batch_size, impl
     d.noise_strength, d.out_scale = noise_strength, out_scale
-    d.x_planar16 = int(planar_x)
+    d.x_planar8 = int(planar_x)
     keep = []
     d.x, d.w, d.y = _fp(x), _fp(w), _fp(y)
     for name, val in (("sn", sn), ("dscale", dscale), ("noise", noise), ("bias", bias), ("res", res)):
@@ -95,6 +95,8 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
         d.trgb_yout = _fp(yrgb)
     lib.glass_op_conv.argtypes = [C.c_int32, C.POINTER(ConvDesc)]
     _check(lib, lib.glass_op_conv(device, C.byref(d)))
+    if both:                  # fused toRGB forms that store the feature map too (impl 2 / 5): (skip image, feature map)
+        return yrgb, y
     return yrgb if yrgb is not None else y
 
 
@@ -173,7 +175,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, impl=0, device=0):
     lib.glass_op_dblock0.argtypes = [C.c_int32] * 4 + [fp] * 9
     _check(lib, lib.glass_op_dblock0(device, B, R, impl, _fp(y), _fp(frgb_w), _fp(frgb_b), _fp(w0), _fp(b0), _fp(w1), _fp(wskip),
                                      _fp(b1), _fp(out)))
-    return from_planar16(out, B, R // 2, R // 2, 64) if impl == 2 else out
+    return from_planar8(out, B, R // 2, R // 2, 64) if impl == 2 else out
 
 
 def fromrgb(y, w, bias, device=0):

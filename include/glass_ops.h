@@ -31,7 +31,7 @@ typedef struct glass_conv_desc {
     const float* bias;     /* [Cout] or NULL */
     const float* res;      /* [B,Ho,Wo,Cout] or NULL */
     float* y;              /* [B,Ho,Wo,Cout] */
-    /* impl 2 / 4 / 5, all or none: toRGB fused into the conv epilogue — y is NOT returned, trgb_yout is */
+    /* impl 2 / 4 / 5, all or none: toRGB fused into the conv epilogue — trgb_yout is returned; y too by the forms that store the map (2 / 5) */
     const float* trgb_w;     /* [3,Cout] scaled */
     const float* trgb_b;     /* [3] */
     const float* trgb_sn;    /* [B,Cout] normalised toRGB style */
@@ -43,8 +43,8 @@ typedef struct glass_conv_desc {
     const float* skip_w;     /* [Cout,Cin,1,1] reference layout, un-scaled */
     /* impl 2, 3x3 stride 1, 64 -> 64: FIR 4x4 (pad 1) + ::2 of the INPUT map as a by-product of the staged patch */
     float* xs_out;           /* [B,H/2,W/2,Cin] or NULL */
-    /* impl 5, 64 -> 64: x is handed over chunk-planar, [B,Cin/16,H,W,16] (the layout conv_wres's producers write for it) */
-    int32_t x_planar16;
+    /* impl 5, 64 -> 64: x is handed over chunk-planar, [B,Cin/8,H,W,8] (the layout conv_wreg's producers write for it) */
+    int32_t x_planar8;
 } glass_conv_desc;
 
 int glass_op_conv(int32_t device, const glass_conv_desc* d);
@@ -66,7 +66,7 @@ int glass_op_dblock_down(int32_t device, int32_t B, int32_t R, int32_t Cin, int3
  * y [B,3,R,R] skip image -> denorm(norm(y)) -> fromRGB (3 -> 32) -> conv3x3 (32 -> 32) -> FIR pad 2 -> conv3x3 stride 2 (32 -> 64),
  * + conv1x1 of FIR pad 1 [::2] of the fromRGB map, merged / sqrt2.  frgb_w [32,3] scaled; w0 [32,32,3,3], w1 [64,32,3,3],
  * wskip [64,32,1,1] reference layouts, un-scaled; out [B,R/2,R/2,64].  impl 0: the fused kernel; 1: conv_stream<fromrgb> + conv_down;
- * 2: the fused kernel writing out chunk-planar, [B,4,R/2,R/2,16] */
+ * 2: the fused kernel writing out chunk-planar, [B,8,R/2,R/2,8] */
 int glass_op_dblock0(int32_t device, int32_t B, int32_t R, int32_t impl, const float* y, const float* frgb_w, const float* frgb_b,
                      const float* w0, const float* b0, const float* w1, const float* wskip, const float* b1, float* out);
 int glass_op_fromrgb(int32_t device, int32_t B, int32_t R, int32_t Cout, const float* y /*[B,3,R,R]*/,

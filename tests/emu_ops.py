@@ -559,7 +559,7 @@ def _d0_swz(row, chunk):
 def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
     """y [B,3,R,R] skip image; frgb_w [32,3] scaled; w0 [32,32,3,3], w1 [64,32,3,3], wskip [64,32,1,1] reference layouts.
     Returns [B,R/2,R/2,64] float32.  n_wg: number of emulated workgroups (contiguous step ranges -> priming mid-column).
-    impl 2: the kernel's chunk-planar output addresses ([B][4][R/2][R/2][16]), un-permuted at the end."""
+    impl 2: the kernel's chunk-planar output addresses ([B][8][R/2][R/2][8]), un-permuted at the end."""
     f16, f32 = np.float16, np.float32
     y = np.asarray(y, f32)
     B, _, R, _ = y.shape
@@ -705,7 +705,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
                 ox = 30 * tx + pix
                 for i in range(64):
                     if pix[i] < 30 and ox[i] < Ro and o_row < Ro:
-                        a = ((((b * 4 + nh * 2 + (chv[i] >> 1)) * Ro + o_row) * Ro + ox[i]) * 16 + (chv[i] & 1) * 8 if planar
+                        a = ((((b * 8 + nh * 4 + chv[i]) * Ro + o_row) * Ro + ox[i]) * 8 if planar
                              else ((b * Ro + o_row) * Ro + ox[i]) * 64 + nh * 32 + chv[i] * 8)
                         assert np.isnan(out[a]), "output written twice"
                         out[a:a + 8] = data[i]
@@ -723,5 +723,5 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
             run_item(b, tx, k, False)
     assert not np.isnan(out).any(), "some outputs were never written"
     if planar:
-        return np.ascontiguousarray(out.reshape(B, 4, Ro, Ro, 16).transpose(0, 2, 3, 1, 4)).reshape(B, Ro, Ro, 64)
+        return np.ascontiguousarray(out.reshape(B, 8, Ro, Ro, 8).transpose(0, 2, 3, 1, 4)).reshape(B, Ro, Ro, 64)
     return out.reshape(B, Ro, Ro, 64)

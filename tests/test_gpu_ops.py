@@ -332,9 +332,10 @@ def test_conv_glds_persistent_matches_tiled():
 
 @pytest.mark.parametrize("B,H,W", [(3, 128, 256), (1, 256, 128), (5, 128, 128), (2, 512, 512)])
 def test_conv_wres_matches_tiled(B, H, W):
-    """conv_wres.hip (64 -> 64 channels: weights resident in LDS, patches on an LDS-DMA double buffer, ping-pong K loop, contiguous tile
-    ranges per workgroup): the tiled kernel's numbers with the full epilogue, image borders through the zero page, ranges that cross
-    candidates and end unevenly; the blur-down by-product; the fused toRGB with and without the skip image."""
+    """conv_wreg.hip (64 -> 64 channels: the weights in registers, one wave per SIMD, a three-tile LDS-DMA ring of patches) and its
+    predecessor conv_wres.hip (weights resident in LDS, ping-pong K loop; takes the call with a residual input): the tiled kernel's numbers
+    with the full epilogue, image borders through the zero page, ranges that cross candidates and end unevenly; the blur-down by-product;
+    the fused toRGB with and without the skip image; the chunk-planar input layout."""
     rng = np.random.default_rng(41)
     C = 64
     x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
@@ -350,7 +351,15 @@ def test_conv_wres_matches_tiled(B, H, W):
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
     check("conv_wres vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
     np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, **kw))          # the ring is deterministic
-    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, planar_x=True, **kw))      # chunk-planar input (common.h x_planar16): same values
+    # without the residual input (neither engine layer has one) the call lands on conv_wreg.hip: weights in registers, one wave per SIMD
+    kw_nr = {k: v for k, v in kw.items() if k != "res"}
+    got_r = ops.conv(x, w, impl=5, **kw_nr)
+    ref_r = ops.conv(x, w, impl=2, **kw_nr)
+    diag("[wreg] B%d %dx%d max|wreg-tiled| %.3e" % (B, H, W, np.abs(got_r - ref_r).max()))
+    assert np.abs(got_r - ref_r).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_r).max()))
+    check("conv_wreg vs direct", got_r, ops.conv(x, w, impl=1, **kw_nr), 4e-3)
+    np.testing.assert_array_equal(got_r, ops.conv(x, w, impl=5, **kw_nr))
+    np.testing.assert_array_equal(got_r, ops.conv(x, w, impl=5, planar_x=True, **kw_nr))      # chunk-planar input (common.h x_planar8): same values
     # blur-down of the input as a by-product of the staged patches
     xs = np.full((B, H // 2, W // 2, C), np.nan, dtype=np.float32)
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
