@@ -75,6 +75,23 @@ def _canon_label(name):
     return base, args
 
 
+def kernel_family(name):
+    """`<layer tag>@<kernel symbol>` -> the kernel's SOURCE name (template arguments dropped): the dominant kernel of the `roofline` block is
+    the source kernel with the largest share of device time — `conv_gldsp_kernel<true,false,false>` / `<false,true,false>` are one kernel
+    with two epilogues (round 6: as separate symbols each was smaller than `dblock0_kernel` and the block would have named that one)."""
+    kern = name.split("@")[1] if "@" in name else name
+    return kern.split("<")[0]
+
+
+def match_family(base, table):
+    """Launch-weighted PMC row of ALL template instances of a source kernel in a {rocprofv3 symbol: row} table."""
+    rows = [row for sym, row in table.items() if _canon_symbol(sym)[0] == base]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None
+    return dict(bytes_per_launch=sum(r["bytes_per_launch"] * r["launches"] for r in rows) / n, launches=n)
+
+
 def match_kernel(name, table):
     """Row of a {rocprofv3 kernel symbol: row} table (tools/traffic_table.py) for an engine kernel label: same base name, and the
     label's template arguments a prefix of the symbol's (rocprofv3 also prints defaulted arguments).  Every label of the top-10
@@ -442,7 +459,7 @@ def main():
         ev.evaluate_local(population(1000 * rank + s, P), generation=s)
         warm = {}
         for r in eng.profile():
-            kern = r["name"].split("@")[1] if "@" in r["name"] else r["name"]
+            kern = kernel_family(r["name"])
             a = warm.setdefault(kern, 0.0)
             warm[kern] = a + r["total_ms"]
     full_prof = {r["name"]: dict(launches=r["launches"], total_ms=r["total_ms"], flops=r["flops"], bytes=r["bytes"])
@@ -493,10 +510,15 @@ def main():
     assert F_all.shape == (P * world, n_obj) and np.isfinite(F_all).all()
 
     if rank == 0:
-        # dominant kernel = the kernel symbol with the largest share of device time
+        # dominant kernel = the SOURCE kernel (all its template instances) with the largest share of device time
+        iso_fam = {}
+        for k3, v3 in iso.items():
+            a4 = iso_fam.setdefault(k3.split("<")[0], dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            for k4 in a4:
+                a4[k4] += v3[k4]
         by_kernel = {}
         for name, a in prof.items():
-            kern = name.split("@")[1] if "@" in name else name
+            kern = kernel_family(name)
             b = by_kernel.setdefault(kern, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
             for k in b:
                 b[k] += a[k]
@@ -520,7 +542,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", tname)
         traffic_rows = json.load(open(tpath)).get("per_kernel", {}) if os.path.exists(tpath) else {}
         if traffic_rows:
-            row = match_kernel(kern, traffic_rows)
+            row = match_family(kern, traffic_rows)
             if row:
                 traffic = row["bytes_per_launch"]
                 traffic_src = ("stored rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE, tools/measure_traffic.sh -> profiles/%s), "
@@ -536,11 +558,12 @@ def main():
                         algorithmic_bytes_per_launch=a["bytes"] / max(a["launches"], 1),
                         algorithmic_flop_per_launch=a["flops"] / max(a["launches"], 1),
                         share_of_gpu_time=warm.get(kern, 0.0) / warm_total if warm_total else None,
-                        isolated=(dict(avg_ms=iso[kern]["total_ms"] / max(iso[kern]["launches"], 1),
-                                       algorithmic_tflops=iso[kern]["flops"] / (iso[kern]["total_ms"] * 1e-3) / 1e12,
-                                       algorithmic_gbs=iso[kern]["bytes"] / (iso[kern]["total_ms"] * 1e-3) / 1e9,
+                        instances=sorted(k for k in iso if k.split("<")[0] == kern),
+                        isolated=(dict(avg_ms=iso_fam[kern]["total_ms"] / max(iso_fam[kern]["launches"], 1),
+                                       algorithmic_tflops=iso_fam[kern]["flops"] / (iso_fam[kern]["total_ms"] * 1e-3) / 1e12,
+                                       algorithmic_gbs=iso_fam[kern]["bytes"] / (iso_fam[kern]["total_ms"] * 1e-3) / 1e9,
                                        note="same kernel, one extra single-stream pass after the timed region")
-                                  if kern in iso and iso[kern]["total_ms"] > 0 else None),
+                                  if kern in iso_fam and iso_fam[kern]["total_ms"] > 0 else None),
                         concurrency={0: "single stream",
                                      1: "two HIP streams (GLASS_OVERLAP=1): durations include co-running kernels",
                                      2: "G and D on one stream; CLIP's image tower on a second stream next to D (G launches never "

@@ -219,7 +219,7 @@ struct ConvParams {
     const half_t* skip_w;   // [Neff][Cin]
     int dry_run;            // conv_tiled / conv_glds launchers: report the kernel that would run, launch nothing
     // chunk-planar activation maps [B][C / 8][H][W][8] (round 6): conv_wreg stages the 16-channel chunks of its input at different times,
-    // and in the pixel-major layout the pieces of every 128-byte line crossed the fabric once per chunk (conv_wres's first form, two
+    // and in the pixel-major layout the pieces of every 128-byte line crossed the fabric once per chunk (the first LDS-resident form of this layer, two
     // 32-channel chunks: 4.6 GB fetched per launch for 2.15 GB of input, PMC).  With 8-channel planes a line belongs to ONE chunk and a
     // 64-lane LDS-DMA piece (16 B per lane) is 1 KB of contiguous memory.  Only the producer / consumer pairs that implement the layout
     // accept the flags (upfir2<false> / dblock0 write it, conv_wreg reads it); every other launcher refuses them.

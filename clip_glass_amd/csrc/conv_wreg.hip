@@ -25,6 +25,7 @@
 #include "kernels.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 constexpr int NT = 64, NTHR = 256, TW = 32, TH = 8, RW = 2;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void swap32(h8& a, h8& b) {
 #define WG_WAIT_LGKM6(a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)::"memory")
 #define WG_WAIT_LGKM4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory")
 // developer builds only: timing experiments that switch parts of a tile off — 1 the whole epilogue, 2 its global
-// stores, 4 the K loop's MFMAs, 8 the patch fragment reads, 32 the ring's requests (WRONG RESULTS)
+// stores, 4 the K loop's MFMAs, 8 the patch fragment reads, 32 the ring's requests, 64 the epilogue's lane swaps, 128 its arithmetic (WRONG RESULTS)
 // (a RUN-TIME bit costs a branch per MFMA group and distorts what it measures: the bits are a COMPILE-time constant, -DWG_ABLATE_CT=<bits>,
 // one library per experiment — tools/build_wreg_ablations.sh)
 #define WG_ABL_ARG
@@ -133,16 +134,6 @@ __global__ __launch_bounds__(256, 1) void conv_wreg_kernel(ConvParams p, int til
     const int pixs = p.x_planar8 ? 8 : p.Cin;                     // elements between pixels
     const int halfs = p.x_planar8 ? p.H * p.W * 8 : 8;            // between the 8-channel halves of a chunk
     const int c_step = p.x_planar8 ? p.H * p.W * 16 : 16;         // between the 16-channel chunks
-    int a_geo[3];             // lane constants: patch row | patch column << 8 | half << 16 | vector exists << 17
-    {
-        const int t = opaque(threadIdx.x), lane = t & 63;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int v = k < 2 ? k * NTHR + t : 2 * NTHR + min(wave, 2) * 64 + lane;
-            const int pr = v / (2 * PW), w = v - pr * (2 * PW), hf = w / PW, pc = w - hf * PW;
-            a_geo[k] = opaque(pr | (pc << 8) | (hf << 16) | (v < NVA ? 1 << 17 : 0));
-        }
-    }
     const half_t* zp;
     const float* ones_page;
     {   // (the pages' addresses are taken ONCE: inside the tile loop they are GOT loads + lgkmcnt(0))
@@ -155,11 +146,17 @@ __global__ __launch_bounds__(256, 1) void conv_wreg_kernel(ConvParams p, int til
     int a_src[3];             // element offset into the image (< 2^31: launcher), or -1 = zero page
     auto aim_a = [&](const Item& w) {
         xb = p.x + (long long)w.b * p.x_bstride;
+        const int org = ((w.ty0 - 1) * p.W + w.tx0 - 1) * pixs;      // the patch's first pixel (uniform; negative at the top / left border)
+        // (the vectors' patch coordinates are re-derived per tile from an opaque thread id — ~50 instructions: as lane constants they were six
+        // registers this kernel does not have: hipcc spilled them and waited vmcnt(0) for the reload, i.e. for the whole ring, every tile)
+        const int t = opaque(threadIdx.x), lane = t & 63;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int iy = w.ty0 - 1 + (a_geo[k] & 255), ix = w.tx0 - 1 + ((a_geo[k] >> 8) & 255);
-            const bool ok = ((a_geo[k] >> 17) & 1) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            a_src[k] = ok ? (iy * p.W + ix) * pixs + ((a_geo[k] >> 16) & 1) * halfs : -1;
+            const int v = k < 2 ? k * NTHR + t : 2 * NTHR + min(wave, 2) * 64 + lane;
+            const int pr = v / (2 * PW), wv = v - pr * (2 * PW), hf = wv / PW, pc = wv - hf * PW;
+            const int iy = w.ty0 - 1 + pr, ix = w.tx0 - 1 + pc;
+            const bool ok = v < NVA && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            a_src[k] = ok ? org + (pr * p.W + pc) * pixs + hf * halfs : -1;
         }
     };
     auto issue_chunk = [&](int slot_off, int c) {      // the three pieces of chunk c of the aimed tile -> ring slot at byte slot_off
@@ -381,48 +378,65 @@ __global__ __launch_bounds__(256, 1) void conv_wreg_kernel(ConvParams p, int til
         const char* Trow = smem + OFF_T + es * T_BYTES + (((tn >> 3) & 1) * 3 + min(tn & 3, 2)) * (NT * 2) + kh * 16;
         const bool trow_ok = (tn & 3) < 3;
         const h8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
+        // PLAIN (both engine layers: pre-modulated weights / a plain D conv): no per-channel scale, no shift — one constant quad per channel
+        // group instead of three, a slice's four requested up front (a wave alone on its SIMD pays every LDS round trip it waits for in line)
+        auto epilogue = [&](auto plain_tag) {
+            constexpr bool PLAIN = decltype(plain_tag)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (WG_ABL(1)) { if (acc[0][j][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
-            h4 va[RW][4];
+            for (int j = 0; j < 2; ++j) {
+                if (WG_ABL(1)) { if (acc[0][j][0] == 12345.678f) p.y[0] = (half_t)1.f; continue; }
+                f4 bias4[4];
+                if (PLAIN) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = j * 32 + 8 * g + 4 * kh;
-                const f4 dq = *(const f4*)(Cc + nl);
-                const f4 bq = *(const f4*)(Cc + NT + nl) + *(const f4*)(Cc + 2 * NT + nl);      // bias + shift
-#pragma unroll
-                for (int i = 0; i < RW; ++i) {
-                    const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-                    f4 v = act_apply(a * dq + bq + nzr[i], ak);
-                    h4 out;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) out[q] = (half_t)v[q];
-                    va[i][g] = out;
+                    for (int g = 0; g < 4; ++g) bias4[g] = *(const f4*)(Cc + NT + j * 32 + 8 * g + 4 * kh);
                 }
-            }
-            if (TRGB) {
+                h4 va[RW][4];
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const h8 wt = *(const h8*)(Trow + ((j * 2 + gp) * 2) * 16);
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = j * 32 + 8 * g + 4 * kh;
+                    f4 dq = {1.f, 1.f, 1.f, 1.f}, bq;
+                    if (PLAIN) {
+                        bq = bias4[g];
+                    } else {
+                        dq = *(const f4*)(Cc + nl);
+                        bq = *(const f4*)(Cc + NT + nl) + *(const f4*)(Cc + 2 * NT + nl);      // bias + shift
+                    }
 #pragma unroll
                     for (int i = 0; i < RW; ++i) {
-                        const h8 wi = (trow_ok && ((tn >> 2) & 1) == i) ? wt : hzero;
-                        rgb = mfma32(wi, __builtin_shufflevector(va[i][2 * gp], va[i][2 * gp + 1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
+                        const f4 a = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+                        f4 v = WG_ABL(128) ? a : act_apply(PLAIN ? a + bq + nzr[i] : a * dq + bq + nzr[i], ak);      // (a * 1 + b == a + b: the same bits)
+                        h4 out;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) out[q] = (half_t)v[q];
+                        va[i][g] = out;
                     }
                 }
-            }
-            // lane (px, kh) holds channels 8 g + 4 kh .. + 3 of every g: the pair (px, 0) / (px, 1) trades quads so that the lower lane owns the
-            // eight channels of g = 2 gp and the upper lane those of g = 2 gp + 1 — 16 contiguous bytes each, 32 per pixel and instruction
+                if (TRGB) {
 #pragma unroll
-            for (int i = 0; i < RW; ++i)
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const h8 wt = *(const h8*)(Trow + ((j * 2 + gp) * 2) * 16);
 #pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    h4 lo = va[i][2 * gp], hi = va[i][2 * gp + 1];
-                    swap32(lo, hi);
-                    const h8 ov = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (!WG_ABL(2) || ov[0] == (half_t)123.f) *(h8*)(yrow + i * yrow_pitch + (j * 32 + 16 * gp) * 2 + yoff) = ov;
+                        for (int i = 0; i < RW; ++i) {
+                            const h8 wi = (trow_ok && ((tn >> 2) & 1) == i) ? wt : hzero;
+                            rgb = mfma32(wi, __builtin_shufflevector(va[i][2 * gp], va[i][2 * gp + 1], 0, 1, 2, 3, 4, 5, 6, 7), rgb);
+                        }
+                    }
                 }
-        }
+                // lane (px, kh) holds channels 8 g + 4 kh .. + 3 of every g: the pair (px, 0) / (px, 1) trades quads so that the lower lane owns the
+                // eight channels of g = 2 gp and the upper lane those of g = 2 gp + 1 — 16 contiguous bytes each, 32 per pixel and instruction
+#pragma unroll
+                for (int i = 0; i < RW; ++i)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        h4 lo = va[i][2 * gp], hi = va[i][2 * gp + 1];
+                        if (!WG_ABL(64)) swap32(lo, hi);
+                        const h8 ov = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        if (!WG_ABL(2) || ov[0] == (half_t)123.f) *(h8*)(yrow + i * yrow_pitch + (j * 32 + 16 * gp) * 2 + yoff) = ov;
+                    }
+            }
+        };
+        if (!p.dscale && !p.shift) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         if (TRGB) {
             const long long hw = (long long)p.Ho * p.Wo;
             float* yo = p.trgb_yout + (long long)b * 3 * hw + (long long)(oyb + kh) * p.Wo + ox;

@@ -942,7 +942,7 @@ static void run_g_blocks(glass_engine* e, int c0, int B, int b_lo, int b_hi, con
     static const bool no_trgb_fuse = glass_knob("GLASS_NO_TRGB_FUSE") != nullptr;   // experiment knobs
     static const bool no_trgb_mid = glass_knob("GLASS_NO_TRGB_MID") != nullptr;
     static const bool no_pre_style = glass_knob("GLASS_NO_PRE_STYLE") != nullptr;
-    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wres's input stays pixel-major
+    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wreg's input stays pixel-major
     // A block's SEPARATE toRGB pass (blocks wider than 128 channels) is a bandwidth-bound read of the map the next block's
     // up-conv reads too; in the two-stream mode it runs on the second stream next to that (issue-bound) up-conv.  The main
     // stream joins before the next block's last conv: that launch overwrites the map toRGB reads and consumes its skip image.
@@ -1146,8 +1146,8 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
                             const float* rgb_y = nullptr) {
     char tag[64];
     half_t *Hb = bufs[0], *HB = bufs[1], *XS = bufs[2], *S = bufs[3], *O = bufs[4];
-    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wres's input stays pixel-major
-    bool x_planar = false;       // X is chunk-planar (common.h x_planar8): written so by the fused first block for conv_wres
+    static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob: conv_wreg's input stays pixel-major
+    bool x_planar = false;       // X is chunk-planar (common.h x_planar8): written so by the fused first block for conv_wreg
     for (int i = i_lo; i < i_hi; ++i) {
         const DBlock& d = e->dblk[i];
         const int r = d.res, r2 = r / 2;

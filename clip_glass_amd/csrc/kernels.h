@@ -15,11 +15,8 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
 bool conv_stream_applies(const ConvParams& p);   // trgb_yout set: the fused conv + toRGB form
 // LDS-DMA staged 3x3 conv for the MFMA-bound mid-resolution layers (conv_glds.hip); nullptr when unsupported / disabled
 const char* launch_conv_glds(const ConvParams& p, hipStream_t st, bool force = false);
-// conv_wres.hip: 3x3 stride-1 conv 64 -> 64 channels with the weights resident in LDS and the patches on an LDS-DMA double buffer (tried
-// first by launch_conv_glds); nullptr: the layer does not qualify
-const char* launch_conv_wres(const ConvParams& p, hipStream_t st);
-bool conv_wres_supported(int Cin, int Cout, int H, int W);
-// the same layers with the weights in REGISTERS, one wave per SIMD (conv_wreg.hip; tried first); reads pixel-major or chunk-planar input
+// conv_wreg.hip: 3x3 stride-1 conv 64 -> 64 channels with the WHOLE weight tensor in registers, one wave per SIMD, the patches on a three-tile
+// LDS-DMA ring (tried first by launch_conv_glds); reads pixel-major or chunk-planar input; nullptr: the layer does not qualify
 const char* launch_conv_wreg(const ConvParams& p, hipStream_t st);
 bool conv_wreg_supported(int Cin, int Cout, int H, int W);
 // conv_s2.hip: the D blocks' stride-2 3x3 conv + fused 1x1 skip branch on an LDS-DMA ring (nullptr: not applicable -> conv_tiled)

@@ -306,9 +306,6 @@ def test_conv_glds_persistent_matches_tiled():
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
     y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
     np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, **kw2))
-    xs_p = np.full_like(xs, np.nan)
-    np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, xs_out=xs_p, planar_x=True, **kw2))
-    np.testing.assert_array_equal(xs, xs_p)
     f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
     xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
     check("persistent conv_glds blur-down by-product", xs,
@@ -331,11 +328,10 @@ def test_conv_glds_persistent_matches_tiled():
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 128, 256), (1, 256, 128), (5, 128, 128), (2, 512, 512)])
-def test_conv_wres_matches_tiled(B, H, W):
-    """conv_wreg.hip (64 -> 64 channels: the weights in registers, one wave per SIMD, a three-tile LDS-DMA ring of patches) and its
-    predecessor conv_wres.hip (weights resident in LDS, ping-pong K loop; takes the call with a residual input): the tiled kernel's numbers
-    with the full epilogue, image borders through the zero page, ranges that cross candidates and end unevenly; the blur-down by-product;
-    the fused toRGB with and without the skip image; the chunk-planar input layout."""
+def test_conv_wreg_matches_tiled(B, H, W):
+    """conv_wreg.hip (64 -> 64 channels: the weights in registers, one wave per SIMD, a three-tile LDS-DMA ring of patches): the tiled
+    kernel's numbers with the full epilogue, image borders through the zero page, ranges that cross candidates and end unevenly; the
+    blur-down by-product; the fused toRGB with and without the skip image; the chunk-planar input layout."""
     rng = np.random.default_rng(41)
     C = 64
     x = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
@@ -344,30 +340,29 @@ def test_conv_wres_matches_tiled(B, H, W):
     noise = rng.standard_normal((B, H, W)).astype(np.float32)
     bias = rng.standard_normal(C).astype(np.float32) * 0.2
     res = rng.standard_normal((B, H, W, C)).astype(np.float16).astype(np.float32)
-    kw = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, res=res, out_scale=0.7)
+    kw = dict(dscale=ds, noise=noise, noise_strength=0.3, batch_size=1, bias=bias, act=True, out_scale=0.7)
     got = ops.conv(x, w, impl=5, **kw)
     ref_t = ops.conv(x, w, impl=2, **kw)
-    diag("[wres] B%d %dx%d max|wres-tiled| %.3e" % (B, H, W, np.abs(got - ref_t).max()))
+    diag("[wreg] B%d %dx%d max|wreg-tiled| %.3e" % (B, H, W, np.abs(got - ref_t).max()))
     assert np.abs(got - ref_t).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_t).max()))
-    check("conv_wres vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
+    check("conv_wreg vs direct", got, ops.conv(x, w, impl=1, **kw), 4e-3)
     np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, **kw))          # the ring is deterministic
-    # without the residual input (neither engine layer has one) the call lands on conv_wreg.hip: weights in registers, one wave per SIMD
-    kw_nr = {k: v for k, v in kw.items() if k != "res"}
-    got_r = ops.conv(x, w, impl=5, **kw_nr)
-    ref_r = ops.conv(x, w, impl=2, **kw_nr)
-    diag("[wreg] B%d %dx%d max|wreg-tiled| %.3e" % (B, H, W, np.abs(got_r - ref_r).max()))
-    assert np.abs(got_r - ref_r).max() <= 2.0 ** -8 * max(1.0, float(np.abs(ref_r).max()))
-    check("conv_wreg vs direct", got_r, ops.conv(x, w, impl=1, **kw_nr), 4e-3)
-    np.testing.assert_array_equal(got_r, ops.conv(x, w, impl=5, **kw_nr))
-    np.testing.assert_array_equal(got_r, ops.conv(x, w, impl=5, planar_x=True, **kw_nr))      # chunk-planar input (common.h x_planar8): same values
+    np.testing.assert_array_equal(got, ops.conv(x, w, impl=5, planar_x=True, **kw))      # chunk-planar input (common.h x_planar8): same values
+    kwp = dict(bias=bias, act=True)                                          # the engine's form: no per-channel scale, no shift (the PLAIN epilogue)
+    check("conv_wreg plain epilogue", ops.conv(x, w, impl=5, **kwp), ops.conv(x, w, impl=1, **kwp), 4e-3)
+    with pytest.raises(Exception):                                            # a residual input is nobody's on this path: refused, not ignored
+        ops.conv(x, w, impl=5, res=res, **kw)
     # blur-down of the input as a by-product of the staged patches
     xs = np.full((B, H // 2, W // 2, C), np.nan, dtype=np.float32)
     kw2 = dict(bias=bias, act=True, out_scale=0.7)
     y2 = ops.conv(x, w, impl=5, xs_out=xs, **kw2)
     np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, **kw2))
+    xs_p = np.full_like(xs, np.nan)
+    np.testing.assert_array_equal(y2, ops.conv(x, w, impl=5, xs_out=xs_p, planar_x=True, **kw2))
+    np.testing.assert_array_equal(xs, xs_p)
     f = np.array([1, 3, 3, 1], dtype=np.float64) / 8
     xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
-    check("conv_wres blur-down by-product", xs, sum(f[a] * f[b2] * xp[:, a:a + H:2, b2:b2 + W:2] for a in range(4) for b2 in range(4)), 2e-3)
+    check("conv_wreg blur-down by-product", xs, sum(f[a] * f[b2] * xp[:, a:a + H:2, b2:b2 + W:2] for a in range(4) for b2 in range(4)), 2e-3)
     xs_t = np.full_like(xs, np.nan)
     ops.conv(x, w, impl=2, xs_out=xs_t, **kw2)
     np.testing.assert_array_equal(xs, xs_t)                                   # the same packed-fp16 FIR as conv_tiled<xs>
@@ -380,7 +375,7 @@ def test_conv_wres_matches_tiled(B, H, W):
     feat = ops.conv(x, w, impl=5, **kw3)
     for yprev in (rng.standard_normal((B, 3, H // 2, W // 2)).astype(np.float32), None):
         got_rgb = ops.conv(x, w, impl=5, torgb=dict(w=wrgb, b=brgb, sn=srgb, smax=smax, yprev=yprev), **kw3)
-        check("conv_wres fused toRGB", got_rgb, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
+        check("conv_wreg fused toRGB", got_rgb, _torgb_ref(feat, wrgb, brgb, srgb, smax, yprev), 2e-5)
 
 
 @pytest.mark.parametrize("impl", [1, 2])
@@ -488,7 +483,7 @@ def test_dblock0_fused(B, R):
     args, ref = _dblock0_case(B, R)
     got = ops.dblock0(*args)
     check("D block0 fused B%d R%d" % (B, R), nchw(got), ref, 6e-3)
-    np.testing.assert_array_equal(got, ops.dblock0(*args, impl=2))     # the chunk-planar output (for conv_wres): same values, other addresses
+    np.testing.assert_array_equal(got, ops.dblock0(*args, impl=2))     # the chunk-planar output (for conv_wreg): same values, other addresses
     for name, sl in (("top", np.s_[:, :, :2, :]), ("bottom", np.s_[:, :, -2:, :]), ("left", np.s_[:, :, :, :2]), ("right", np.s_[:, :, :, -2:])):
         check("D block0 fused border " + name, nchw(got)[sl], ref[sl], 8e-3)
     if R >= 192 and R % 64 == 0 and ops is not None and hasattr(ops, "load_library"):

@@ -478,7 +478,7 @@ def test_bench_kernel_labels_resolve_to_pmc_rows():
     assert bench._canon_label("conv_tiled_kernel<3,1,8,64,xs,deep>")[1] == "3,1,8,64,false,false,false,true,false,false,true,false".split(",")
     assert bench._canon_label("conv_stream_kernel<torgb>")[1] == ["false", "true", "false"]
     labels = ["conv_gldsp_kernel<false,true,false>", "dblock0_kernel", "upfir2_kernel<false>", "upfir2_kernel<true>", "conv_s2_kernel",
-              "conv_wres_kernel<true,false>", "conv_wres_kernel<false,true>", "conv_stream_kernel<torgb>",
+              "conv_wreg_kernel<true,false>", "conv_wreg_kernel<false,true>", "conv_stream_kernel<torgb>",
               "conv_gldsp_kernel<true,false,false>", "trgb_finish_kernel", "gemm_tiled_kernel<64>", "gemm_tiled_kernel<128>",
               "D.blur.r512", "D.blur.r64", "G.torgb.r16", "G.torgb.r8", "clip.layernorm", "clip.attention", "noise", "mapping",
               "conv_glds_kernel<16>"]
@@ -486,6 +486,10 @@ def test_bench_kernel_labels_resolve_to_pmc_rows():
         row = bench.match_kernel(name, table)
         assert row is not None and row["bytes_per_launch"] > 0, name
     assert bench.match_kernel("D.blur.r512", table) is not bench.match_kernel("D.blurdown.r16", table)
+    # the `roofline` block's dominant kernel is a SOURCE kernel: its template instances together (round 6)
+    assert bench.kernel_family("G.conv.r64.512x512@conv_gldsp_kernel<true,false,false>") == "conv_gldsp_kernel"
+    fam = bench.match_family("conv_gldsp_kernel", table)
+    assert fam and fam["launches"] >= 2 and fam["bytes_per_launch"] > 0
     fam = bench.family_table({"upfir2_kernel<false>": dict(launches=2, total_ms=3.4, flops=1.2e12, bytes=9.6e9),
                               "D.blur.r512": dict(launches=1, total_ms=0.8, flops=0.0, bytes=4.3e9)}, 31.0, table)
     assert [r["kernel"] for r in fam["rows"]] == ["upfir2_kernel<false>", "D.blur.r512"] and all(r["traffic_ratio"] for r in fam["rows"])
