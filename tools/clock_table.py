@@ -14,6 +14,7 @@ for r in csv.DictReader(open(cc[0])):
     k = re.sub(r"\(.*", "", name).replace("void ", "")[:70]
     a = acc[k]
     a[0] += float(r["Counter_Value"]); a[1] += ns; a[2] += 1
-print("# effective shader clock per kernel = GRBM_GUI_ACTIVE / duration (sum over the dispatches of one bench pass + warm-up; PMC run: kernels serialised)")
+XCDS = 8    # rocprofv3 reports GRBM_GUI_ACTIVE summed over the eight XCDs (each counts its own busy cycles)
+print("# effective shader clock per kernel = GRBM_GUI_ACTIVE / 8 XCDs / duration (sum over the dispatches of one bench pass + warm-up; PMC run: kernels serialised; dispatches of a few microseconds over-count: the counter also runs between them)")
 for k, (cyc, ns, n) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
-    print("%-72s n=%4d  %9.1f us  %.3f GHz" % (k, n, ns / 1e3, cyc / ns if ns else 0))
+    print("%-72s n=%4d  %9.1f us  %.3f GHz" % (k, n, ns / 1e3, cyc / XCDS / ns if ns else 0))
