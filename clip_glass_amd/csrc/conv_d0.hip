@@ -93,7 +93,9 @@ struct D0Params {
                           // 128 output stores.  WRONG RESULTS.
 #endif
 };
-#ifdef GLASS_AB_KNOBS
+#if defined(D0_ABLATE_CT)       // compile-time bits (tools/build_ablations.sh): a run-time bit costs branches and lets nothing be deleted (DESIGN "Round 6")
+#define D0_ABL(bit) (((D0_ABLATE_CT) & (bit)) != 0)
+#elif defined(GLASS_AB_KNOBS)
 #define D0_ABL(bit) (p.ablate & (bit))
 #else
 #define D0_ABL(bit) false
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
                 const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
-                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && !D0_ABL(128)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
+                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && (!D0_ABL(128) || d[0] == (half_t)777.f)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
             }
             __builtin_amdgcn_wave_barrier();
             D0TRACE(11);

@@ -97,7 +97,7 @@ __device__ __forceinline__ void swap32(h8& a, h8& b) {
 // developer builds only: timing experiments that switch parts of a tile off — 1 the whole epilogue, 2 its global
 // stores, 4 the K loop's MFMAs, 8 the patch fragment reads, 32 the ring's requests, 64 the epilogue's lane swaps, 128 its arithmetic (WRONG RESULTS)
 // (a RUN-TIME bit costs a branch per MFMA group and distorts what it measures: the bits are a COMPILE-time constant, -DWG_ABLATE_CT=<bits>,
-// one library per experiment — tools/build_wreg_ablations.sh)
+// one library per experiment — tools/build_ablations.sh)
 #define WG_ABL_ARG
 #ifdef WG_ABLATE_CT
 #define WG_ABL(bit) (((WG_ABLATE_CT) & (bit)) != 0)

@@ -294,7 +294,9 @@ struct UpGeo {
                                // behind the FIR (correct results: the r04 order, addresses derived and loads issued after the step barrier).
 #endif
 };
-#ifdef GLASS_AB_KNOBS
+#if defined(U_ABLATE_CT)        // compile-time bits (tools/build_ablations.sh): a run-time bit costs branches and lets nothing be deleted (DESIGN "Round 6")
+#define U_ABL(bit) (!GRID && (((U_ABLATE_CT) & (bit)) != 0))
+#elif defined(GLASS_AB_KNOBS)
 #define U_ABL(bit) (!GRID && (g.ablate & (bit)))
 #else
 #define U_ABL(bit) false
@@ -821,7 +823,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                         yoff += (unsigned)rowpitch * 2u;
                     } else
 #endif
-                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && !U_ABL(4)) *(h8*)yp = v;
+                    if ((step > 0 || r >= 4) && ovy0 + r < p.Ho && (!U_ABL(4) || v[0] == (half_t)777.f)) *(h8*)yp = v;
                     yp += rowpitch;
                     __builtin_amdgcn_sched_barrier(0);
                     if (r + 1 < TR) {
