@@ -27,7 +27,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int lr = lane & 31, kh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * BN;
+    // XCD-aware tile walk (round 6).  Workgroup i of a launch runs on XCD i % 8, each XCD has its own 4 MB L2: with the (m, n) tiles dealt
+    // x-fastest every XCD saw every panel of both operands (CLIP's linears, M = 3200: 25 x 18 tiles of 2 x 196 KB panels each — PMC traffic
+    // 6.1 x the algorithmic bytes, the kernel bound by the fabric).  Now XCD x owns a CONTIGUOUS slice of the m-major tile list: ~3 of the 25
+    // activation panels (kept) and one pass over the weights.  Same tiles, same arithmetic: bit-identical outputs.
+    const int gy = p.N / BN, n_tiles = ((p.M + 127) >> 7) * gy;
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int tile = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, n_tiles)) return;      // (padding of the last slices; uniform)
+    const int m0 = (tile / gy) * 128, n0 = (tile % gy) * BN;
     const int part = t & 7;                      // which 16-byte piece of the 128-byte row chunk
 
     h8 ra[NA], rb[NB];
@@ -151,11 +159,11 @@ const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     const long long gz_n = p.cand_batch ? GLASS_NOMINAL_POP : gz;
     const bool fills = gx_n * (p.N / 128) * gz_n >= 256;
     if (p.N % 128 == 0 && (fills || wide_only)) {
-        hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(gx, p.N / 128, gz), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(8 * ((gx * (p.N / 128) + 7) / 8), 1, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<128>";
     }
     if (p.N % 64 == 0) {
-        hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(gx, p.N / 64, gz), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(8 * ((gx * (p.N / 64) + 7) / 8), 1, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<64>";
     }
     return nullptr;
