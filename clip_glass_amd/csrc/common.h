@@ -223,6 +223,9 @@ struct ConvParams {
     // 32-channel chunks: 4.6 GB fetched per launch for 2.15 GB of input, PMC).  With 8-channel planes a line belongs to ONE chunk and a
     // 64-lane LDS-DMA piece (16 B per lane) is 1 KB of contiguous memory.  Only the producer / consumer pairs that implement the layout
     // accept the flags (upfir2<false> / dblock0 write it, conv_wreg reads it); every other launcher refuses them.
+    int x_planar32;        // conv_s2 only (round 6): its blurred input map is [B][Cin / 32][H][W][32] — written so by blur_kernel for it.  The kernel
+                            // stages ONE 32-channel chunk of a patch per K step; pixel-major, the 64-byte pieces of a 128-byte line belong to two K
+                            // steps and every line crossed the fabric twice (PMC traffic 1.59 x the algorithmic bytes: the r256 layer ran at 5.6 TB/s)
     int x_planar8;         // the input map is chunk-planar
     int y_planar8;         // the output map is written chunk-planar
     int no_tstore;          // experiment knob: 1 = scattered 8-byte stores (no LDS-transposed epilogue)

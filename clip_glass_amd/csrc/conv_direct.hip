@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvParams p) {
 }
 
 const char* launch_conv_direct(const ConvParams& p, hipStream_t st) {
-    if (p.x_planar8 || p.y_planar8) return nullptr;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8 || p.x_planar32) return nullptr;   // chunk-planar maps (common.h): not implemented here
     if (p.w_bstride != 0) return nullptr;  // per-sample weights are a tiled / up-conv-only path: refuse, the caller reports it
     const long long M = (long long)p.B * p.Hc * p.Wc;
     // instance choice at the NOMINAL population (common.h): the row-parallel and the split-K forms sum in different orders

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_finish_kernel(ConvParams p, const fl
 // cap_a / cap_c: scratch capacity PER CANDIDATE (halfs of A, floats of C); the buffers hold p.B candidates
 const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a, float* ws_c, long long cap_c, hipStream_t st) {
     static const bool off = glass_knob("GLASS_NO_CONV_GEMM") != nullptr;   // A/B knob: these layers stay on conv_direct
-    if (p.x_planar8 || p.y_planar8) return nullptr;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8 || p.x_planar32) return nullptr;   // chunk-planar maps (common.h): not implemented here
     if (off || !ws_a || !ws_c || p.y32 || !p.y || p.w_bstride != 0 || p.rgb_y || p.trgb_yout || p.skip_x) return nullptr;
     if (p.pre_shift && !p.sn) return nullptr;
     if (p.xs_out || p.post_scale16) return nullptr;   // by-products / output transforms this path does not implement: refuse, never ignore

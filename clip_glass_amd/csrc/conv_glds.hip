@@ -756,7 +756,7 @@ static const char* launch_glds_inst(const ConvParams& p, hipStream_t st, const c
 const char* launch_conv_glds(const ConvParams& p0, hipStream_t st, bool force) {
     ConvParams p = p0;
     if (const char* k = launch_conv_wreg(p, st)) return k;     // 64 -> 64 channels: the weights-in-registers form (conv_wreg.hip)
-    if (p.x_planar8 || p.y_planar8) return nullptr;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8 || p.x_planar32) return nullptr;   // chunk-planar maps (common.h): not implemented here
     static const bool on = glass_knob("GLASS_NO_GLDS") == nullptr;   // A/B knob: GLASS_NO_GLDS=1 falls back to conv_tiled
     if (!glass_lds_fits(Geo<32>::LDS_BYTES) || !glass_lds_fits(Geo<16>::LDS_BYTES)) return nullptr;
     if ((!on && !force) || p.up || (p.xs_out && (p.sn || p.trgb_yout || p.Wc % 32 != 0)) || p.y32 || !p.y || p.KS != 3 || p.stride != 1 || p.pad != 1) return nullptr;

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
     // ---- per-thread DMA source offsets (elements), tile- and chunk-independent: every tile is interior -----------------------------
     // a half's vector v sits at LDS byte v * 16: pixel P = v >> 2 (row P / 65, de-interleaved column q = P % 65), physical chunk v & 3
     // holding the pixel's LOGICAL 8-channel chunk (v & 3) ^ ((P >> 2) & 3).  Wave-round r = k * 8 + wave covers vectors r * 64 + lane.
+    // input layout: pixel-major [H][W][Cin], or 32-channel planes [Cin / 32][H][W][32] (common.h x_planar32: a line then belongs to ONE K step)
+    const int pixs = p.x_planar32 ? 32 : p.Cin;
+    const long long c_step = p.x_planar32 ? (long long)p.H * p.W * 32 : 32;
     int o_src[5], e_src[5];        // -1: this lane does not take part in the (partial) round
     int na_o = 0, na_e = 0;        // wave-uniform: DMA instructions this wave issues per half
     {
@@ -97,14 +100,14 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                 const int v = r * 64 + lane, P = v >> 2, row = P / PXR, q = P - row * PXR;
                 const int col = q < 33 ? 2 * q : 2 * (q - 33) + 1;
                 const int lc = (v & 3) ^ ((P >> 2) & 3);
-                o_src[k] = (r < ODD_WR && v < ODD_V) ? ((2 * row + 1) * p.W + col) * p.Cin + lc * 8 : -1;
+                o_src[k] = (r < ODD_WR && v < ODD_V) ? ((2 * row + 1) * p.W + col) * pixs + lc * 8 : -1;
                 if (r < ODD_WR) na_o = k + 1;
             }
             {
                 const int v = r * 64 + lane, P = v >> 2, row = P / PXR, q = P - row * PXR;
                 const int col = q < 33 ? 2 * q : 2 * (q - 33) + 1;
                 const int lc = (v & 3) ^ ((P >> 2) & 3);
-                e_src[k] = (r < EVEN_WR && v < EVEN_V) ? ((2 * row) * p.W + col) * p.Cin + lc * 8 : -1;
+                e_src[k] = (r < EVEN_WR && v < EVEN_V) ? ((2 * row) * p.W + col) * pixs + lc * 8 : -1;
                 if (r < EVEN_WR) na_e = k + 1;
             }
         }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
     struct Src { const half_t* hb; const half_t* xs; const half_t* w; const half_t* ws; };
     auto src_of = [&](const Item& it) {
         Src s;
-        s.hb = p.x + (long long)it.b * p.x_bstride + ((long long)(2 * it.ty0) * p.W + 2 * it.tx0) * p.Cin;
+        s.hb = p.x + (long long)it.b * p.x_bstride + ((long long)(2 * it.ty0) * p.W + 2 * it.tx0) * pixs;
         s.xs = p.skip_x + (((long long)it.b * p.Ho + it.ty0) * p.Wo + it.tx0) * p.Cin;
         s.w = p.w + (long long)it.n0 * p.Cin;
         s.ws = p.skip_w + (long long)it.n0 * p.Cin;
@@ -142,12 +145,12 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
     // one DMA instruction (1 KB per wave) of each operand: k-th wave-round of a half / the skip operand / a weight slice
     auto odd_piece = [&](const Src& s, int c, int k) {
         if (k < na_o) {
-            if (o_src[k] >= 0) dma16(s.hb + o_src[k] + c * 32, smem + OFF_ODD + wave * 1024 + k * 8192);
+            if (o_src[k] >= 0) dma16(s.hb + o_src[k] + c * c_step, smem + OFF_ODD + wave * 1024 + k * 8192);
         }
     };
     auto even_piece = [&](const Src& s, int c, int k) {
         if (k < na_e) {
-            if (e_src[k] >= 0) dma16(s.hb + e_src[k] + c * 32, smem + OFF_EVEN + wave * 1024 + k * 8192);
+            if (e_src[k] >= 0) dma16(s.hb + e_src[k] + c * c_step, smem + OFF_EVEN + wave * 1024 + k * 8192);
         }
     };
     auto xs_piece = [&](const Src& s, int c, int k) { dma16(s.xs + x_src[k] + c * 32, smem + OFF_XS + wave * 1024 + k * 8192); };

@@ -458,7 +458,7 @@ bool conv_stream_applies(const ConvParams& p) {
     static const bool off = glass_knob("GLASS_NO_STREAM") != nullptr;   // experiment knob
     const bool trgb = p.trgb_yout != nullptr;
     if (!glass_lds_fits(LDS_BYTES)) return false;
-    if (p.x_planar8 || p.y_planar8) return false;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8 || p.x_planar32) return false;   // chunk-planar maps (common.h): not implemented here
     if (off || p.up || p.xs_out || p.y32 || (!p.y && !trgb) || p.KS != 3 || p.stride != 1 || p.pad != 1 || (p.sn && !p.sn16)) return false;
     const bool frgb = p.rgb_y != nullptr;
     if (frgb && (!p.rgb_w || !p.rgb_b || (!p.rgb_x_out && !p.rgb_xs_out) || p.sn || trgb)) return false;

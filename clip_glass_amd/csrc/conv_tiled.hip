@@ -614,7 +614,7 @@ static const char* launch_inst(const ConvParams& p, hipStream_t st, const char* 
 
 const char* launch_conv_tiled(const ConvParams& p0, hipStream_t st) {
     ConvParams p = p0;
-    if (p.x_planar8 || p.y_planar8) return nullptr;   // chunk-planar maps (common.h): not implemented here
+    if (p.x_planar8 || p.y_planar8 || p.x_planar32) return nullptr;   // chunk-planar maps (common.h): not implemented here
     static const bool no_ts = glass_knob("GLASS_NO_TSTORE") != nullptr;   // experiment knob
     if (no_ts) p.no_tstore = 1;
     // A/B knob GLASS_DEEP: 0 = round 2's one-stage prefetch distance, 1 = patch three stages ahead, 2 = + two weight register sets (stride 2)

@@ -482,7 +482,7 @@ const char* launch_conv_wreg(const ConvParams& p, hipStream_t st) {
     if (p.Hc % TH != 0 || p.Wc % TW != 0 || p.Hc != p.H || p.Wc != p.W || (p.x_bstride == 0 && p.B > 1)) return nullptr;
     if (p.xs_out && p.trgb_yout) return nullptr;
     if (p.res) return nullptr;                     // (no residual input: neither layer has one; conv_wres takes such a call)
-    if (p.y_planar8) return nullptr;               // (reads the chunk-planar layout, writes pixel-major)
+    if (p.y_planar8 || p.x_planar32) return nullptr;   // (reads the 8-channel-plane layout, writes pixel-major)
     if (p.trgb_yout && (!p.trgb_tab || !p.trgb_b)) return nullptr;
     const int tiles_x = p.Wc / TW, tiles_y = p.Hc / TH;
     const int n_cu = glass_cu_count();

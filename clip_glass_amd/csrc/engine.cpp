@@ -1227,25 +1227,35 @@ static half_t* run_d_blocks(glass_engine* e, int B, int i_lo, int i_hi, half_t* 
             }
             pr.on = false;
         }
-        {
-            snprintf(tag, sizeof tag, "D.blur.r%d", r);
-            Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
-            launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->cur);
-        }
         ConvParams q = conv_defaults();
         q.x = HB; q.x_bstride = (long long)(r + 1) * (r + 1) * d.cin; q.B = B; q.H = q.W = r + 1; q.Cin = d.cin;
         q.Hc = q.Wc = r2; q.KS = 3; q.stride = 2; q.pad = 0; q.w = d.w1; q.Cout = q.Neff = d.cout; q.Ho = q.Wo = r2;
         q.bias = d.b1; q.act = 1; q.out_scale = 0.70710678118654752440f; q.y = O;
+        // blur -> conv_s2 link: that kernel stages its input one 32-channel chunk per K step, so (where it runs) the blur writes 32-channel planes
+        bool hb_planar = false;
+        {
+            static const bool no_planar = glass_knob("GLASS_NO_PLANAR") != nullptr;      // A/B knob
+            static const bool no_skip_fuse0 = glass_knob("GLASS_NO_SKIP_FUSE") != nullptr;
+            ConvParams qp = q;
+            qp.skip_x = XS; qp.skip_w = d.wskip; qp.x_planar32 = 1; qp.dry_run = 1;
+            hb_planar = !no_planar && !no_skip_fuse0 && blur_pad2_planar32_ok(d.cin) && launch_conv_s2(qp, e->cur) != nullptr;
+        }
+        {
+            snprintf(tag, sizeof tag, "D.blur.r%d", r);
+            Prof pr(e, tag, 2.0 * B * (double)(r + 1) * (r + 1) * d.cin * 16, 4.0 * B * (double)r * r * d.cin);
+            launch_blur_pad2(Hb, B, r, r, d.cin, HB, e->cur, hb_planar);
+        }
         snprintf(tag, sizeof tag, "D.conv1.r%d.%dx%d", r2, d.cin, d.cout);
         const double f1 = 2.0 * B * (double)r2 * r2 * 9 * d.cin * d.cout, fs = 2.0 * B * (double)r2 * r2 * d.cin * d.cout;
         {   // skip branch as extra K stages of the stride-2 conv (conv_tiled<3,2,4,N,skip>) where that kernel applies
             static const bool no_skip_fuse = glass_knob("GLASS_NO_SKIP_FUSE") != nullptr;   // A/B knob
             ConvParams qs = q;
             qs.skip_x = XS; qs.skip_w = d.wskip; qs.dry_run = 1;
-            if (!no_skip_fuse && launch_conv_tiled(qs, e->cur)) {
+            qs.x_planar32 = hb_planar;
+            if (!no_skip_fuse && (hb_planar ? launch_conv_s2(qs, e->cur) : launch_conv_tiled(qs, e->cur))) {
                 qs.dry_run = 0;
                 Prof pr(e, tag, f1 + fs, 2.0 * B * ((double)(r + 1) * (r + 1) * d.cin + (double)r2 * r2 * (d.cin + d.cout)));
-                const char* k = launch_conv_tiled(qs, e->cur);
+                const char* k = hb_planar ? launch_conv_s2(qs, e->cur) : launch_conv_tiled(qs, e->cur);
                 if (pr.on) pr.pe.name = std::string(tag) + "@" + k;
                 if (e->profiling) e->tag_kernel[tag] = k;
                 std::swap(X, O);

@@ -82,7 +82,8 @@ void launch_resize_patches(const float* y, int B, int R, int clip_res, int ps, h
 void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, const float* bias,
                     half_t* out, hipStream_t st);
 // 4x4 FIR [1,3,3,1]^2/64, zero pad 2, stride 1: [B,H,W,C] -> [B,H+1,W+1,C]
-void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st);
+void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st, int planar32 = 0);   // planar32: [C/32][H+1][W+1][32] for conv_s2
+bool blur_pad2_planar32_ok(int C);      // the channel counts that form exists for
 // 4x4 FIR, zero pad 1, then ::2 subsample: [B,H,W,C] -> [B,H/2,W/2,C]
 void launch_blur_down(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st);
 // minibatch-std (reference quirk: features are group-mean subtracted): [B,hw,C] -> [B,hw,Cpad]

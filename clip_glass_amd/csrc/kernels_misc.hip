@@ -666,16 +666,33 @@ void launch_fromrgb(const float* y, int B, int R, int Cout, const float* w, cons
 // vertical sum.  (RS + 3) * 4 loads per RS outputs instead of 16 per output.
 template <int PAD, int STRIDE, int RS>
 __global__ __launch_bounds__(256) void blur_kernel(const half_t* x, int H, int W, int C, int Ho, int Wo,
-                                                   half_t* out) {
+                                                   half_t* out, int planar32) {
     const int cg = C >> 3;
     const int idx = blockIdx.x * 256 + threadIdx.x;      // over (ox, channel group)
-    if (idx >= Wo * cg) return;
+    if (!planar32 && idx >= Wo * cg) return;
     const int b = blockIdx.z;
-    const int g = idx % cg, ox = idx / cg;
+    // thread -> (output column, 8-channel group): groups fastest (a wave loads and stores 1 KB of consecutive pixels' channels).
+    // 32-channel-plane output, measured per channel count (us per launch, pixel-major output = 774 / 410 / 224 / 136 at C = 64 / 128 / 256 / 512):
+    //   groups fastest (stores of 64-byte pieces into 2 .. 16 planes):                        830 / 453 / 268 / 172
+    //   the workgroup's columns and groups re-dealt inside it, a plane's four groups fastest
+    //   (a wave stores consecutive pixels of ONE plane, loads 64-byte pieces of each pixel):    937 / 494 / 230 / 139
+    //   planes dealt over the whole grid:                                                       942 / 533 / 277 / 149
+    // -> the first form for C <= 128, the second from 256 channels on.
+    int g = idx % cg, ox = idx / cg;
+    if (planar32 && idx >= Wo * cg && cg < 32) return;
+    if (planar32 && cg >= 32) {
+        const int P = 256 / cg;                 // columns of this workgroup (cg divides 256: C is a power of two here; checked by the launcher)
+        const int t = threadIdx.x, pl = (t >> 2) / P;
+        g = pl * 4 + (t & 3);
+        ox = blockIdx.x * P + (t >> 2) % P;
+        if (ox >= Wo) return;
+    }
     const int oy0 = blockIdx.y * RS;
     const float f[4] = {0.125f, 0.375f, 0.375f, 0.125f};
     const half_t* xb = x + (long long)b * H * W * C + g * 8;
-    half_t* ob = out + (long long)b * Ho * Wo * C + g * 8;
+    // output: pixel-major [Ho][Wo][C], or 32-channel planes [C / 32][Ho][Wo][32] for conv_s2 (common.h x_planar32)
+    const int opix = planar32 ? 32 : C;
+    half_t* ob = out + (long long)b * Ho * Wo * C + (planar32 ? (long long)(g >> 2) * Ho * Wo * 32 + (g & 3) * 8 : g * 8);
     // Loads are UNCONDITIONAL (clamped column / row, the tap weight carries the zero padding): a load under a
     // branch makes the compiler wait for it at the join, i.e. one load in flight per thread.
     int xoff[4];
@@ -719,23 +736,25 @@ __global__ __launch_bounds__(256) void blur_kernel(const half_t* x, int H, int W
                     for (int j = 0; j < 8; ++j)
                         o[j] = (half_t)(f[0] * hs[(r - 3) & 3][j] + f[1] * hs[(r - 2) & 3][j] + f[2] * hs[(r - 1) & 3][j] +
                                         f[3] * hs[r & 3][j]);
-                    *(h8*)(ob + ((long long)oy * Wo + ox) * C) = o;
+                    *(h8*)(ob + ((long long)oy * Wo + ox) * opix) = o;
                 }
             }
         }
     }
 }
-void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
+bool blur_pad2_planar32_ok(int C) { return C % 32 == 0 && (C >> 3) <= 64 && 256 % (C >> 3) == 0; }
+void launch_blur_pad2(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st, int planar32) {
     const int Ho = H + 1, Wo = W + 1;
     constexpr int RS = 16;
     dim3 g((Wo * (C >> 3) + 255) / 256, (Ho + RS - 1) / RS, B);
-    hipLaunchKernelGGL((blur_kernel<2, 1, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out);
+    if (planar32 && !blur_pad2_planar32_ok(C)) abort();       // (the caller asks blur_pad2_planar32_ok first: a silent pixel-major map would be mis-read)
+    hipLaunchKernelGGL((blur_kernel<2, 1, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out, planar32);
 }
 void launch_blur_down(const half_t* x, int B, int H, int W, int C, half_t* out, hipStream_t st) {
     const int Ho = H / 2, Wo = W / 2;
     constexpr int RS = 8;
     dim3 g((Wo * (C >> 3) + 255) / 256, (Ho + RS - 1) / RS, B);
-    hipLaunchKernelGGL((blur_kernel<1, 2, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out);
+    hipLaunchKernelGGL((blur_kernel<1, 2, RS>), g, dim3(256), 0, st, x, H, W, C, Ho, Wo, out, 0);
 }
 
 // ---- MinibatchStd (modules.py:701-747).  Per D call (minibatch of batch_size), groups of

@@ -139,6 +139,7 @@ extern "C" int glass_op_conv(int32_t device, const glass_conv_desc* d) {
         }
     }
     p.x_planar8 = d->x_planar8;
+    p.x_planar32 = d->x_planar32;
     if (d->impl == 1) { if (!launch_conv_direct(p, 0)) { glass_set_error("direct conv: unsupported launch"); return GLASS_ERR_ARG; } }
     else if (d->impl == 3) {
         if (!launch_upconv_fused(p, 0)) { glass_set_error("fused up-conv: unsupported shape"); return GLASS_ERR_ARG; }
@@ -228,9 +229,10 @@ extern "C" int glass_op_blur(int32_t device, int32_t mode, int32_t B, int32_t H,
     GLASS_HIP(hipSetDevice(device));
     Dev dv;
     half_t* dx = dv.up16(x, (size_t)B * H * H * C);
-    const int Ho = mode == 0 ? H + 1 : H / 2;
+    OPREQ(mode != 2 || blur_pad2_planar32_ok(C), "blur in 32-channel planes: C must be 32 x a power of two, <= 512");
+    const int Ho = mode != 1 ? H + 1 : H / 2;
     half_t* dy = dv.alloc<half_t>((size_t)B * Ho * Ho * C);
-    if (mode == 0) launch_blur_pad2(dx, B, H, H, C, dy, 0);
+    if (mode != 1) launch_blur_pad2(dx, B, H, H, C, dy, 0, mode == 2);
     else launch_blur_down(dx, B, H, H, C, dy, 0);
     int rc = finish();
     if (rc) return rc;

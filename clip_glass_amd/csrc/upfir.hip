@@ -972,7 +972,7 @@ const char* launch_upconv_fused(const ConvParams& p, hipStream_t st) {
     if (!p.up || !p.w_up || p.y32 || !p.y || p.res || (p.sn && !p.sn16)) return nullptr;
     if (p.Cin % 32 != 0 || p.Cout % 32 != 0 || p.KS != 3) return nullptr;
     if (p.x_bstride == 0 && p.B > 1) return nullptr;
-    if (p.x_planar8) return nullptr;              // chunk-planar input (common.h): not implemented here
+    if (p.x_planar8 || p.x_planar32) return nullptr;   // chunk-planar input (common.h): not implemented here
     static const bool v1 = glass_knob("GLASS_UPFIR_V1") != nullptr;      // A/B knob: round 2's one-tile-per-workgroup kernel
     if (!v1) {
         const char* k = launch_upfir2(p, st);

@@ -24,13 +24,23 @@ class ConvDesc(C.Structure):
                 ("trgb_smax", C.POINTER(C.c_float)), ("trgb_yprev", C.POINTER(C.c_float)),
                 ("trgb_yout", C.POINTER(C.c_float)),
                 ("skip_x", C.POINTER(C.c_float)), ("skip_w", C.POINTER(C.c_float)), ("xs_out", C.POINTER(C.c_float)),
-                ("x_planar8", C.c_int32)]
+                ("x_planar8", C.c_int32), ("x_planar32", C.c_int32)]
 
 
 def to_planar8(a):
     """[B,H,W,C] -> the chunk-planar layout [B,C/8,H,W,8] conv_wreg's producers write (csrc/common.h x_planar8)."""
     B, H, W, Cc = a.shape
     return np.ascontiguousarray(a.reshape(B, H, W, Cc // 8, 8).transpose(0, 3, 1, 2, 4))
+
+
+def to_planar32(a):
+    """[B,H,W,C] -> 32-channel planes [B,C/32,H,W,32]: the layout the pad-2 blur writes for conv_s2 (csrc/common.h x_planar32)."""
+    B, H, W, Cc = a.shape
+    return np.ascontiguousarray(a.reshape(B, H, W, Cc // 32, 32).transpose(0, 3, 1, 2, 4))
+
+
+def from_planar32(a, B, H, W, Cc):
+    return np.ascontiguousarray(a.reshape(B, Cc // 32, H, W, 32).transpose(0, 2, 3, 1, 4)).reshape(B, H, W, Cc)
 
 
 def from_planar8(a, B, H, W, Cc):
@@ -46,7 +56,7 @@ def _opt(a):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None, skip=None, xs_out=None, planar_x=False, both=False):
+         torgb=None, skip=None, xs_out=None, planar_x=False, both=False, planar32_x=False):
     """x [B,H,W,Cin] NHWC; w [Cout,Cin,KS,KS] (reference layout).  Returns y [B,Ho,Wo,Cout].
     torgb = dict(w [3,Cout], b [3], sn [B,Cout], smax [B], yprev [B,3,Ho/2,Wo/2] or None) with impl=4: the fused conv + toRGB
     form of the streaming kernel — returns the skip image [B,3,Ho,Wo] instead of y.
@@ -56,6 +66,8 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
     Bx, H, W, Cin = x.shape
     if planar_x:
         x = to_planar8(x)
+    if planar32_x:            # conv_s2's input in 32-channel planes (permuted here)
+        x = to_planar32(x)
     B = B if B is not None else Bx
     Cout, _, KS, _ = w.shape
     pad = (KS // 2) if pad is None else pad
@@ -70,6 +82,7 @@ def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None
     d.broadcast_x, d.act, d.batch_size, d.impl = int(broadcast_x), int(act), batch_size, impl
     d.noise_strength, d.out_scale = noise_strength, out_scale
     d.x_planar8 = int(planar_x)
+    d.x_planar32 = int(planar32_x)
     keep = []
     d.x, d.w, d.y = _fp(x), _fp(w), _fp(y)
     for name, val in (("sn", sn), ("dscale", dscale), ("noise", noise), ("bias", bias), ("res", res)):
@@ -143,12 +156,12 @@ def blur(x, mode, device=0):
     lib = load_library()
     x = _f32(x)
     B, H, _, Cc = x.shape
-    Ho = H + 1 if mode == 0 else H // 2
+    Ho = H + 1 if mode != 1 else H // 2      # mode 2: pad 2 written in 32-channel planes (un-permuted here)
     out = np.empty((B, Ho, Ho, Cc), dtype=np.float32)
     fp = C.POINTER(C.c_float)
     lib.glass_op_blur.argtypes = [C.c_int32] * 5 + [fp, fp]
     _check(lib, lib.glass_op_blur(device, mode, B, H, Cc, _fp(x), _fp(out)))
-    return out
+    return from_planar32(out, B, Ho, Ho, Cc) if mode == 2 else out
 
 
 def dblock_down(h, x, w1, wskip, b1, device=0):

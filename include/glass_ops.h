@@ -45,6 +45,8 @@ typedef struct glass_conv_desc {
     float* xs_out;           /* [B,H/2,W/2,Cin] or NULL */
     /* impl 5, 64 -> 64: x is handed over chunk-planar, [B,Cin/8,H,W,8] (the layout conv_wreg's producers write for it) */
     int32_t x_planar8;
+    /* impl 5 with the fused skip branch (conv_s2): x is handed over in 32-channel planes, [B,Cin/32,H,W,32] (the layout the pad-2 blur writes for it) */
+    int32_t x_planar32;
 } glass_conv_desc;
 
 int glass_op_conv(int32_t device, const glass_conv_desc* d);
@@ -55,7 +57,7 @@ int glass_op_dense(int32_t device, int32_t P, int32_t K, int32_t N, const float*
                    const float* bias, int32_t in_sq, int32_t mode, const float* eps_row, float* out);
 int glass_op_torgb(int32_t device, int32_t B, int32_t H, int32_t C, const float* x, const float* wrgb /*[3,C] scaled*/,
                    const float* bias, const float* sn, const float* smax, const float* yprev, float* yout);
-int glass_op_blur(int32_t device, int32_t mode /*0: pad2 stride1, 1: pad1 + ::2*/, int32_t B, int32_t H, int32_t C,
+int glass_op_blur(int32_t device, int32_t mode /*0: pad2 stride1, 1: pad1 + ::2, 2: pad2 stride1 written as [B,C/32,H+1,H+1,32]*/, int32_t B, int32_t H, int32_t C,
                   const float* x, float* out);
 /* second half of a discriminator block in one kernel (conv_down.hip; stylegan2/modules.py:1204-1254, 1587-1601):
  * y = (lrelu(conv3x3 stride 2 (fir pad 2 (h)) + b1) * sqrt2 + conv1x1(fir pad 1 (x)[::2])) / sqrt2.

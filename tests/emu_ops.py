@@ -26,7 +26,7 @@ def mfma_probe(a, b):
 
 def conv(x, w, *, stride=1, pad=None, up=False, sn=None, dscale=None, noise=None, noise_strength=0.0,
          batch_size=1, bias=None, act=False, res=None, out_scale=1.0, impl=0, broadcast_x=False, B=None, device=0,
-         torgb=None, skip=None, xs_out=None, planar_x=False):
+         torgb=None, skip=None, xs_out=None, planar_x=False, both=False, planar32_x=False):
     x = np.asarray(x, np.float32)       # (planar_x: a device-side layout of the real op; the values are the same)
     Bx, H, W, Cin = x.shape
     B = B or Bx
@@ -141,7 +141,7 @@ def blur(x, mode, device=0):
     t = torch.tensor(_h(x)).permute(0, 3, 1, 2)
     f = torch.tensor([1., 3., 3., 1.]) / 8
     k = (f[:, None] * f[None, :])[None, None].repeat(t.shape[1], 1, 1, 1)
-    if mode == 0:
+    if mode != 1:      # (mode 2: a device-side output layout of the real op; the values are the same)
         y = F.conv2d(F.pad(t, [2, 2, 2, 2]), k, groups=t.shape[1])
     else:
         y = F.conv2d(F.pad(t, [1, 1, 1, 1]), k, groups=t.shape[1])[:, :, ::2, ::2]

@@ -143,6 +143,8 @@ def _stride2_skip_case(B, R, Cin, Cout, impl, label):
     ref = ((y + F.conv2d(t(xs), wss)) * 2.0 ** -0.5).numpy().transpose(0, 2, 3, 1)
     check(label + " vs float64", got, ref, 2e-3)
     check(label + " vs two passes", got, ref2, 3e-3)
+    if impl == 5:     # conv_s2: the blurred input in 32-channel planes (common.h x_planar32, written so by the pad-2 blur): same values
+        np.testing.assert_array_equal(got, ops.conv(hb, w1, skip=(xs, ws), impl=impl, planar32_x=True, **kw))
 
 
 @pytest.mark.parametrize("B,R,Cin,Cout", [(2, 64, 64, 128), (3, 64, 32, 64), (1, 128, 128, 256)])
@@ -426,6 +428,8 @@ def test_d_block_pieces(impl, H, Cin, Cout):
     check("D conv0", nchw(g_h), h.numpy(), 4e-3)
     g_hb = ops.blur(g_h, 0)
     check("D blur pad2", nchw(g_hb), hb.numpy(), 4e-3)
+    if g_h.shape[-1] % 32 == 0:
+        np.testing.assert_array_equal(g_hb, ops.blur(g_h, 2))       # the same values written in 32-channel planes (for conv_s2)
     g_xs = ops.blur(nhwc(x), 1)
     check("D blur-down", nchw(g_xs), xs.numpy(), 4e-3)
     g_s = ops.conv(g_xs, ws, pad=0, impl=impl)
