@@ -36,7 +36,7 @@ struct Geo {
     static constexpr int OFF_C = OFF_B + 3 * (3 * NT * 64);      // epilogue constants [3][NT] floats
     static constexpr int OFF_S = OFF_C + 3 * NT * 4;             // this sample's style row, Cin <= 1024 halfs
     static constexpr int OFF_T = OFF_S + 2048;                   // TRGB: compact toRGB weight rows [hi r,g,b | lo r,g,b][NT] fp16
-    static constexpr int OFF_N = OFF_T + 6 * NT * 2;             // persistent form: the tile's noise values [8 waves][2 rows][32 px] fp32
+    static constexpr int OFF_N = OFF_T + 6 * NT * 2 + 512;       // persistent form: the tile's noise values [8 waves][2 rows][32 px] fp32 (+ 512: the idle lanes of the table's second full-wave piece)
     static constexpr int LDS_BYTES = OFF_N + 8 * 64 * 4;
     static_assert(LDS_BYTES <= 163840, "one workgroup per CU");
 };
@@ -475,10 +475,11 @@ __global__ __launch_bounds__(512, 1) void conv_gldsp_kernel(ConvParams p, int NT
                 if (p.shift) dma4(p.shift + (long long)b * p.ds_stride + n0 + t, cc + 2 * NT * 4);
             }
             if (p.noise) dma4(p.noise + ((long long)(b / p.batch_size) * p.Ho + ty0 + wave * RW + kh) * p.Wo + tx0 + lr, smem + G::OFF_N + wave * 256);
-            if (TRGB && t < 6 * (NT / 8)) {
-                const int row6 = t / (NT / 8), piece = t % (NT / 8);
+            if (TRGB && wave < 2) {            // two FULL-wave pieces (96 vectors + 32 idle lanes fed from the zero page into the slack behind the table:
+                                               // an LDS-DMA under a lane mask is what hipcc mis-merged in conv_wreg.hip, DESIGN "Round 6")
+                const int row6 = min(t / (NT / 8), 5), piece = t % (NT / 8);
                 const int n = row6 < 3 ? row6 : 8 + (row6 - 3);
-                dma16(p.trgb_tab + ((long long)b * 32 + n) * p.Neff + n0 + piece * 8, smem + G::OFF_T + wave * 1024);     // (rows of Neff entries: this n tile's 128)
+                dma16(t < 6 * (NT / 8) ? p.trgb_tab + ((long long)b * 32 + n) * p.Neff + n0 + piece * 8 : g_zero_page, smem + G::OFF_T + wave * 1024);     // (rows of Neff entries: this n tile's 128)
             }
         };
         if (grp) __builtin_amdgcn_s_barrier();     // group 1 falls one barrier behind: its load intervals face group 0's MFMA intervals

@@ -40,14 +40,18 @@ constexpr int PXR = 65;                                  // input pixels per pat
 constexpr int ODD_V = 8 * PXR * 4, EVEN_V = 9 * PXR * 4; // 16-byte vectors of the two halves (2080, 2340)
 constexpr int ODD_WR = (ODD_V + 63) / 64, EVEN_WR = (EVEN_V + 63) / 64;   // wave-rounds (64 vectors each): 33, 37
 constexpr int OFF_ODD = 0;
-constexpr int OFF_EVEN = ODD_V * 16;                     // 33280
-constexpr int OFF_XS = OFF_EVEN + EVEN_V * 16;           // 70720: skip operand [8][32] px x 64 B
+// every piece is a FULL 64-lane instruction (an LDS-DMA under a lane mask in divergent control flow is what hipcc mis-merged in conv_wreg.hip,
+// DESIGN "Round 6"): the idle lanes of a half's last, partial round fetch a zero page into the slack behind the half
+constexpr int OFF_EVEN = ODD_WR * 1024;                  // 33792 (33280 used)
+constexpr int OFF_XS = OFF_EVEN + EVEN_WR * 1024;        // 71680 (37440 used): skip operand [8][32] px x 64 B
 constexpr int XS_BYTES = TH * 32 * 64;                   // 16384
-constexpr int OFF_W = OFF_XS + XS_BYTES;                 // 87104
+constexpr int OFF_W = OFF_XS + XS_BYTES;                 // 88064
 constexpr int W_SLOT = 3 * NT * 64;                      // 24576
-constexpr int OFF_C = OFF_W + 3 * W_SLOT;                // 160832: bias [Neff <= 512] fp32
+constexpr int OFF_C = OFF_W + 3 * W_SLOT;                // 161792: bias [Neff <= 512] fp32
 constexpr int MAX_N = 512;
-constexpr int LDS_BYTES = OFF_C + MAX_N * 4;             // 162880 of 163840
+constexpr int LDS_BYTES = OFF_C + MAX_N * 4;             // 163840 of 163840
+static_assert(LDS_BYTES <= 163840, "one workgroup per CU");
+__device__ __attribute__((aligned(64))) half_t g_s2_zero_page[32];   // zero-initialised: what the idle lanes of a partial round fetch
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
@@ -145,12 +149,12 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
     // one DMA instruction (1 KB per wave) of each operand: k-th wave-round of a half / the skip operand / a weight slice
     auto odd_piece = [&](const Src& s, int c, int k) {
         if (k < na_o) {
-            if (o_src[k] >= 0) dma16(s.hb + o_src[k] + c * c_step, smem + OFF_ODD + wave * 1024 + k * 8192);
+            dma16(o_src[k] >= 0 ? s.hb + o_src[k] + c * c_step : g_s2_zero_page, smem + OFF_ODD + wave * 1024 + k * 8192);
         }
     };
     auto even_piece = [&](const Src& s, int c, int k) {
         if (k < na_e) {
-            if (e_src[k] >= 0) dma16(s.hb + e_src[k] + c * c_step, smem + OFF_EVEN + wave * 1024 + k * 8192);
+            dma16(e_src[k] >= 0 ? s.hb + e_src[k] + c * c_step : g_s2_zero_page, smem + OFF_EVEN + wave * 1024 + k * 8192);
         }
     };
     auto xs_piece = [&](const Src& s, int c, int k) { dma16(s.xs + x_src[k] + c * 32, smem + OFF_XS + wave * 1024 + k * 8192); };
