@@ -9,9 +9,10 @@
 // store epilogue and a full staging prologue per 64-byte pixel in kernels that are bound by instruction issue, 4.3 ms.  Here only
 // the 12-byte-per-pixel image comes in and the 128-byte-per-pixel block output goes out; x and h exist in LDS only.
 //
-// Geometry.  A step produces 2 output rows x 30 output columns (of the R/2 grid).  It needs h rows 4k-2 .. 4k+5 and columns
-// 60tx-2 .. 60tx+61 (an 8 x 64 window: 64 columns = two 32-pixel MFMA blocks per row, which is what fixes the tile width at 30),
-// and for the NEW rows of that window the fromRGB map x on rows 4k+1 .. 4k+6 x columns 60tx-3 .. 60tx+62 (the patch F, 6 x 66 pixels).
+// Geometry.  A step produces 2 output rows x 29 output columns (of the R/2 grid).  It needs h rows 4k-2 .. 4k+5 and columns
+// 58tx-2 .. 58tx+59 (an 8 x 62 window inside the 64 columns = two 32-pixel MFMA blocks a row is computed on),
+// and for the NEW rows of that window the fromRGB map x on rows 4k+1 .. 4k+6 x columns 58tx-3 .. 58tx+60 (the patch F, 6 x 64 pixels =
+// twelve 32-pixel blocks, three per wave; rounds 4-5 used 30-column tiles: a 6 x 66 patch with a thirteenth, 12-pixel block).
 // Steps walk DOWN a tile column, so 4 of the 8 window rows are carried from the previous step: a step computes 4 new h rows.  The
 // skip-branch input of an output row needs x rows 2o-1 .. 2o+2: the patch of step k holds them for rows 2k+1 and 2k+2, so that input
 // runs one row AHEAD of the stride-2 conv, through a 3-row ring.  A workgroup's range starts (and every column starts) with a
@@ -46,7 +47,8 @@
 
 namespace {
 constexpr int NW = 4, NTHR = 64 * NW;                 // waves = new h rows per step
-constexpr int TW = 30, FP = 66, FR = NW + 2, FC = 66; // patch: 6 rows x 66 columns (the swizzle key is the column only: any pitch works)
+constexpr int TW = 29, XW = 2 * TW;                    // output columns per tile, h / x columns a tile advances by (round 6: 30 -> 29, see NFB)
+constexpr int FP = 66, FR = NW + 2, FC = 64;          // patch: 6 rows x 64 columns at a pitch of 66 (the swizzle key is the column only: any pitch works)
 constexpr int RING = 8, AR = 5, XSR = 3;              // h window rows (4 carried + 4 new), operand rows, skip-input ring rows
 constexpr int F_BYTES = FR * FP * 64;                 // 25344: fromRGB patch; the operand image A (5 x 4096) aliases it
 constexpr int ROWB = 64 * 64;                         // one 64-slot row of 64-byte pixels
@@ -55,7 +57,12 @@ constexpr int OFF_HB = OFF_RT + NW * ROWB;            // ring of 8 horizontally 
 constexpr int OFF_XS = OFF_HB + RING * ROWB;          // skip-branch input ring [3 rows][32 px][32 ch]
 constexpr int OFF_C = OFF_XS + XSR * 32 * 64;         // bias0 [32] f32, bias1 [64] f32
 constexpr int LDS_BYTES = OFF_C + 32 * 4 + 64 * 4;    // 81024 -> two workgroups per CU
-constexpr int NFB = (FR * FC + 31) / 32;              // 13 blocks of 32 patch pixels (the last holds 12); block i belongs to wave i % 4
+constexpr int NFB [[maybe_unused]] = FR * FC / 32;                     // 12 blocks of 32 patch pixels: three per wave (block i belongs to wave i % 4).  With 30-column tiles
+// the h window was 64 columns wide and the patch 66: a thirteenth block of 12 pixels, wave 0's fourth, kept the other three waves at the barrier
+// behind P1 for a quarter of the phase.  29-column tiles cover 512 columns with the same 18 tiles; the window needs 62 h columns (the MFMA
+// blocks still compute 64: columns 62 / 63 read patch columns 64 / 65 that nobody writes — finite or not, a pixel's lane never meets another
+// pixel's, and the blurred columns 59 / 60 they reach are neither written to the ring nor read by a stored output).
+static_assert(FR * FC == 32 * 3 * NW, "three full patch blocks per wave");
 static_assert(AR * ROWB <= F_BYTES, "operand image aliases the patch");
 static_assert(2 * ((LDS_BYTES + 511) / 512 * 512) <= 160 * 1024, "two workgroups per CU");
 
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             }
         (void)lane; (void)nh;
         rtw = opaque(OFF_RT + wave * ROWB + vrot(lr, 0) + kh * 8);                                                // conv0 row image: + g * 16 + blk * 2048
-        p4off = opaque(swz(min(t, 243) >> 2, t & 3));
+        p4off = opaque(swz(min(t, 239) >> 2, t & 3));
     }
 
     // ---- the walk: steps (b, tx, k), k fastest (down a tile column); a priming item (k - 1, no output) opens every range / column ---
@@ -206,16 +213,16 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     // image values of an item's patch: patch pixel 32 * (wave + 4u) + lr for u = 0 .. 3 (both lane halves fetch the same pixel: the
     // MFMA operand of a pixel lives in lane half 0); unconditional loads at clamped coordinates (the zero padding is a mask applied
     // when the operand is built)
-    float yv[4][3];
+    float yv[3][3];
     auto load_image = [&](const Item& c) {
         if (D0_ABL(1)) return;
         const int t = opaque(threadIdx.x);
-        const int y0 = 4 * c.k + 1, x0 = 60 * c.tx - 3;
+        const int y0 = 4 * c.k + 1, x0 = XW * c.tx - 3;
         const long long hw = (long long)R * R;
         const float* yb = p.rgb_y + (long long)c.b * 3 * hw;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int px = min(32 * ((t >> 6) + NW * u) + (t & 31), FR * FC - 1);
+        for (int u = 0; u < 3; ++u) {
+            const int px = 32 * ((t >> 6) + NW * u) + (t & 31);
             const int fr = px / FC, fc = px - fr * FC;
             const int iy = min(max(y0 + fr, 0), R - 1), ix = min(max(x0 + fc, 0), R - 1);
             const int off = iy * R + ix;
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
     int n_item = 0;
     auto step = [&](const Item& c, const Item& nx) {
         const int b = c.b, tx = c.tx, k = c.k;
-        const int y0 = 4 * k + 1, x0 = 60 * tx - 3;
+        const int y0 = 4 * k + 1, x0 = XW * tx - 3;
         D0TRACE(0);
         __syncthreads();       // B0: every wave is done with the previous item's operand image / patch / XS
         D0TRACE(1);
@@ -237,11 +244,15 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             f16x zacc;
 #pragma unroll
             for (int q = 0; q < 16; ++q) zacc[q] = 0.f;
+            // the three blocks of a wave side by side (no early exit between them: as a loop with a uniform break every block was its own
+            // basic block and ran its whole chain — operand, MFMA latency, conversion, activation, stores — before the next one started)
+            f16x z[3];
+            int fr3[3], fc3[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (wv + NW * u >= NFB) break;                                         // (uniform: only wave 0 has a fourth block)
-                const int pxr = 32 * (wv + NW * u) + lr1, px = min(pxr, FR * FC - 1);
+            for (int u = 0; u < 3; ++u) {
+                const int px = 32 * (wv + NW * u) + lr1;
                 const int fr = px / FC, fc = px - fr * FC;
+                fr3[u] = fr; fc3[u] = fc;
                 const int iy = y0 + fr, ix = x0 + fc;
                 const bool ok = kh1 == 0 && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R;
                 h8 cf = zero;                                                          // (r, g, b, 1, 0, 0, 0, 0) or all zero
@@ -253,16 +264,19 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 cf[2] = (half_t)__builtin_amdgcn_fmed3f(yv[u][2], -1.f, 1.f);
                 cf[3] = (half_t)1.f;
                 if (!ok) cf = zero;
-                const f16x z = mfma32(Wrgb, cf, zacc);                                 // z[4g + q] = x[channel 8g + 4kh + q] of pixel lr, fp32
-                char* dst = smem + ((fr * FP + fc) << 6) + kh1 * 8;
-                const int key = (fc >> 2) & 3;
+                z[u] = mfma32(Wrgb, cf, zacc);                                         // z[4g + q] = x[channel 8g + 4kh + q] of pixel lr, fp32
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                char* dst = smem + ((fr3[u] * FP + fc3[u]) << 6) + kh1 * 8;
+                const int key = (fc3[u] >> 2) & 3;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     h4 v;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (half_t)z[g * 4 + q];
+                    for (int q = 0; q < 4; ++q) v[q] = (half_t)z[u][g * 4 + q];
                     v = __builtin_elementwise_max(v, v * (half_t)0.2f);
-                    if (pxr < FR * FC) *(h4*)(dst + ((g ^ key) << 4)) = v;
+                    *(h4*)(dst + ((g ^ key) << 4)) = v;
                 }
             }
         }
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         if (!D0_ABL(4)) {
             const int r = wave >> 1, nh = wave & 1, ch = nh * 2 + (lane & 1), lrx = lane >> 1;
             h8 hr[4];
-            const int fc0 = min(2 * lrx + 2, FC - 4);
+            const int fc0 = min(2 * lrx + 2, FC - 4);                                  // (lanes past the tile's 29 columns: any columns that exist)
             int xa[4];
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) xa[jx] = swa(2 * r, fc0 + jx, ch);
@@ -307,7 +321,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             if ((unsigned)yh >= (unsigned)R) {                                         // outside the image: the FIR's zero padding
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = zero;
+                    if (4 * jj + i <= XW) *(h8*)(ring + hw4[i]) = zero;
             } else {
                 // the accumulators START at the bias (lane (px, kh) owns channels 8g + 4kh + q): the first version read the bias quads in the
                 // epilogue, eight LDS round trips in a row with nothing to overlap them (2400 of the step's 12 900 clocks)
@@ -346,11 +360,11 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 // (r05: moving the sqrt2 gain into conv1's weight fragments saves 16 of the step's ~880 VALU instructions, changes no
                 // timing — the kernel is not bound by VALU issue, DESIGN section 5 — and re-rounds the weights: D error 5.4e-4 -> 8.1e-4; not kept)
                 const half_t k1 = (half_t)GLASS_SQRT2, k2 = (half_t)(0.2f * GLASS_SQRT2);
-                const bool edge = tx == 0 || 60 * tx + 62 > R;                          // uniform: only the first / last tile column masks
+                const bool edge = tx == 0 || XW * tx + 62 > R;                          // uniform: only the first / last tile column masks
                 auto epi0 = [&](bool masked) {
 #pragma unroll
                     for (int blk = 0; blk < 2; ++blk) {
-                        const bool colok = !masked || (unsigned)(60 * tx - 2 + blk * 32 + lr) < (unsigned)R;
+                        const bool colok = !masked || (unsigned)(XW * tx - 2 + blk * 32 + lr) < (unsigned)R;
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             h4 v;
@@ -381,7 +395,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 D0TRACE(13);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (4 * jj + i <= 60) *(h8*)(ring + hw4[i]) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+                    if (4 * jj + i <= XW) *(h8*)(ring + hw4[i]) = fir4(v[i], v[i + 1], v[i + 2], v[i + 3]);
                 __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
         // ---- P4: vertical FIR over the ring -> operand image A (rows 0 .. 4 = blurred rows 4k .. 4k + 4) -----------------------------------
         {
             const int t = opaque(threadIdx.x);
-            if (t < 244 && !D0_ABL(32)) {
+            if (t < 240 && !D0_ABL(32)) {                                           // ring slots 0 .. 59 (even columns 0 .. 58 | 30 unused | odd columns 1 .. 57)
                 const int base = uni((4 * k + RING) & (RING - 1));                      // ring slot of window row 0 (h row 4k - 2)
                 h8 v[8];
 #pragma unroll
@@ -461,13 +475,13 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
             // this half's 32 channels of a row: pixel-major, or four planes of 8 channels (vector chv = plane chv)
             const int ypix = p.y_planar8 ? 8 : 64;
             const long long yplane = p.y_planar8 ? (long long)Ro * Ro * 8 - 8 : 0;
-            half_t* yrow = p.y_planar8 ? p.y + ((((long long)b * 8 + nh * 4) * Ro + orow) * Ro + 30 * tx) * 8
-                                       : p.y + (((long long)b * Ro + orow) * Ro + 30 * tx) * 64 + nh * 32;
+            half_t* yrow = p.y_planar8 ? p.y + ((((long long)b * 8 + nh * 4) * Ro + orow) * Ro + TW * tx) * 8
+                                       : p.y + (((long long)b * Ro + orow) * Ro + TW * tx) * 64 + nh * 32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
                 const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
-                if (pix < TW && 30 * tx + pix < Ro && orow < Ro && (!D0_ABL(128) || d[0] == (half_t)777.f)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
+                if (pix < TW && TW * tx + pix < Ro && orow < Ro && (!D0_ABL(128) || d[0] == (half_t)777.f)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
             }
             __builtin_amdgcn_wave_barrier();
             D0TRACE(11);

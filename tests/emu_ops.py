@@ -534,13 +534,14 @@ def upfir2(x, w, *, sn=None, dscale=None, noise=None, noise_strength=0.0, batch_
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# conv_d0.hip / dblock0_kernel emulated at the level of its INDEX MATH: 2 x 30 output tiles walked down tile columns, the fromRGB
-# patch F (6 x 66 px, column-keyed chunk swizzle) built by one MFMA per 32-pixel block, conv0 per wave = one new h row (2 x 32 px
+# conv_d0.hip / dblock0_kernel emulated at the level of its INDEX MATH: 2 x 29 output tiles walked down tile columns, the fromRGB
+# patch F (6 x 64 px at a pitch of 66, column-keyed chunk swizzle) built by one MFMA per 32-pixel block, conv0 per wave = one new h row (2 x 32 px
 # blocks) with the weight fragments in registers, wave-local horizontal FIR through the per-wave row image into the 8-row ring of
 # de-interleaved rows, vertical FIR into the operand image (aliases F), stride-2 conv per (row, n half) wave + skip MFMAs from the
 # 3-row XS ring (filled one output row ahead), priming steps at every range / column start.  Constants and address functions
 # mirror the kernel's namespace.
-_D0_NW, _D0_FR, _D0_FC, _D0_FP, _D0_RING, _D0_AR, _D0_XSR = 4, 6, 66, 66, 8, 5, 3
+_D0_NW, _D0_FR, _D0_FC, _D0_FP, _D0_RING, _D0_AR, _D0_XSR = 4, 6, 64, 66, 8, 5, 3
+_D0_TW = 29; _D0_XW = 2 * _D0_TW      # output columns per tile / h columns a tile advances by (round 6: 30 -> 29, twelve full patch blocks)
 _D0_OFF_F = 0
 _D0_OFF_RT = _D0_FR * _D0_FP * 64
 _D0_OFF_HB = _D0_OFF_RT + _D0_NW * 4096
@@ -565,7 +566,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
     B, _, R, _ = y.shape
     assert R % 4 == 0
     Ro = R // 2
-    tiles_x, tiles_y = (Ro + 29) // 30, R // 4
+    tiles_x, tiles_y = (Ro + _D0_TW - 1) // _D0_TW, R // 4
     pk0 = real_ops.host_pack_conv(w0, False).astype(f16)        # [9][32][32]
     pk1 = real_ops.host_pack_conv(w1, False).astype(f16)        # [9][64][32]
     pks = (real_ops.host_pack_conv(wskip, False).astype(f32) * f32(0.70710678118654752440)).astype(f16)[0]   # [64][32]
@@ -599,8 +600,8 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
     NPX = _D0_FR * _D0_FC
 
     def run_item(b, tx, k, prime):
-        y0, x0 = 4 * k + 1, 60 * tx - 3            # image row / column of F[0][0]
-        # ---- P1: fromRGB patch as an MFMA per 32-pixel block (block i of 13 -> wave i % 4); lane half 0 carries (r, g, b, 1) ------------
+        y0, x0 = 4 * k + 1, _D0_XW * tx - 3            # image row / column of F[0][0]
+        # ---- P1: fromRGB patch as an MFMA per 32-pixel block (block i of 12 -> wave i % 4); lane half 0 carries (r, g, b, 1) ------------
         for blk in range((NPX + 31) // 32):
             px = 32 * blk + np.arange(32)
             px = px[px < NPX]
@@ -635,7 +636,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
             if yh < 0 or yh >= R:
                 for i in range(4):
                     cb = 4 * jj + i
-                    m = cb <= 60
+                    m = cb <= _D0_XW
                     wr((ring + _d0_swz(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], np.zeros((int(m.sum()), 8), f16))
                 continue
             acc = np.zeros((2, 32, 32), np.float64)
@@ -648,7 +649,7 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
                             acc[blk] += wf @ frag_to_mat(xf).T
             for blk in range(2):
                 col = blk * 32 + lr
-                xh = 60 * tx - 2 + col
+                xh = _D0_XW * tx - 2 + col
                 colok = (xh >= 0) & (xh < R)
                 for g in range(4):
                     quad = np.stack([acc[blk, 8 * g + 4 * kh[i]:8 * g + 4 * kh[i] + 4, lr[i]] for i in range(64)]).astype(f32)
@@ -665,13 +666,13 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
                 v.append(np.where((c < 64)[:, None], val, f16(0)))
             for i in range(4):
                 cb = 4 * jj + i
-                m = cb <= 60
+                m = cb <= _D0_XW
                 o = _fir4(v[i], v[i + 1], v[i + 2], v[i + 3])
                 wr((ring + _d0_swz(np.where(cb & 1, 31 + (cb >> 1), cb >> 1), cgl))[m], o[m])
         if prime:
             return
         # ---- P4: vertical FIR over the ring -> operand image A (aliases F) ------------------------------------------------------
-        tt = t[t < 244]
+        tt = t[t < 240]
         off = _d0_swz(tt >> 2, tt & 3)
         rows = [rd(_D0_OFF_HB + ((4 * k + i) % _D0_RING) * 4096 + off) for i in range(8)]        # window row i = h row 4k - 2 + i
         for br in range(_D0_AR):
@@ -702,9 +703,9 @@ def dblock0(y, frgb_w, frgb_b, w0, b0, w1, wskip, b1, n_wg=3, device=0, impl=0):
                 vv = lane + 64 * kq
                 pix, chv = vv >> 2, vv & 3
                 data = rd(rt + _d0_swz(pix, chv))
-                ox = 30 * tx + pix
+                ox = _D0_TW * tx + pix
                 for i in range(64):
-                    if pix[i] < 30 and ox[i] < Ro and o_row < Ro:
+                    if pix[i] < _D0_TW and ox[i] < Ro and o_row < Ro:
                         a = ((((b * 8 + nh * 4 + chv[i]) * Ro + o_row) * Ro + ox[i]) * 8 if planar
                              else ((b * Ro + o_row) * Ro + ox[i]) * 64 + nh * 32 + chv[i] * 8)
                         assert np.isnan(out[a]), "output written twice"
