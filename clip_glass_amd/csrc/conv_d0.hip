@@ -77,6 +77,8 @@ __device__ __forceinline__ h8 fir4(h8 a, h8 b, h8 c, h8 d) {   // [1,3,3,1]/8, p
     return (a + d) * (half_t)0.125f + (b + c) * (half_t)0.375f;
 }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+typedef unsigned u2x __attribute__((ext_vector_type(2)));
+typedef unsigned u4x __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 }  // namespace
 
@@ -462,6 +464,29 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
                 if (!D0_ABL(64)) acc = mfma32(Wsf[kk], *(const h8*)(smem + OFF_XS + xslot * 2048 + swz(lr, kk * 2 + kh)), acc);
+            const int orow = 2 * k + r;
+            if (p.y_planar8) {
+                // chunk-planar output (four planes of 8 channels per n half): lane (px, kh) holds channels 4kh .. 4kh + 3 of planes g = 0 .. 3 —
+                // v_permlane32_swap hands a lane pair one whole plane each (lower lane: plane 2 pr, upper lane: plane 2 pr + 1) and the 16-byte
+                // stores leave from the registers: 32 lanes x 16 contiguous bytes per plane, no trip through the row image (round 6)
+                const long long plane = (long long)Ro * Ro * 8;
+                half_t* ypx = p.y + ((((long long)b * 8 + nh * 4 + kh) * Ro + orow) * Ro + TW * tx + lr) * 8;
+                const bool on = lr < TW && TW * tx + lr < Ro && orow < Ro;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    u2x lo, hi;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        h2 a = {(half_t)acc[(2 * pr) * 4 + 2 * e], (half_t)acc[(2 * pr) * 4 + 2 * e + 1]};
+                        h2 c = {(half_t)acc[(2 * pr + 1) * 4 + 2 * e], (half_t)acc[(2 * pr + 1) * 4 + 2 * e + 1]};
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, c), false, false);
+                        lo[e] = sw[0];
+                        hi[e] = sw[1];
+                    }
+                    const u4x d = {lo[0], lo[1], hi[0], hi[1]};
+                    if (on && (!D0_ABL(128) || d[0] == 777u)) *(u4x*)(ypx + 2 * pr * plane) = d;
+                }
+            } else {
             // transposition through the wave's row image (32 px x 64 B), then 16-byte stores in row order
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -471,19 +496,15 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 *(h4*)(smem + OFF_RT + wave * ROWB + swz(lr, g) + kh * 8) = o;
             }
             __builtin_amdgcn_wave_barrier();
-            const int orow = 2 * k + r;
-            // this half's 32 channels of a row: pixel-major, or four planes of 8 channels (vector chv = plane chv)
-            const int ypix = p.y_planar8 ? 8 : 64;
-            const long long yplane = p.y_planar8 ? (long long)Ro * Ro * 8 - 8 : 0;
-            half_t* yrow = p.y_planar8 ? p.y + ((((long long)b * 8 + nh * 4) * Ro + orow) * Ro + TW * tx) * 8
-                                       : p.y + (((long long)b * Ro + orow) * Ro + TW * tx) * 64 + nh * 32;
+            half_t* yrow = p.y + (((long long)b * Ro + orow) * Ro + TW * tx) * 64 + nh * 32;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int v = lane + 64 * u, pix = v >> 2, chv = v & 3;
                 const h8 d = *(const h8*)(smem + OFF_RT + wave * ROWB + swz(pix, chv));
-                if (pix < TW && TW * tx + pix < Ro && orow < Ro && (!D0_ABL(128) || d[0] == (half_t)777.f)) *(h8*)(yrow + pix * ypix + chv * 8 + chv * yplane) = d;
+                if (pix < TW && TW * tx + pix < Ro && orow < Ro && (!D0_ABL(128) || d[0] == (half_t)777.f)) *(h8*)(yrow + pix * 64 + chv * 8) = d;
             }
             __builtin_amdgcn_wave_barrier();
+            }
             D0TRACE(11);
         }
         ++n_item;
