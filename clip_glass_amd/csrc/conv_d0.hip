@@ -346,6 +346,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                         for (int blk = 0; blk < 2; ++blk) d[kk * 2 + blk] = *(const h8*)(smem + fb[kx][kk] + ky * (FP * 64) + blk * 2048);
                 };
                 if (!D0_ABL(8)) rd4(0, xq[0]);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     if (D0_ABL(8)) break;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                         for (int blk = 0; blk < 2; ++blk) acc[blk] = mfma32(W0f[tap][kk], xq[tap & 1][kk * 2 + blk], acc[blk]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                __builtin_amdgcn_s_setprio(0);
                 D0TRACE(5);
                 // bias + lrelu * sqrt2 exactly as conv_stream<fromrgb> formed h: fp32 sum -> fp16 -> max(v k1, v k2) in packed fp16
                 // (r05: moving the sqrt2 gain into conv1's weight fragments saves 16 of the step's ~880 VALU instructions, changes no
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int kk = 0; kk < 2; ++kk) d[kk] = *(const h8*)(smem + sb[kx][kk] + ky * ROWB);
             };
             if (!D0_ABL(64)) { rd2(0, xq[0]); rd2(1, xq[1]); }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 if (D0_ABL(64)) break;
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(NTHR, 2) void dblock0_kernel(D0Params p, int tiles_
                 for (int kk = 0; kk < 2; ++kk) acc = mfma32(W1f[tap][kk], xq[tap % 3][kk], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
             D0TRACE(10);
             // lrelu; its sqrt2 gain cancels against the merge's 1/sqrt2.  As f4 arithmetic: v_pk_mul_f32 + v_max_f32 (24 instructions; the
             // scalar fmaxf form compiled to 48: a canonicalising v_max per operand)

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                 // ---- MFMAs ---------------------------------------------------------------------------------------------------------
                 const int tm = opq(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1;
                 const char* Ws = smem + OFF_W + slot * W_SLOT;
+                __builtin_amdgcn_s_setprio(1);
                 if (f < 3) {
                     const int ky = f == 0 ? 1 : (f == 1 ? 0 : 2);
                     const char* As = smem + (f == 0 ? OFF_ODD : OFF_EVEN);
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(512, 1) void conv_s2_kernel(ConvParams p, int NTn, 
                             for (int j = 0; j < 2; ++j) acs[i][j] = mfma32(wf[j], xf[i], acs[i][j]);
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
                 S2TRACE(4);
                 if (TR) ++gst;
                 slot = slot == 2 ? 0 : slot + 1;

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
         const int tm = opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, wave = tm >> 6, lane = tm & 63;
         char* Os = smem + W_BYTES + A_BYTES + wave * (32 * 64);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(256, 3) void conv_stream_kernel(ConvParams p, int t
                     }
                 }
             }
+        __builtin_amdgcn_s_setprio(0);
 
         STRACE(5);
         if (FRGB && p.rgb_xs_out && valid) {

@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
         auto mfma_block = [&]() {
             if (U_ABL(1)) return;
             const int tm = u_opaque(threadIdx.x), lr = tm & 31, kh = (tm >> 5) & 1, wave = tm >> 6;
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         };
         const int n_stages = p.Cin >> 5;
         for (int s = 0; s + 1 < n_stages; ++s) {
