@@ -889,14 +889,16 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
     g.tiles_x = (2 * PX * g.NXI - 2 + 59) / 60;
     const int out_rows = 2 * PY * g.NYI - 2;
     // steps per segment: as long as possible (only a segment's first step recomputes the t halo) while the launch still has
-    // >= 8 workgroups per CU-slot pair to balance (2048); never longer than the grid
-    int S = 16 / RW;
+    // >= 8 workgroups per CU-slot pair to balance (2048) — >= 20 (5120) for segments longer than 8 steps, whose workgroups run twice as
+    // long (round 6, same box: the r1024 layer 1955 -> 1880 us at S = 16, 5760 workgroups; the r512 layer 1377 -> 1420 us at its 3456:
+    // it stays at S = 8); never longer than the grid
+    int S = 32 / RW;
+    if (RW == 2 && S > 16) S = 16;
     for (; S > 1; --S) {
         const int R = (TR - 4) + TR * (S - 1);
         const long long wgs = (long long)g.n_grids * g.tiles_x * ((out_rows + R - 1) / R) * g.NTn;
-        if (wgs >= 2048 && R <= out_rows + TR - 1) break;
+        if (wgs >= (S > 8 ? 5120 : 2048) && R <= out_rows + TR - 1) break;
     }
-    if (RW == 2 && S > 8) S = 8;
     if (env_s > 0) S = env_s;
     g.S = S;
     const int R = (TR - 4) + TR * (S - 1);
