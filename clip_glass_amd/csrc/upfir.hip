@@ -19,6 +19,9 @@
 #include "common.h"
 #include "kernels.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 #define ROWB 80
 typedef unsigned int u4v __attribute__((ext_vector_type(4)));
@@ -861,6 +864,45 @@ __global__ __launch_bounds__(256, 4 - RW) void upfir2_kernel(ConvParams p, UpGeo
 
 static unsigned u_inv(int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
 
+// steps per segment of the image-grid instance by a list-scheduling model (see launch_upfir2_t); per_seg = workgroups per segment
+// index, fallback = the count-rule's answer (kept when no length fills the slots).  Cached per geometry: the launcher runs every pass.
+static int upfir2_model_steps(int per_seg, int out_rows, int TR, int slots, int fallback) {
+    struct Key { int per_seg, out_rows, slots, S; };
+    static std::mutex mu;
+    static std::vector<Key> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Key& k : cache)
+        if (k.per_seg == per_seg && k.out_rows == out_rows && k.slots == slots) return k.S;
+    int best = fallback;
+    double best_t = 1e30;
+    std::vector<double> heap;
+    for (int S = 1; S <= 16; ++S) {
+        const int R = (TR - 4) + TR * (S - 1);
+        if (R > out_rows + TR - 1 && S > 1) break;
+        const int n_seg = (out_rows + R - 1) / R;
+        if ((long long)per_seg * n_seg < slots) break;             // longer segments would leave slots empty
+        heap.assign(slots, 0.0);                                    // min-heap of slot finish times
+        auto cmp = [](double a, double b) { return a > b; };
+        for (int seg = 0; seg < n_seg; ++seg) {
+            int steps = 0;
+            for (int st = 0; st < S; ++st) {
+                if (seg * R + (st ? TR * st - 4 : 0) >= out_rows) break;
+                ++steps;
+            }
+            for (int w = 0; w < per_seg; ++w) {
+                std::pop_heap(heap.begin(), heap.end(), cmp);
+                heap.back() += steps + 0.5;
+                std::push_heap(heap.begin(), heap.end(), cmp);
+            }
+        }
+        double t = 0;
+        for (double v : heap) t = v > t ? v : t;
+        if (t < best_t - 1e-9) { best_t = t; best = S; }
+    }
+    cache.push_back({per_seg, out_rows, slots, best});
+    return best;
+}
+
 // RW = m rows per wave: 2 = the two-workgroup step (8 m rows), 1 = the half-height step of the single-image instance (three workgroups per CU)
 template <int RW>
 static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lean) {
@@ -899,6 +941,13 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
         const long long wgs = (long long)g.n_grids * g.tiles_x * ((out_rows + R - 1) / R) * g.NTn;
         if (wgs >= (S > 8 ? 5120 : 2048) && R <= out_rows + TR - 1) break;
     }
+    // image-grid instance (round 6): the rule above left the low-resolution layers at S = 1 / 2 / 4 (25 / 12 / 6 % of their rows recomputed as
+    // halo) for the sake of a workgroup count they do not need.  A sweep of S (tools: GLASS_UPFIR_S on the developer build, medians of 5) follows
+    // a plain list-scheduling model — workgroups of (steps + 1/2) step times dealt in launch order to 2 x CUs slots — closely (r64: minima at
+    // S = 5 and 10, maximum at 8, as measured: 457 / 455 / 588 us against 514 at the old S = 2; r32: 183 -> 143 us at S = 3): S = the model's
+    // minimum among the lengths that still fill every slot once — where the count rule ends at S <= 2 (at S = 4 / 8, r128 / r256, the model's pick measured
+    // 1-3 % slower than the rule's: those launches have enough rounds to average out).  (S only decides which t rows are recomputed: results do not depend on it.)
+    if (!lean && RW == 2 && S <= 2) S = upfir2_model_steps(g.n_grids * g.tiles_x * g.NTn, out_rows, TR, 2 * glass_cu_count(), S);
     if (env_s > 0) S = env_s;
     g.S = S;
     const int R = (TR - 4) + TR * (S - 1);
