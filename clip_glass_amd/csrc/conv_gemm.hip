@@ -103,10 +103,24 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
     const long long M = (long long)p.B * p.Hc * p.Wc, K = (long long)p.KS * p.KS * p.Cin;
     if ((long long)p.Hc * p.Wc * K > cap_a || (long long)p.Hc * p.Wc * p.Neff > cap_c || M * K >= (1LL << 31)) return nullptr;
     const long long n_vec = M * K / 8, n_quad = M * p.Neff / 4;
-    hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
+    // a 1x1 convolution of an un-modulated, contiguous map IS its patch matrix (the D blocks' skip branches: the im2col pass was a copy);
+    // with nothing to do after the product either (no demodulation / noise / bias / activation / residual / gain) the GEMM's own fp16
+    // store (mode 0: the same (half_t) rounding of the same fp32 sum) is the finishing pass: one launch instead of three (round 6)
+    const bool direct_a = p.KS == 1 && p.stride == 1 && p.pad == 0 && !p.sn && !p.pre_shift && !p.in_up && p.H == p.Hc && p.W == p.Wc &&
+                          p.x_bstride == (long long)p.Hc * p.Wc * p.Cin;
+    const bool direct_y = direct_a && !p.up && !p.dscale && !p.noise && !p.bias && !p.shift && p.act == 0 && !p.res && p.out_scale == 1.f &&
+                          p.Ho == p.Hc && p.Wo == p.Wc && p.Neff == p.Cout;
+    if (p.dry_run) return direct_y ? "gemm_tiled_kernel" : "conv_gemm(im2col+gemm_tiled+finish)";
+    if (!direct_a) hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
     GemmParams g;
     memset(&g, 0, sizeof g);
-    g.a = ws_a; g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
+    g.a = direct_a ? p.x : ws_a; g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
+    if (direct_y) {
+        g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;
+        g.mode = 0; g.out16 = p.y; g.ldo = p.Cout;
+        g.cand_rows = p.Hc * p.Wc;
+        if (const char* k = launch_gemm_tiled(g, st)) return k;
+    }
     g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;        // weights stay [tap][n][Cin]; (kpt: any M is accepted —
                                                                       // the kernel choice must not depend on the candidate count)
     g.mode = 3; g.out32 = ws_c; g.ldo = p.Neff;
