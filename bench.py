@@ -343,6 +343,7 @@ def main():
     ap.add_argument("--pop", type=int, default=POP)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-pop", type=int, default=BATCH, help="candidates in the CPU baseline sample (multiple of 4; 64 = the whole headline population, ~4 min)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=150.0, help="seconds the CPU baseline's sweep + fresh calls may spend (a P = 64 sweep needs ~1500)")
     ap.add_argument("--cpu-baseline-threads", type=int, default=0, help="torch intra-op threads of the CPU baseline (0 = sweep 8/16/32/64/128 and report the best)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--no-legs", action="store_true", help="headline only: skip the biggan512 / gpt2 legs attached to the default line")
@@ -593,7 +594,7 @@ def main():
                    # ... D2H of F): checkable against `ms_per_step` even when an smi sampler misses the ~1 s window
                    gpu_active_s=gpu_ms * 1e-3, gpu_active_frac_of_timed_region=gpu_ms * 1e-3 / dt)
         if world == 1 and not args.no_cpu_baseline and not biggan:
-            out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH),
+            out["cpu_baseline"] = cpu_baseline(sd, cfg, target, pop=max(BATCH, args.cpu_baseline_pop // BATCH * BATCH), budget_s=args.cpu_baseline_budget,
                                                threads=((args.cpu_baseline_threads,) if args.cpu_baseline_threads else (8, 16, 32, 64, 128)))
         if world == 1 and args.config == "ffhq" and not args.no_legs and dist is None:
             # the other single-GPU configs of BASELINE.json (configs[2] DeepMindBigGAN512, configs[4] GPT2) as short legs of the

@@ -922,7 +922,10 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
     // candidates per virtual grid: per-sample weights -> one (its tiles share a weight set); shared weights -> up to 8 x 8
     if (p.w_bstride || no_grid) { g.NXI = 1; g.NYI = 1; }
     else {
-        g.NXI = p.B < 8 ? p.B : 8;
+        // a tile's 33-pixel patch must not touch more than the FOUR images a table row holds: at pitches below 11 (the 8 x 8 input of the
+        // r16 layer, round 6) a virtual row is three images wide — one 30-column tile covers it
+        const int nxi_max = p.W + 1 >= 11 ? 8 : 3;
+        g.NXI = p.B < nxi_max ? p.B : nxi_max;
         g.NYI = (p.B + g.NXI - 1) / g.NXI;
         if (g.NYI > 8) g.NYI = 8;
     }
@@ -1003,7 +1006,7 @@ static const char* launch_upfir2_t(const ConvParams& p, hipStream_t st, bool lea
 }
 
 static const char* launch_upfir2(const ConvParams& p, hipStream_t st) {
-    if (p.Cin > 512 || p.H < 8 || p.W < 16) return nullptr;
+    if (p.Cin > 512 || p.H < 8 || p.W < 8) return nullptr;
     if ((long long)p.B * p.H * p.W * p.Cin >= (1LL << 31) || 9LL * p.Cout * p.Cin >= (1LL << 31)) return nullptr;
     if (p.x_bstride != (long long)p.H * p.W * p.Cin) return nullptr;
     static const bool no_grid = glass_knob("GLASS_UPFIR_NO_GRID") != nullptr;

@@ -407,7 +407,7 @@ def upfir2_geometry(B, H, W, Cout, per_sample_weights=False, S=None):
     if per_sample_weights:
         NXI = NYI = 1
     else:
-        NXI = min(B, 8)
+        NXI = min(B, 8 if W + 1 >= 11 else 3)      # (round 6: a 33-pixel patch touches at most four images — three per row at pitches below 11)
         NYI = min((B + NXI - 1) // NXI, 8)
     n_grids = (B + NXI * NYI - 1) // (NXI * NYI)
     PX, PY = W + 1, H + 1

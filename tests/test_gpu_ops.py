@@ -399,6 +399,9 @@ def test_conv_modulated_up(impl):
     (20, 16, 32, 96, 1),     # 8 x 3 grid, three n tiles
     (70, 16, 32, 32, 2),     # two grids (8 x 8 + 6)
     (3, 64, 96, 64, 1),      # three chunks, rolling segments inside one image row
+    (5, 8, 32, 32, 1),       # 8 x 8 images (the r16 layer, round 6): three per virtual row, a tile spans all of them
+    (26, 8, 64, 96, 2),      # two grids of 3 x 8 (+ 2), three n tiles
+    (64, 8, 32, 32, 4),      # the population's geometry: 3 x 8 grids, the last one with 16 images
 ])
 def test_conv_up_virtual_grid(B, H, Cin, Cout, bs):
     """upfir2_kernel (round 3): tiles and strips run across the candidates of a launch (csrc/upfir.hip)."""

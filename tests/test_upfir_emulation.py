@@ -25,6 +25,8 @@ def h16(a):
     (3, 24, 40, 32, 64, 3, False),        # odd sizes, two n tiles
     (2, 32, 32, 32, 32, 2, True),         # per-sample weights: one image per grid
     (9, 16, 16, 32, 32, 1, False),        # 8 x 2 grid with seven empty slots, one step per segment
+    (7, 8, 8, 32, 32, 2, False),          # 8 x 8 images (the r16 layer): 3 x 3 grid with two empty slots, one tile across the whole row
+    (26, 8, 8, 32, 32, 1, False),         # two grids of 3 x 8 (+ 2)
 ])
 def test_upfir2_geometry_emulation(B, H, W_, Cin, Cout, S, per_sample):
     L, bs = 16, 1
