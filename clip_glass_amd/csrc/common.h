@@ -249,6 +249,10 @@ struct GemmParams {
     long long a_bs, w_bs, o_bs;
     int cand_rows;          // rows of M one candidate contributes (0: M does not scale with the population) and
     int cand_batch;         // 1: blockIdx.z walks candidates — the tile-width choice is made at the nominal population (GLASS_NOMINAL_POP)
+    // implicit patch matrix (conv_gemm.hip, round 6; gemm_tiled only): row m = (b, oy, ox) of the conv grid, column k = (tap, ci) —
+    // A[m][k] = x[b][oy * g_stride + ty - g_pad][ox * g_stride + tx - g_pad][ci] (zero outside the image), a = x, K steps never straddle a tap
+    int g_on, g_h, g_w, g_hc, g_wc, g_stride, g_pad, g_ks, g_cin;
+    long long g_xbs;        // elements between the images of x
     int ld;                 // 0: rows of a and w are K long.  > 0: their row stride (a K slice of longer rows: split-K as `batch` slices,
                             // a_bs = w_bs = K, raw partial sums to out32 + z * o_bs; gemm_tiled only.  With kpt: w_bs = 0, slice z starts at k = z * K of the tap walk)
 };

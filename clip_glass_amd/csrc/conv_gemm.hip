@@ -111,10 +111,19 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
     const bool direct_y = direct_a && !p.up && !p.dscale && !p.noise && !p.bias && !p.shift && p.act == 0 && !p.res && p.out_scale == 1.f &&
                           p.Ho == p.Hc && p.Wo == p.Wc && p.Neff == p.Cout;
     if (p.dry_run) return direct_y ? "gemm_tiled_kernel" : "conv_gemm(im2col+gemm_tiled+finish)";
-    if (!direct_a) hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
+    // no activation-side transform of the input (the D blocks' convolutions): the GEMM's loader walks the map itself (GemmParams::g_*,
+    // gemm_tiled_kernel<.., gather>) — the patch matrix, a 9x copy of the map written to HBM and read back, is never materialised (round 6)
+    static const bool no_gather = glass_knob("GLASS_CONV_GEMM_NO_GATHER") != nullptr;   // A/B knob
+    bool gather = !no_gather && !direct_a && !p.sn && !p.pre_shift && !p.in_up && p.Cin % 64 == 0;
     GemmParams g;
     memset(&g, 0, sizeof g);
-    g.a = direct_a ? p.x : ws_a; g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
+    auto set_gather = [&](bool on) {
+        g.g_on = on ? 1 : 0;
+        g.a = on || direct_a ? p.x : ws_a;
+        if (on) { g.g_h = p.H; g.g_w = p.W; g.g_hc = p.Hc; g.g_wc = p.Wc; g.g_stride = p.stride; g.g_pad = p.pad; g.g_ks = p.KS; g.g_cin = p.Cin; g.g_xbs = p.x_bstride; }
+    };
+    set_gather(gather);
+    g.w = p.w; g.M = (int)M; g.N = p.Neff; g.K = (int)K;
     if (direct_y) {
         g.kpt = p.Cin; g.w_tap_stride = (long long)p.Neff * p.Cin;
         g.mode = 0; g.out16 = p.y; g.ldo = p.Cout;
@@ -136,11 +145,24 @@ const char* launch_conv_gemm(const ConvParams& p, half_t* ws_a, long long cap_a,
         while (S > 1 && (K % (64LL * S) != 0 || (long long)S * px * p.Neff > cap_c)) S >>= 1;
     }
     const long long slab = M * p.Neff;
-    if (S > 1) { g.ld = (int)K; g.K = (int)(K / S); g.batch = S; g.a_bs = g.K; g.w_bs = 0; g.o_bs = slab; }
-    if (!launch_gemm_tiled(g, st)) {
+    if (S > 1) { g.ld = (int)K; g.K = (int)(K / S); g.batch = S; g.a_bs = gather ? 0 : g.K; g.w_bs = 0; g.o_bs = slab; }
+    const char* gk = nullptr;
+    if (gather) {
+        gk = launch_gemm_tiled(g, st);
+        if (!gk) {                             // the gather instance refused: materialise the patch matrix after all
+            gather = false;
+            set_gather(false);
+            if (S > 1) g.a_bs = g.K;
+        }
+    }
+    if (!gk) {
+        if (!direct_a) hipLaunchKernelGGL(conv_im2col_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, st, p, ws_a, n_vec);
+        gk = launch_gemm_tiled(g, st);
+    }
+    if (!gk) {
         if (S > 1) { S = 1; g.ld = 0; g.K = (int)K; g.batch = 0; g.a_bs = g.o_bs = 0; }
         if (!launch_gemm_tiled(g, st)) launch_gemm_direct(g, st);
     }
     hipLaunchKernelGGL(conv_finish_kernel, dim3((unsigned)((n_quad + 255) / 256)), dim3(256), 0, st, p, ws_c, n_quad, S, slab);
-    return "conv_gemm(im2col+gemm_tiled+finish)";
+    return gather ? "conv_gemm(gather+gemm_tiled+finish)" : "conv_gemm(im2col+gemm_tiled+finish)";
 }

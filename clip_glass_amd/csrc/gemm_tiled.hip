@@ -10,7 +10,9 @@
 
 #define GROWB 144
 
-template <int BN>
+// GATHER (round 6): the A operand is the IMPLICIT patch matrix of a convolution (GemmParams::g_*): the loader walks x itself, the im2col
+// pass of conv_gemm.hip (a 9x copy of the map to HBM and back) disappears for the layers without an activation-side style
+template <int BN, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
     if (p.batch > 1) {   // batched problems (BigGAN self-attention): one z-slice per problem
         p.a += (long long)blockIdx.z * p.a_bs;
@@ -39,7 +41,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
     const int part = t & 7;                      // which 16-byte piece of the 128-byte row chunk
 
     h8 ra[NA], rb[NB];
+    long long gbase[GATHER ? NA : 1];            // GATHER: this thread's rows of the conv grid — element offset of tap (0, 0), its input row / column
+    int giy[GATHER ? NA : 1], gix[GATHER ? NA : 1], okm = 0;   // okm bit k: vector k of the stage in registers lies inside the image
+    if (GATHER) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int row = min(m0 + (t >> 3) + 32 * k, p.M - 1), hw = p.g_hc * p.g_wc;
+            const int b = row / hw, rem = row - b * hw, oy = rem / p.g_wc, ox = rem - oy * p.g_wc;
+            giy[k] = oy * p.g_stride - p.g_pad;
+            gix[k] = ox * p.g_stride - p.g_pad;
+            gbase[k] = (long long)b * p.g_xbs + ((long long)giy[k] * p.g_w + gix[k]) * p.g_cin + part * 8;
+        }
+    }
     auto load = [&](int k0) {
+        const int kw = k0 + ((p.kpt && p.ld) ? (int)blockIdx.z * p.K : 0);   // split-K over a packed conv weight: this slice's first k
+        if (GATHER) {
+            const int tap = kw / p.g_cin, ci = kw - tap * p.g_cin, ty = tap / p.g_ks, tx = tap - ty * p.g_ks;      // uniform
+            const long long toff = ((long long)ty * p.g_w + tx) * p.g_cin + ci;
+            okm = 0;
+#pragma unroll
+            for (int k = 0; k < NA; ++k) {     // unconditional loads at a valid address; the zero padding is applied when the vector goes to LDS
+                const bool ok = (unsigned)(giy[k] + ty) < (unsigned)p.g_h && (unsigned)(gix[k] + tx) < (unsigned)p.g_w;
+                ra[k] = *(const h8*)(p.a + (ok ? gbase[k] + toff : (long long)part * 8));
+                okm |= (ok ? 1 : 0) << k;
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
             // unconditional (rows past M read row M - 1; their outputs are never stored): a conditional load costs a
@@ -47,8 +73,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
             const int row = min(m0 + (t >> 3) + 32 * k, p.M - 1);
             ra[k] = *(const h8*)(p.a + (long long)row * (p.ld ? p.ld : p.K) + k0 + part * 8);
         }
+        }
         const int rs = p.kpt ? p.kpt : (p.ld ? p.ld : p.K);      // weight row stride; a conv weight is walked tap by tap
-        const int kw = k0 + ((p.kpt && p.ld) ? (int)blockIdx.z * p.K : 0);   // split-K over a packed conv weight: this slice's first k
         const half_t* wk = p.kpt ? p.w + (long long)(kw / p.kpt) * p.w_tap_stride + (kw % p.kpt) : p.w + k0;   // uniform
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -57,8 +83,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tiled_kernel(GemmParams p) {
         }
     };
     auto store = [&]() {
+        const h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < NA; ++k) *(h8*)(As + ((t >> 3) + 32 * k) * GROWB + part * 16) = ra[k];
+        for (int k = 0; k < NA; ++k) *(h8*)(As + ((t >> 3) + 32 * k) * GROWB + part * 16) = (!GATHER || ((okm >> k) & 1)) ? ra[k] : zero;
 #pragma unroll
         for (int k = 0; k < NB; ++k) *(h8*)(Bs + ((t >> 3) + 32 * k) * GROWB + part * 16) = rb[k];
     };
@@ -158,11 +185,20 @@ const char* launch_gemm_tiled(const GemmParams& p, hipStream_t st) {
     const long long gx_n = p.cand_rows ? ((long long)p.cand_rows * GLASS_NOMINAL_POP + 127) / 128 : gx;
     const long long gz_n = p.cand_batch ? GLASS_NOMINAL_POP : gz;
     const bool fills = gx_n * (p.N / 128) * gz_n >= 256;
+    if (p.g_on && (!p.kpt || p.kpt != p.g_cin || p.g_cin % 64 != 0)) return nullptr;      // (a K step must sit inside one tap)
     if (p.N % 128 == 0 && (fills || wide_only)) {
+        if (p.g_on) {
+            hipLaunchKernelGGL((gemm_tiled_kernel<128, true>), dim3(8 * ((gx * (p.N / 128) + 7) / 8), 1, gz), dim3(256), 0, st, p);
+            return "gemm_tiled_kernel<128,true>";
+        }
         hipLaunchKernelGGL(gemm_tiled_kernel<128>, dim3(8 * ((gx * (p.N / 128) + 7) / 8), 1, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<128>";
     }
     if (p.N % 64 == 0) {
+        if (p.g_on) {
+            hipLaunchKernelGGL((gemm_tiled_kernel<64, true>), dim3(8 * ((gx * (p.N / 64) + 7) / 8), 1, gz), dim3(256), 0, st, p);
+            return "gemm_tiled_kernel<64,true>";
+        }
         hipLaunchKernelGGL(gemm_tiled_kernel<64>, dim3(8 * ((gx * (p.N / 64) + 7) / 8), 1, gz), dim3(256), 0, st, p);
         return "gemm_tiled_kernel<64>";
     }

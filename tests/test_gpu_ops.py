@@ -166,10 +166,11 @@ def test_conv_s2_dma_ring(B, R, Cin, Cout):
     _stride2_skip_case(B, R, Cin, Cout, 5, "conv_s2")
 
 
-@pytest.mark.parametrize("case", ["conv8", "up8", "down17", "skip1x1", "const4"])
+@pytest.mark.parametrize("case", ["conv8", "up8", "down17", "skip1x1", "const4", "plain8", "plain4"])
 def test_conv_gemm_matches_direct(case):
     """conv_gemm.hip (im2col + gemm_tiled + finishing pass) for the low-resolution layers against conv_direct: modulated 3x3,
-    folded up-conv with depth-to-space, stride-2 with residual, 1x1, broadcast (learned const) input."""
+    folded up-conv with depth-to-space, stride-2 with residual (gathered patch matrix), 1x1 (one launch), broadcast (learned const) input,
+    un-modulated 3x3 (gathered)."""
     rng = np.random.default_rng(23)
     B, C = 6, 128
     kw = {}
@@ -187,6 +188,10 @@ def test_conv_gemm_matches_direct(case):
     elif case == "skip1x1":
         x = rng.standard_normal((B, 8, 8, C)); w = rng.standard_normal((2 * C, C, 1, 1))
         kw = dict(pad=0)
+    elif case in ("plain8", "plain4"):      # no activation-side style (the D blocks' first convs): the GEMM gathers its patch matrix itself (round 6);
+        R = 8 if case == "plain8" else 4    # zero padding on every border, split-K slices at 4 x 4
+        x = rng.standard_normal((B, R, R, C)); w = rng.standard_normal((C, C, 3, 3))
+        kw = dict(bias=rng.standard_normal(C) * 0.2, act=True)
     else:
         x = rng.standard_normal((1, 4, 4, C)); w = rng.standard_normal((C, C, 3, 3))
         kw = dict(broadcast_x=True, B=16, sn=rng.uniform(0.3, 1.0, (16, C)), dscale=rng.uniform(0.5, 2.0, (16, C)), bias=rng.standard_normal(C) * 0.2, act=True)
